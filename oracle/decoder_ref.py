@@ -1,0 +1,578 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+A plain PyTorch-CPU (fp32) restatement of the wavelet-monodepth decoder hot path, written from the
+reference's *behaviour*; nothing in the product package imports this file.  Only tests/,
+__graft_entry__.smoke() and bench.py's `cpu_baseline` leg may use it, and only as the checker.
+
+Pinning (see DESIGN.md "Oracle"): tests/golden/*.npz were produced in the build container by
+running the reference's own Python modules (tests/golden/make_golden.py) on synth inputs; the test
+suite checks this file against those vectors.  The third-party `pytorch_wavelets` package is absent
+from the reference tree and from this image, so for the Haar transforms the pins are (1) the
+reference authors' closed form `my_iwt_once` (KITTI/networks/decoders/depth_decoder.py:225-239)
+and (2) PyWavelets 1.1.1 idwt2/dwt2 vectors (tests/golden/make_golden_pywt.py).
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+Parameters travel as flat dicts keyed exactly like the reference modules' state_dict.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# Haar wavelets (pytorch_wavelets DWTInverse / DWTForward, wave="haar")
+# --------------------------------------------------------------------------------------------
+
+
+def haar_idwt(yl, yh):
+    """IDWT(wave='haar', mode='zero'), one level.  yl [B,C,h,w], yh [B,C,3,h,w] (LH,HL,HH).
+    Call sites depth_decoder.py:164; closed form depth_decoder.py:225-239."""
+    a = yl
+    b, c, d = yh[:, :, 0], yh[:, :, 1], yh[:, :, 2]
+    B, C, h, w = a.shape
+    out = a.new_empty(B, C, 2 * h, 2 * w)
+    out[:, :, 0::2, 0::2] = (a + b + c + d) * 0.5
+    out[:, :, 0::2, 1::2] = (a + b - c - d) * 0.5
+    out[:, :, 1::2, 0::2] = (a - b + c - d) * 0.5
+    out[:, :, 1::2, 1::2] = (a - b - c + d) * 0.5
+    return out
+
+
+def haar_dwt(x, J=1):
+    """DWT(J, wave='haar', mode='reflect') on even sizes (NYUv2/train.py:258,289).
+    Returns (yl, [yh_fine, ..., yh_coarse]) with yh[k] of shape [B,C,3,h,w]."""
+    yh = []
+    ll = x
+    for _ in range(J):
+        a = ll[:, :, 0::2, 0::2]
+        b = ll[:, :, 0::2, 1::2]
+        c = ll[:, :, 1::2, 0::2]
+        d = ll[:, :, 1::2, 1::2]
+        yh.append(torch.stack([(a + b - c - d) * 0.5, (a - b + c - d) * 0.5, (a - b - c + d) * 0.5], dim=2))
+        ll = (a + b + c + d) * 0.5
+    return ll, yh
+
+
+# --------------------------------------------------------------------------------------------
+# dense building blocks
+# --------------------------------------------------------------------------------------------
+_PAD = {"reflect": "reflect", "reflection": "reflect", "replicate": "replicate", "zero": "constant",
+        "constant": "constant"}
+
+
+def pad1(x, mode):
+    return F.pad(x, (1, 1, 1, 1), mode=_PAD[mode])
+
+
+def conv3x3(x, w, b, pad="reflect"):
+    """Conv3x3: pad by one then a valid 3x3 cross-correlation (KITTI/layers.py:146-161,
+    NYUv2/networks/layers.py:11-32)."""
+    return F.conv2d(pad1(x, pad), w, b)
+
+
+def conv1x1(x, w, b):
+    """Conv1x1 (KITTI/layers.py:164-173)."""
+    return F.conv2d(x, w, b)
+
+
+def up2(x):
+    """nearest x2 (KITTI/layers.py:233-236)."""
+    return F.interpolate(x, scale_factor=2, mode="nearest")
+
+
+def conv_block(x, sd, key, pad):
+    """ConvBlock = Conv3x3 -> Identity -> ELU (KITTI/layers.py:120-143)."""
+    return F.elu(conv3x3(x, sd[key + ".conv.conv.weight"], sd[key + ".conv.conv.bias"], pad))
+
+
+def wave_head(x, sd, key):
+    """nn.Sequential(Conv1x1, LeakyReLU(0.1), Conv3x3(refl)) (depth_decoder.py:104-120)."""
+    t = F.leaky_relu(conv1x1(x, sd[key + ".0.conv.weight"], sd[key + ".0.conv.bias"]), 0.1)
+    return conv3x3(t, sd[key + ".2.conv.weight"], sd[key + ".2.conv.bias"], "reflect")
+
+
+# --------------------------------------------------------------------------------------------
+# KITTI decoders
+# --------------------------------------------------------------------------------------------
+NUM_CH_DEC = [16, 32, 64, 128, 256]
+
+
+def kitti_wave_keys():
+    """("role", i, j) -> index in the reference's nn.ModuleList `decoder`
+    (construction order, depth_decoder.py:88-122)."""
+    keys = {}
+    n = 0
+    for i in range(4, 0, -1):
+        keys[("upconv", i, 0)] = n; n += 1
+        keys[("upconv", i, 1)] = n; n += 1
+        if i == 4:
+            keys[("waveconv", i, 0)] = n; n += 1
+        keys[("waveconv", i, 1)] = n; n += 1
+        keys[("waveconv", i, -1)] = n; n += 1
+    return keys
+
+
+def kitti_wave_param_shapes(num_ch_enc):
+    """state_dict name -> shape for DepthWaveProgressiveDecoder (depth_decoder.py:73-124)."""
+    keys = kitti_wave_keys()
+    shapes = {}
+    for i in range(4, 0, -1):
+        cin0 = int(num_ch_enc[-1]) if i == 4 else NUM_CH_DEC[i + 1]
+        c = NUM_CH_DEC[i]
+        p = "decoder.%d" % keys[("upconv", i, 0)]
+        shapes[p + ".conv.conv.weight"] = (c, cin0, 3, 3)
+        shapes[p + ".conv.conv.bias"] = (c,)
+        p = "decoder.%d" % keys[("upconv", i, 1)]
+        shapes[p + ".conv.conv.weight"] = (c, c + int(num_ch_enc[i - 1]), 3, 3)
+        shapes[p + ".conv.conv.bias"] = (c,)
+        heads = [(0, c // 4, 1)] if i == 4 else []
+        heads += [(1, c, 3), (-1, c, 3)]
+        for j, mid, cout in heads:
+            p = "decoder.%d" % keys[("waveconv", i, j)]
+            shapes[p + ".0.conv.weight"] = (mid, c, 1, 1)
+            shapes[p + ".0.conv.bias"] = (mid,)
+            shapes[p + ".2.conv.weight"] = (cout, mid, 3, 3)
+            shapes[p + ".2.conv.bias"] = (cout,)
+    return shapes
+
+
+def kitti_wave_coefficients(x, sd, keys, i, with_ll):
+    """get_coefficients (depth_decoder.py:126-136)."""
+    yl = None
+    if with_ll:
+        yl = 2 ** i * torch.sigmoid(wave_head(x, sd, "decoder.%d" % keys[("waveconv", i, 0)]))
+    pos = torch.sigmoid(wave_head(x, sd, "decoder.%d" % keys[("waveconv", i, 1)])).unsqueeze(1)
+    neg = torch.sigmoid(wave_head(x, sd, "decoder.%d" % keys[("waveconv", i, -1)])).unsqueeze(1)
+    yh = 2 ** (i - 1) * pos - 2 ** (i - 1) * neg
+    return yl, yh
+
+
+def kitti_wave_decoder(feats, sd):
+    """DepthWaveProgressiveDecoder.forward (depth_decoder.py:138-168)."""
+    keys = kitti_wave_keys()
+    out = {}
+    x = feats[-1]
+    yl = None
+    for i in range(4, 0, -1):
+        x = conv_block(x, sd, "decoder.%d" % keys[("upconv", i, 0)], "reflect")
+        x = torch.cat([up2(x), feats[i - 1]], 1)
+        x = conv_block(x, sd, "decoder.%d" % keys[("upconv", i, 1)], "reflect")
+        ll_new, yh = kitti_wave_coefficients(x, sd, keys, i, with_ll=(i == 4))
+        if i == 4:
+            yl = ll_new
+        out[("wavelets", i - 1, "LL")] = yl
+        out[("wavelets", i - 1, "LH")] = yh[:, :, 0]
+        out[("wavelets", i - 1, "HL")] = yh[:, :, 1]
+        out[("wavelets", i - 1, "HH")] = yh[:, :, 2]
+        yl = haar_idwt(yl, yh)
+        out[("disp", i - 1)] = torch.clamp(yl / 2 ** (i - 1), 0, 1)
+    return out
+
+
+def kitti_baseline_param_shapes(num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+    """DepthDecoder parameters (depth_decoder.py:19-50)."""
+    shapes = {}
+    n = 0
+    for i in range(4, -1, -1):
+        cin0 = int(num_ch_enc[-1]) if i == 4 else NUM_CH_DEC[i + 1]
+        c = NUM_CH_DEC[i]
+        shapes["decoder.%d.conv.conv.weight" % n] = (c, cin0, 3, 3)
+        shapes["decoder.%d.conv.conv.bias" % n] = (c,)
+        n += 1
+        cin1 = c + (int(num_ch_enc[i - 1]) if use_skips and i > 0 else 0)
+        shapes["decoder.%d.conv.conv.weight" % n] = (c, cin1, 3, 3)
+        shapes["decoder.%d.conv.conv.bias" % n] = (c,)
+        n += 1
+    for s in scales:
+        shapes["decoder.%d.conv.weight" % n] = (num_output_channels, NUM_CH_DEC[s], 3, 3)
+        shapes["decoder.%d.conv.bias" % n] = (num_output_channels,)
+        n += 1
+    return shapes
+
+
+def kitti_baseline_decoder(feats, sd, scales=range(4), use_skips=True):
+    """DepthDecoder.forward (depth_decoder.py:52-69): zero-padded ConvBlocks (ConvBlock's default
+    use_refl=False, layers.py:123) and reflect-padded dispconv + sigmoid."""
+    scales = list(scales)
+    out = {}
+    x = feats[-1]
+    n = 0
+    disp_base = 10
+    for i in range(4, -1, -1):
+        x = conv_block(x, sd, "decoder.%d" % n, "zero"); n += 1
+        parts = [up2(x)]
+        if use_skips and i > 0:
+            parts.append(feats[i - 1])
+        x = conv_block(torch.cat(parts, 1), sd, "decoder.%d" % n, "zero"); n += 1
+        if i in scales:
+            k = "decoder.%d" % (disp_base + scales.index(i))
+            out[("disp", i)] = torch.sigmoid(conv3x3(x, sd[k + ".conv.weight"], sd[k + ".conv.bias"], "reflect"))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# sparse machinery (KITTI/layers.py:337-507; NYUv2/networks/layers.py:82-223 is the same code)
+# Internal representation here: compact values as [C, nnz] (channel-major, raster order) which is
+# what the reference's flat `xvals` reshapes to.
+# --------------------------------------------------------------------------------------------
+
+
+def dilate(mask, k):
+    """MaxPool2d(k, stride=1, padding=k//2) on a {0,1} float mask (depth_decoder.py:221-223)."""
+    return F.max_pool2d(mask, k, stride=1, padding=k // 2)
+
+
+def mask_to_idxmap(mask):
+    """mask2idxmap (layers.py:382-389): raster rank of every active pixel, -1 elsewhere."""
+    m = mask.reshape(-1) > 0.5
+    idx = torch.full((m.numel(),), -1, dtype=torch.long)
+    idx[m] = torch.arange(int(m.sum()), dtype=torch.long)
+    return idx.reshape(mask.shape[-2], mask.shape[-1])
+
+
+def mask_coords(mask):
+    """mask2yx (layers.py:371-379): (y, x) of active pixels in raster order."""
+    m = mask.reshape(mask.shape[-2], mask.shape[-1]) > 0.5
+    ys, xs = torch.nonzero(m, as_tuple=True)
+    return ys, xs
+
+
+def gather_with_zero(vals, idx):
+    """vals [C,n]; idx (any shape) in [-1, n): -1 reads 0 (the zero column trick, layers.py:439-442)."""
+    padded = torch.cat([vals.new_zeros(vals.shape[0], 1), vals], 1)
+    return padded[:, (idx + 1).reshape(-1)].reshape(vals.shape[0], *idx.shape)
+
+
+def sparse_select_ref(vals, idxmap_prev, mask_new, ufactor=1):
+    """sparse_select(pad=True) (layers.py:337-362): re-gather compact features at the positions of
+    a new mask; positions missing from the previous index map read zero."""
+    ys, xs = mask_coords(mask_new)
+    if ufactor == 2:
+        ys, xs = ys // 2, xs // 2
+    return gather_with_zero(vals, idxmap_prev[ys, xs])
+
+
+def sparse_upsample_ref(vals, idxmap_coarse, skip, mask_fine):
+    """sparse_upsample(make_result=False) (layers.py:483-507): nearest-upsample in compact space,
+    then append the skip features gathered at the same pixels.  Coarse look-ups are NOT zero-padded in
+    the reference (index -1 would wrap to the last element); the masks guarantee it never happens."""
+    ys, xs = mask_coords(mask_fine)
+    idx = idxmap_coarse[ys // 2, xs // 2]
+    up = vals[:, idx]
+    sk = skip[0][:, ys, xs]
+    return torch.cat([up, sk], 0)
+
+
+def pad_idxmap(idxmap, mode):
+    """F.pad(idxmap.float(), 1, mode) on the +1-shifted index map (layers.py:442-444)."""
+    t = (idxmap + 1).to(torch.float32).reshape(1, 1, *idxmap.shape)
+    return F.pad(t, (1, 1, 1, 1), mode=_PAD[mode]).long()[0, 0] - 1
+
+
+def sparse_conv3x3_ref(vals, idxmap_in, mask_out, w, b, padding="reflect"):
+    """sparse_conv3x3 core (layers.py:434-467): for every active output pixel gather the 3x3
+    neighbourhood through the padded index map (missing -> 0) and contract with the filter.
+    Returns compact [Cout, nnz_out] pre-activation... plus bias (activation applied by callers)."""
+    pidx = pad_idxmap(idxmap_in, padding)          # [H+2, W+2], -1 = zero
+    ys, xs = mask_coords(mask_out)
+    cols = []
+    for t in range(9):
+        ky, kx = t // 3, t % 3
+        cols.append(gather_with_zero(vals, pidx[ys + ky, xs + kx]))   # [Ci, nnz]
+    g = torch.stack(cols, 1)                        # [Ci, 9, nnz]  (row = ci*9 + tap, layers.py:457-464)
+    out = w.reshape(w.shape[0], -1) @ g.reshape(vals.shape[0] * 9, g.shape[-1]) + b.reshape(-1, 1)
+    return out
+
+
+def scatter_dense(vals, mask):
+    """make_result (layers.py:365-368, 473-478)."""
+    C = vals.shape[0]
+    H, W = mask.shape[-2:]
+    out = vals.new_zeros(1, C, H, W)
+    ys, xs = mask_coords(mask)
+    out[0][:, ys, xs] = vals
+    return out
+
+
+def conv_ops(cin, cout, npix, k):
+    """(1 + k*k*cin*npix... ) op model used by the reference for dense layers
+    (depth_decoder.py:246-266,386-398): note the '1 +' sits inside the pixel product."""
+    return (1 + k * k * cin * npix) * cout
+
+
+def sparse_conv_ops(cin, cout, nnz_out, with_mid=None):
+    """ops returned by sparse_conv3x3 (layers.py:405,462,469)."""
+    ops = 0
+    if with_mid is not None:
+        c_in_mid, c_mid, nnz_in = with_mid
+        ops += nnz_in * c_in_mid * c_mid + nnz_in * c_mid
+    ops += cin * 9 * nnz_out                 # gathered element count (layers.py:462)
+    ops += (1 + 9 * cin) * nnz_out * cout    # layers.py:469
+    return ops
+
+
+def kitti_sparse_decoder(feats, sd, thresh_ratio=0.05, sparse_scales=(0, 1, 2, 3)):
+    """SparseDepthWaveProgressiveDecoder.forward (depth_decoder.py:292-428), batch 1."""
+    keys = kitti_wave_keys()
+    sparse_scales = list(sparse_scales)
+    out = {}
+    x = feats[-1]
+    assert x.shape[0] == 1
+    total_ops = 0
+    yl = yh = None
+    vals = None
+    prev_idxmap = None
+    for i in range(4, -1, -1):
+        scale_ops = 0
+        if i == 4:
+            mask = torch.ones_like(x[:, 0:1])
+        else:
+            thresh = (yl.max() - yl.min()) * thresh_ratio
+            mask = (yh.abs().max(2)[0] > thresh).float()
+            scale_ops += 3 * mask.shape[2] * mask.shape[3]
+        umask = up2(mask)
+        wavelet_mask = umask > 0.5
+        lowres_mask = dilate(mask, 3) > 0.5
+        upconv0_mask = dilate(mask, 5) > 0.5
+        upsample_mask = dilate(umask, 5) > 0.5
+        upconv1_mask = dilate(umask, 3) > 0.5
+        h, w = mask.shape[2:]
+        scale_ops += 25 * h * w + 100 * h * w
+        out[("lowres_mask", i - 1)] = lowres_mask
+        out[("upconv0_mask", i - 1)] = upconv0_mask
+        out[("upsample_mask", i - 1)] = upsample_mask
+        out[("upconv1_mask", i - 1)] = upconv1_mask
+        out[("wavelet_mask", i - 1)] = wavelet_mask
+
+        k0 = "decoder.%d" % keys.get(("upconv", i, 0), -1)
+        k1 = "decoder.%d" % keys.get(("upconv", i, 1), -1)
+        if i in sparse_scales:
+            assert i > 0 and yl is not None
+            lowres_idx = mask_to_idxmap(lowres_mask)
+            upconv0_idx = mask_to_idxmap(upconv0_mask)
+            upsample_idx = mask_to_idxmap(upsample_mask)
+            upconv1_idx = mask_to_idxmap(upconv1_mask)
+            scale_ops += 2 * h * w + 2 * 4 * h * w
+            if i == max(sparse_scales):
+                ys, xs = mask_coords(lowres_mask)
+                vals = x[0][:, ys, xs]
+            else:
+                vals = sparse_select_ref(vals, prev_idxmap, lowres_mask)
+            w0, b0 = sd[k0 + ".conv.conv.weight"], sd[k0 + ".conv.conv.bias"]
+            nnz0 = int(upconv0_mask.sum())
+            vals = F.elu(sparse_conv3x3_ref(vals, lowres_idx, upconv0_mask, w0, b0, "reflect"))
+            scale_ops += sparse_conv_ops(w0.shape[1], w0.shape[0], nnz0)
+            vals = sparse_upsample_ref(vals, upconv0_idx, feats[i - 1], upsample_mask)
+            w1, b1 = sd[k1 + ".conv.conv.weight"], sd[k1 + ".conv.conv.bias"]
+            nnz1 = int(upconv1_mask.sum())
+            vals = F.elu(sparse_conv3x3_ref(vals, upsample_idx, upconv1_mask, w1, b1, "reflect"))
+            scale_ops += sparse_conv_ops(w1.shape[1], w1.shape[0], nnz1)
+            # heads: fused 1x1 + LeakyReLU on the upconv1 support, 3x3 on the wavelet mask
+            nnzw = int(wavelet_mask.sum())
+            sig = []
+            for j in (1, -1):
+                kh = "decoder.%d" % keys[("waveconv", i, j)]
+                wm, bm = sd[kh + ".0.conv.weight"], sd[kh + ".0.conv.bias"]
+                mid = F.leaky_relu(wm.reshape(wm.shape[0], -1) @ vals + bm.reshape(-1, 1), 0.1)
+                w3, b3 = sd[kh + ".2.conv.weight"], sd[kh + ".2.conv.bias"]
+                r = torch.sigmoid(sparse_conv3x3_ref(mid, upconv1_idx, wavelet_mask, w3, b3, "reflect"))
+                sig.append(scatter_dense(r, wavelet_mask))
+                scale_ops += sparse_conv_ops(w3.shape[1], w3.shape[0], nnzw,
+                                             with_mid=(wm.shape[1], wm.shape[0], nnz1))
+            yh = (2 ** (i - 1) * (sig[0] - sig[1])).unsqueeze(1)
+            out[("wavelets", i - 1, "LL")] = yl
+            out[("wavelets", i - 1, "LH")] = yh[:, :, 0]
+            out[("wavelets", i - 1, "HL")] = yh[:, :, 1]
+            out[("wavelets", i - 1, "HH")] = yh[:, :, 2]
+            yl = haar_idwt(yl, yh)
+            scale_ops += 4 * yl.shape[2] * yl.shape[3]
+            out[("disp", i - 1)] = torch.clamp(yl / 2 ** (i - 1), 0, 1)
+            total_ops += scale_ops
+            out[("total_ops", i - 1)] = scale_ops
+            if i == 1:
+                break
+            prev_idxmap = upconv1_idx
+        else:
+            w0 = sd[k0 + ".conv.conv.weight"]
+            scale_ops += conv_ops(x.shape[1], w0.shape[0], x.shape[2] * x.shape[3], 3)
+            x = conv_block(x, sd, k0, "reflect")
+            ux = torch.cat([up2(x), feats[i - 1]], 1)
+            w1 = sd[k1 + ".conv.conv.weight"]
+            scale_ops += conv_ops(ux.shape[1], w1.shape[0], ux.shape[2] * ux.shape[3], 3)
+            ux = conv_block(ux, sd, k1, "reflect")
+            npix = ux.shape[2] * ux.shape[3]
+            heads = ([0] if i == 4 else []) + [-1, 1]
+            for j in heads:
+                kh = "decoder.%d" % keys[("waveconv", i, j)]
+                wm, w3 = sd[kh + ".0.conv.weight"], sd[kh + ".2.conv.weight"]
+                scale_ops += conv_ops(wm.shape[1], wm.shape[0], npix, 1)
+                scale_ops += conv_ops(w3.shape[1], w3.shape[0], npix, 3)
+            ll_new, yh = kitti_wave_coefficients(ux, sd, keys, i, with_ll=(i == 4))
+            # dense branch of the sparse class: 2^(s-1)*(sig+ - sig-) then * mask (depth_decoder.py:268-272)
+            pos = torch.sigmoid(wave_head(ux, sd, "decoder.%d" % keys[("waveconv", i, 1)]))
+            neg = torch.sigmoid(wave_head(ux, sd, "decoder.%d" % keys[("waveconv", i, -1)]))
+            yh = (2 ** (i - 1) * (pos - neg) * wavelet_mask).unsqueeze(1)
+            if i == 4:
+                yl = ll_new
+            out[("wavelets", i - 1, "LL")] = yl
+            out[("wavelets", i - 1, "LH")] = yh[:, :, 0]
+            out[("wavelets", i - 1, "HL")] = yh[:, :, 1]
+            out[("wavelets", i - 1, "HH")] = yh[:, :, 2]
+            yl = haar_idwt(yl, yh)
+            scale_ops += 4 * yl.shape[2] * yl.shape[3]
+            out[("disp", i - 1)] = torch.clamp(yl / 2 ** (i - 1), 0, 1)
+            total_ops += scale_ops
+            out[("total_ops", i - 1)] = scale_ops
+            if i == 1:
+                break
+            x = ux
+    out["total_ops"] = total_ops
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# NYUv2 DenseDepth-style wavelet decoders
+# --------------------------------------------------------------------------------------------
+
+
+def nyu_wave_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0.5):
+    """DecoderWave parameters (NYUv2/networks/decoders/densedepth_decoder.py:93-115)."""
+    f = int(enc_features[-1] * decoder_width)
+    e = list(enc_features)
+    return {
+        "conv2.conv.weight": (f, e[-1], 3, 3), "conv2.conv.bias": (f,),
+        "up1.convA.conv.weight": (f // 2, f + e[-2], 3, 3), "up1.convA.conv.bias": (f // 2,),
+        "wave1_ll.conv.weight": (1, f // 2, 3, 3), "wave1_ll.conv.bias": (1,),
+        "wave1.conv.weight": (3, f // 2, 3, 3), "wave1.conv.bias": (3,),
+        "up2.convA.conv.weight": (f // 4, f // 2 + e[-3], 3, 3), "up2.convA.conv.bias": (f // 4,),
+        "wave2.conv.weight": (3, f // 4, 3, 3), "wave2.conv.bias": (3,),
+        "up3.convA.conv.weight": (f // 8, f // 4 + e[-4], 3, 3), "up3.convA.conv.bias": (f // 8,),
+        "wave3.conv.weight": (3, f // 8, 3, 3), "wave3.conv.bias": (3,),
+    }
+
+
+def nyu_up_block(x, skip, sd, key):
+    """UpSampleBlock (NYUv2/networks/layers.py:57-67): up2 -> cat -> Conv3x3(reflection) -> LeakyReLU(0.2)."""
+    t = torch.cat([up2(x), skip], 1)
+    return F.leaky_relu(conv3x3(t, sd[key + ".convA.conv.weight"], sd[key + ".convA.conv.bias"], "reflect"), 0.2)
+
+
+def nyu_wave_decoder(x_blocks, sd):
+    """DecoderWave.forward (densedepth_decoder.py:117-148)."""
+    out = {}
+    x_d0 = conv3x3(x_blocks[-1], sd["conv2.conv.weight"], sd["conv2.conv.bias"], "replicate")
+    x_d1 = nyu_up_block(x_d0, x_blocks[-2], sd, "up1")
+    ll = 8 * conv3x3(x_d1, sd["wave1_ll.conv.weight"], sd["wave1_ll.conv.bias"], "replicate")
+    out[("disp", 3)] = ll / 8
+    h = 4 * conv3x3(x_d1, sd["wave1.conv.weight"], sd["wave1.conv.bias"], "zero").unsqueeze(1)
+    out[("wavelets", 2, "LL")] = ll
+    out[("wavelets", 2, "LH")], out[("wavelets", 2, "HL")], out[("wavelets", 2, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+    ll = haar_idwt(ll, h)
+    out[("disp", 2)] = ll / 4
+    x_d2 = nyu_up_block(x_d1, x_blocks[-3], sd, "up2")
+    h = 2 * conv3x3(x_d2, sd["wave2.conv.weight"], sd["wave2.conv.bias"], "zero").unsqueeze(1)
+    out[("wavelets", 1, "LH")], out[("wavelets", 1, "HL")], out[("wavelets", 1, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+    ll = haar_idwt(ll, h)
+    out[("disp", 1)] = ll / 2
+    x_d3 = nyu_up_block(x_d2, x_blocks[-4], sd, "up3")
+    h = conv3x3(x_d3, sd["wave3.conv.weight"], sd["wave3.conv.bias"], "zero").unsqueeze(1)
+    out[("wavelets", 0, "LH")], out[("wavelets", 0, "HL")], out[("wavelets", 0, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+    ll = haar_idwt(ll, h)
+    out[("disp", 0)] = ll
+    return out
+
+
+def nyu_sparse_wave_decoder(x_blocks, sd, thresh_ratio=0.1):
+    """SparseDecoderWave.forward (densedepth_decoder.py:271-409), batch 1."""
+    out = {}
+    total_ops = 0
+    xb = x_blocks
+    w2 = sd["conv2.conv.weight"]
+    total_ops += (1 + 9 * xb[-1].shape[1]) * xb[-1].shape[2] * xb[-1].shape[3] * w2.shape[0]
+    x_d0 = conv3x3(xb[-1], w2, sd["conv2.conv.bias"], "replicate")
+    x_d1 = nyu_up_block(x_d0, xb[-2], sd, "up1")
+    chn = x_d0.shape[1] + xb[-2].shape[1]
+    total_ops += (1 + 9 * chn) * x_d1.shape[2] * x_d1.shape[3] * x_d1.shape[1]
+    ll = 8 * conv3x3(x_d1, sd["wave1_ll.conv.weight"], sd["wave1_ll.conv.bias"], "replicate")
+    out[("disp", 3)] = ll / 8
+    h = (4 * conv3x3(x_d1, sd["wave1.conv.weight"], sd["wave1.conv.bias"], "zero")).unsqueeze(1)
+    total_ops += (1 + 9 * x_d1.shape[1]) * x_d1.shape[2] * x_d1.shape[3] * 4
+    out[("wavelet_mask", 2)] = torch.ones_like(h[:, 0])
+    out[("wavelets", 2, "LL")] = ll
+    out[("wavelets", 2, "LH")], out[("wavelets", 2, "HL")], out[("wavelets", 2, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+    ll = haar_idwt(ll, h)
+    total_ops += ll.shape[2] * ll.shape[3]
+    out[("disp", 2)] = ll / 4
+
+    vals = None
+    prev_idx = None
+    dense_prev = x_d1
+    for level, (up_key, wave_key, skip, scale) in enumerate((("up2", "wave2", xb[-3], 2.0), ("up3", "wave3", xb[-4], 1.0))):
+        thresh = (ll.max() - ll.min()) * thresh_ratio
+        mask = (h.abs().max(2)[0] > thresh).float()
+        mh, mw = mask.shape[2:]
+        total_ops += 3 * mh * mw
+        up_mask = dilate(mask, 5) > 0.5
+        conva_mask = dilate(up2(mask), 5) > 0.5
+        wave_mask = dilate(up2(mask), 3) > 0.5
+        wavelet_mask = up2(mask)
+        total_ops += 25 * mh * mw + 100 * mh * mw
+        # mask2idxmap calls: wavelet, conva, wave, up (+ a repeated `wave` at the second level,
+        # densedepth_decoder.py:374-375)
+        total_ops += 3 * 4 * mh * mw + mh * mw + (4 * mh * mw if level == 1 else 0)
+        conva_idx = mask_to_idxmap(conva_mask)
+        wave_idx = mask_to_idxmap(wave_mask)
+        up_idx = mask_to_idxmap(up_mask)
+        out[("wavelet_mask", 1 - level)] = wavelet_mask
+        if level == 0:
+            ys, xs = mask_coords(up_mask)
+            vals = dense_prev[0][:, ys, xs]
+        else:
+            vals = sparse_select_ref(vals, prev_idx, up_mask)
+        vals = sparse_upsample_ref(vals, up_idx, skip, conva_mask)
+        wa, ba = sd[up_key + ".convA.conv.weight"], sd[up_key + ".convA.conv.bias"]
+        nnz_wave = int(wave_mask.sum())
+        vals = F.leaky_relu(sparse_conv3x3_ref(vals, conva_idx, wave_mask, wa, ba, "reflect"), 0.2)
+        total_ops += sparse_conv_ops(wa.shape[1], wa.shape[0], nnz_wave)
+        ww, bw = sd[wave_key + ".conv.weight"], sd[wave_key + ".conv.bias"]
+        nnz_wl = int((wavelet_mask > 0.5).sum())
+        hv = sparse_conv3x3_ref(vals, wave_idx, wavelet_mask, ww, bw, "constant")
+        total_ops += sparse_conv_ops(ww.shape[1], ww.shape[0], nnz_wl)
+        h = (scale * scatter_dense(hv, wavelet_mask)).unsqueeze(1)
+        s = 1 - level
+        out[("wavelets", s, "LH")], out[("wavelets", s, "HL")], out[("wavelets", s, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+        ll = haar_idwt(ll, wavelet_mask.unsqueeze(2) * h)
+        total_ops += ll.shape[2] * ll.shape[3]
+        out[("disp", s)] = ll / (2.0 if level == 0 else 1.0)
+        prev_idx = wave_idx
+    out["total_ops"] = total_ops
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# misc
+# --------------------------------------------------------------------------------------------
+
+
+def disp_to_depth(disp, min_depth, max_depth):
+    """KITTI/layers.py:16-25."""
+    min_disp, max_disp = 1.0 / max_depth, 1.0 / min_depth
+    scaled = min_disp + (max_disp - min_disp) * disp
+    return scaled, 1.0 / scaled
+
+
+def make_state_dict(shapes, seed=0):
+    """Deterministic parameters for a name->shape table (scale 1/sqrt(fan_in), like nn.Conv2d)."""
+    import numpy as np
+    from wavelet_monodepth_amd import synth
+
+    sd = {}
+    for name, shp in shapes.items():
+        if name.endswith(".weight"):
+            fan_in = shp[1] * shp[2] * shp[3]
+        else:
+            w = shapes[name[: -len(".bias")] + ".weight"]
+            fan_in = w[1] * w[2] * w[3]
+        bound = 1.0 / math.sqrt(fan_in)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(synth.uniform(tuple(shp), name, seed, -bound, bound)))
+    return sd

@@ -1,0 +1,226 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python modules on synth inputs.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py kitti
+    python tests/golden/make_golden.py nyu
+(two processes because both reference projects call their package `networks`).
+The outputs are data (inputs are regenerated from wavelet_monodepth_amd.synth); no reference source
+is copied.  See refshim/pytorch_wavelets/__init__.py for how the absent third-party IDWT is handled.
+"""
+import io
+import json
+import os
+import sys
+import contextlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+
+from wavelet_monodepth_amd import synth  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def key_str(k):
+    return k if isinstance(k, str) else "|".join(str(p) for p in k)
+
+
+def outputs_to_np(out):
+    res = {}
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            res[key_str(k)] = v.detach().cpu().numpy().astype(np.float32 if v.dtype.is_floating_point else np.uint8)
+        else:
+            res[key_str(k)] = np.asarray(int(v), dtype=np.int64)
+    return res
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def sample(a, limit=4096):
+    """big gradients are stored as a strided sample flat[::step], step = ceil(numel/limit)"""
+    flat = a.reshape(-1)
+    step = max(1, -(-flat.size // limit))
+    return flat[::step].copy()
+
+
+def loss_of(out):
+    return sum(out[("disp", s)].mean() for s in range(4))
+
+
+def gen_kitti():
+    sys.path.insert(0, "/root/reference/KITTI")
+    import layers as L
+    from networks.decoders import DepthDecoder, DepthWaveProgressiveDecoder, SparseDepthWaveProgressiveDecoder
+
+    # --- (ii) single layers -------------------------------------------------------------------
+    layer_cases = {}
+    for name, cin, cout, h, w, refl, block in [
+        ("refl_3_5", 3, 5, 6, 10, True, False), ("zero_19_7", 19, 7, 5, 8, False, False),
+        ("block_refl_37_32", 37, 32, 8, 12, True, True), ("block_zero_16_19", 16, 19, 4, 6, False, True),
+    ]:
+        m = L.ConvBlock(cin, cout, use_refl=refl) if block else L.Conv3x3(cin, cout, use_refl=refl)
+        synth.fill_state_dict(m, seed=3)
+        x = t(synth.normal((2, cin, h, w), "x_" + name, 3))
+        layer_cases["kitti_" + name] = m(x).detach().numpy()
+    m = L.Conv1x1(21, 9)
+    synth.fill_state_dict(m, seed=3)
+    layer_cases["kitti_conv1x1_21_9"] = m(t(synth.normal((2, 21, 5, 7), "x_c1", 3))).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "kitti_layers.npz"), **layer_cases)
+
+    # --- (iii) dense wavelet decoder, R18 channels, 64x64 input, B=2 ------------------------------
+    num_ch_enc = np.array([64, 64, 128, 256, 512])
+    feats = [t(f) for f in synth.encoder_features(2, 64, 64, num_ch_enc, seed=1)]
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(num_ch_enc), seed=1)
+    out = dec(feats)
+    np.savez_compressed(os.path.join(HERE, "kitti_dense_r18_64x64.npz"), **outputs_to_np(out))
+
+    # (vi) gradients of loss = sum_s mean(disp_s)
+    feats_g = [f.clone().requires_grad_(True) for f in feats]
+    out = dec(feats_g)
+    loss = loss_of(out)
+    loss.backward()
+    g = {"loss": loss.detach().numpy()}
+    for k, f in enumerate(feats_g):
+        g["dfeat%d" % k] = f.grad.numpy()
+    for n, p in dec.named_parameters():
+        g["d|" + n] = sample(p.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "kitti_dense_r18_64x64_grads.npz"), **g)
+
+    # --- (iv) sparse decoder, same weights, B=1 -------------------------------------------------
+    sp = SparseDepthWaveProgressiveDecoder(num_ch_enc)
+    sp.load_state_dict(dec.state_dict())
+    feats1 = [f[:1] for f in feats]
+    for thr in (-1.0, 0.01, 0.05, 0.1):
+        with torch.no_grad():
+            out = quiet(sp, feats1, thr)
+        np.savez_compressed(os.path.join(HERE, "kitti_sparse_r18_64x64_thr%g.npz" % thr), **outputs_to_np(out))
+    # a higher-resolution sparse case with a less saturated mask (96x160 input)
+    feats_b = [t(f) for f in synth.encoder_features(1, 96, 160, num_ch_enc, seed=2)]
+    for thr in (0.15, 0.2):
+        with torch.no_grad():
+            out = quiet(sp, feats_b, thr)
+        np.savez_compressed(os.path.join(HERE, "kitti_sparse_r18_96x160_thr%g.npz" % thr), **outputs_to_np(out))
+
+    # --- baseline DepthDecoder -------------------------------------------------------------------
+    base = synth.fill_state_dict(DepthDecoder(num_ch_enc), seed=4)
+    with torch.no_grad():
+        out = base(feats)
+    np.savez_compressed(os.path.join(HERE, "kitti_baseline_r18_64x64.npz"), **outputs_to_np(out))
+
+    # --- (vii) sparse primitives -------------------------------------------------------------------
+    prim = {}
+    mask = t((synth.uniform((1, 1, 6, 9), "pm", 5, 0, 1) > 0.55).astype(np.float32))
+    idxmap, _ = L.mask2idxmap(mask)
+    prim["mask"] = mask.numpy()
+    prim["idxmap"] = idxmap.numpy()
+    prim["yx"] = L.mask2yx(mask).numpy()
+    cin, cout = 5, 4
+    nnz = int(mask.sum())
+    vals = t(synth.normal((cin * nnz,), "pv", 5))
+    conv = synth.fill_state_dict(L.Conv3x3(cin, cout), seed=5)
+    omask = t((synth.uniform((1, 1, 6, 9), "pom", 5, 0, 1) > 0.4).astype(np.float32))
+    for pad in ("reflect", "constant"):
+        dense, ops = L.sparse_conv3x3(conv, vals, idxmap, omask, padding=pad, make_result=True)
+        comp, ochn, ops2 = L.sparse_conv3x3(conv, vals, idxmap, omask, padding=pad, make_result=False)
+        prim["sconv_dense_" + pad] = dense.detach().numpy()
+        prim["sconv_compact_" + pad] = comp.detach().numpy()
+        prim["sconv_ops_" + pad] = np.asarray(int(ops))
+    prim["omask"] = omask.numpy()
+    sel = L.sparse_select(vals, cin, idxmap, omask, pad=True)
+    prim["select_pad"] = sel.numpy()
+    fmask = t((synth.uniform((1, 1, 12, 18), "pfm", 5, 0, 1) > 0.5).astype(np.float32)) * L.upsample(mask)
+    skip = t(synth.normal((1, 3, 12, 18), "pskip", 5))
+    upv, uch = L.sparse_upsample(vals, cin, idxmap, skip, fmask, make_result=False)
+    prim["fmask"] = fmask.numpy()
+    prim["upsample_vals"] = upv.numpy()
+    np.savez_compressed(os.path.join(HERE, "kitti_sparse_primitives.npz"), **prim)
+
+    # --- (viii) op-count known answers ----------------------------------------------------------------
+    known = {}
+    for tag, chans, hh, ww in (("r50_1024x320", [64, 256, 512, 1024, 2048], 320, 1024),
+                               ("r18_640x192", [64, 64, 128, 256, 512], 192, 640)):
+        nce = np.array(chans)
+        spd = synth.fill_state_dict(SparseDepthWaveProgressiveDecoder(nce), seed=6)
+        fs = [t(f) for f in synth.encoder_features(1, hh, ww, nce, seed=6)]
+        with torch.no_grad():
+            out = quiet(spd, fs, -1.0)
+        known["kitti_" + tag] = {"total_ops": int(out["total_ops"]),
+                                 "per_scale": [int(out[("total_ops", s)]) for s in (3, 2, 1, 0)]}
+    with open(os.path.join(HERE, "kitti_total_ops.json"), "w") as f:
+        json.dump(known, f, indent=1)
+    print("kitti goldens written")
+
+
+def gen_nyu():
+    sys.path.insert(0, "/root/reference/NYUv2")
+    import networks.layers as NL
+    from networks.decoders import DecoderWave, SparseDecoderWave
+
+    layer_cases = {}
+    for name, cin, cout, h, w, pad in [("reflection_6_5", 6, 5, 5, 7, "reflection"), ("replicate_19_3", 19, 3, 4, 6, "replicate"),
+                                       ("zero_9_3", 9, 3, 6, 5, "zero")]:
+        m = synth.fill_state_dict(NL.Conv3x3(cin, cout, padding=pad), seed=7)
+        x = t(synth.normal((2, cin, h, w), "x_" + name, 7))
+        layer_cases["nyu_" + name] = m(x).detach().numpy()
+    blk = synth.fill_state_dict(NL.UpSampleBlock(7 + 5, 6, padding="reflection"), seed=7)
+    xs = t(synth.normal((2, 7, 3, 4), "ub_x", 7))
+    sk = t(synth.normal((2, 5, 6, 8), "ub_s", 7))
+    layer_cases["nyu_upsampleblock"] = blk(xs, sk).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "nyu_layers.npz"), **layer_cases)
+
+    enc = [8, 8, 16, 32, 64]
+    H, W, B = 64, 96, 2
+    blocks = [t(synth.normal((B, c, H >> (k + 1), W >> (k + 1)), "nyu_feat%d" % k, 8)) for k, c in enumerate(enc)]
+    dec = synth.fill_state_dict(quiet(DecoderWave, enc_features=enc), seed=8)
+    out = dec(blocks)
+    np.savez_compressed(os.path.join(HERE, "nyu_dense_small_64x96.npz"), **outputs_to_np(out))
+
+    bg = [b_.clone().requires_grad_(True) for b_ in blocks]
+    out = dec(bg)
+    loss = loss_of(out)
+    loss.backward()
+    g = {"loss": loss.detach().numpy()}
+    for k, f in enumerate(bg):
+        if f.grad is not None:
+            g["dfeat%d" % k] = f.grad.numpy()
+    for n, p in dec.named_parameters():
+        if p.grad is not None:
+            g["d|" + n] = sample(p.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "nyu_dense_small_64x96_grads.npz"), **g)
+
+    sp = quiet(SparseDecoderWave, enc_features=enc)
+    sp.load_state_dict(dec.state_dict())
+    b1 = [b_[:1] for b_ in blocks]
+    for thr in (-1.0, 0.02, 0.1):
+        with torch.no_grad():
+            out = quiet(sp, b1, thr)
+        np.savez_compressed(os.path.join(HERE, "nyu_sparse_small_64x96_thr%g.npz" % thr), **outputs_to_np(out))
+
+    # (viii) NYUv2 DenseNet161 640x480 op count at full density
+    encf = [96, 96, 192, 384, 2208]
+    spd = synth.fill_state_dict(quiet(SparseDecoderWave, enc_features=encf), seed=9)
+    fs = [t(synth.normal((1, c, 480 >> (k + 1), 640 >> (k + 1)), "nyu_big%d" % k, 9)) for k, c in enumerate(encf)]
+    with torch.no_grad():
+        out = quiet(spd, fs, -1.0)
+    with open(os.path.join(HERE, "nyu_total_ops.json"), "w") as f:
+        json.dump({"nyu_densenet161_640x480": {"total_ops": int(out["total_ops"])}}, f, indent=1)
+    print("nyu goldens written")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "kitti"
+    {"kitti": gen_kitti, "nyu": gen_nyu}[which]()

@@ -1,0 +1,240 @@
+"""CPU: the oracle (oracle/decoder_ref.py) against the golden vectors produced by the reference's
+own Python modules (tests/golden/make_golden.py) and by PyWavelets (make_golden_pywt.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as R
+from wavelet_monodepth_amd import synth
+from util import GOLDEN, R18, R50, assert_close, key_str, kitti_feats, load_golden, nyu_feats, sample, t
+
+TOL = 2e-6  # same fp32 ops in a different order on the same CPU: only rounding noise is allowed
+
+
+def check_outputs(out, gold, tol=TOL, skip=()):
+    seen = 0
+    for k, v in out.items():
+        ks = key_str(k)
+        if ks in skip or ks not in gold:
+            continue
+        seen += 1
+        if torch.is_tensor(v):
+            if v.dtype == torch.bool:
+                assert np.array_equal(v.numpy().astype(np.uint8), gold[ks]), ks
+            else:
+                assert_close(v, gold[ks], tol, ks)
+        else:
+            assert int(v) == int(gold[ks]), "%s: %d vs %d" % (ks, int(v), int(gold[ks]))
+    missing = [k for k in gold if k not in {key_str(q) for q in out}]
+    assert not missing, "oracle misses outputs %s" % missing
+    assert seen == len(gold)
+
+
+def test_haar_idwt_vs_pywavelets():
+    g = load_golden("pywt_haar.npz")
+    for name, (h, w) in {"a": (4, 6), "b": (12, 40), "c": (7, 5), "d": (24, 80)}.items():
+        yl = t(synth.normal((h, w), "pywt_yl_" + name, 11)).reshape(1, 1, h, w)
+        yh = t(synth.normal((3, h, w), "pywt_yh_" + name, 11)).reshape(1, 1, 3, h, w)
+        assert_close(R.haar_idwt(yl, yh)[0, 0], g["idwt_" + name], 1e-6, "idwt_" + name)
+
+
+def test_haar_dwt_vs_pywavelets():
+    g = load_golden("pywt_haar.npz")
+    for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4)}.items():
+        x = t(synth.normal((h, w), "pywt_x_" + name, 12)).reshape(1, 1, h, w)
+        yl, yh = R.haar_dwt(x, J)
+        assert_close(yl[0, 0], g["dwt_%s_yl" % name], 2e-6, "yl")
+        for j in range(J):
+            k = "dwt_%s_yh%d" % (name, j)
+            if k in g:
+                assert_close(yh[j][0, 0], g[k], 2e-6, k)
+
+
+def test_haar_roundtrip_and_adjoint():
+    x = t(synth.normal((2, 1, 16, 24), "rt", 1))
+    yl, yh = R.haar_dwt(x, 1)
+    assert_close(R.haar_idwt(yl, yh[0]), x, 1e-6, "idwt(dwt(x))")
+    # orthonormality: <idwt(c), y> == <c, dwt(y)>
+    y = t(synth.normal((2, 1, 16, 24), "rt2", 1))
+    yl2, yh2 = R.haar_dwt(y, 1)
+    lhs = (R.haar_idwt(yl, yh[0]) * y).sum()
+    rhs = (yl * yl2).sum() + (yh[0] * yh2[0]).sum()
+    assert abs(float(lhs - rhs)) < 1e-3 * abs(float(lhs))
+
+
+def test_kitti_layers():
+    g = load_golden("kitti_layers.npz")
+    for name, cin, cout, h, w, refl, block in [
+        ("refl_3_5", 3, 5, 6, 10, True, False), ("zero_19_7", 19, 7, 5, 8, False, False),
+        ("block_refl_37_32", 37, 32, 8, 12, True, True), ("block_zero_16_19", 16, 19, 4, 6, False, True),
+    ]:
+        prefix = "conv." if block else ""
+        wgt, b = synth_params(prefix + "conv", cout, cin, 3, 3)
+        x = t(synth.normal((2, cin, h, w), "x_" + name, 3))
+        y = R.conv3x3(x, wgt, b, "reflect" if refl else "zero")
+        if block:
+            y = torch.nn.functional.elu(y)
+        assert_close(y, g["kitti_" + name], TOL, name)
+    wgt, b = synth_params("conv", 9, 21, 1, 3)
+    assert_close(R.conv1x1(t(synth.normal((2, 21, 5, 7), "x_c1", 3)), wgt, b), g["kitti_conv1x1_21_9"], TOL, "1x1")
+
+
+def synth_params(prefix, cout, cin, k, seed):
+    bound = 1.0 / np.sqrt(cin * k * k)
+    w = t(synth.uniform((cout, cin, k, k), prefix + ".weight", seed, -bound, bound))
+    b = t(synth.uniform((cout,), prefix + ".bias", seed, -bound, bound))
+    return w, b
+
+
+def test_kitti_dense_decoder():
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    out = R.kitti_wave_decoder(kitti_feats(2, 64, 64), sd)
+    check_outputs(out, load_golden("kitti_dense_r18_64x64.npz"))
+
+
+def test_kitti_dense_decoder_grads():
+    g = load_golden("kitti_dense_r18_64x64_grads.npz")
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    for v in sd.values():
+        v.requires_grad_(True)
+    feats = [f.requires_grad_(True) for f in kitti_feats(2, 64, 64)]
+    out = R.kitti_wave_decoder(feats, sd)
+    loss = sum(out[("disp", s)].mean() for s in range(4))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for k, f in enumerate(feats):
+        assert_close(f.grad, g["dfeat%d" % k], 2e-5, "dfeat%d" % k)
+    n = 0
+    for name, v in sd.items():
+        assert_close(sample(v.grad.numpy()), g["d|" + name], 2e-5, name)
+        n += 1
+    assert n == len([k for k in g if k.startswith("d|")])
+
+
+@pytest.mark.parametrize("thr", [-1.0, 0.01, 0.05, 0.1])
+def test_kitti_sparse_decoder(thr):
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    feats = [f[:1] for f in kitti_feats(2, 64, 64)]
+    out = R.kitti_sparse_decoder(feats, sd, thr)
+    check_outputs(out, load_golden("kitti_sparse_r18_64x64_thr%g.npz" % thr))
+
+
+@pytest.mark.parametrize("thr", [0.15, 0.2])
+def test_kitti_sparse_decoder_96x160(thr):
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    out = R.kitti_sparse_decoder(kitti_feats(1, 96, 160, seed=2), sd, thr)
+    gold = load_golden("kitti_sparse_r18_96x160_thr%g.npz" % thr)
+    check_outputs(out, gold)
+    dens = [float(gold["wavelet_mask|%d" % s].mean()) for s in range(3)]
+    assert 0.01 < min(dens) and max(dens) < 0.98, "fixture should exercise a non-trivial mask: %s" % dens
+
+
+def test_sparse_equals_dense_at_negative_threshold():
+    """Reference invariant: thresh_ratio <= 0 reproduces the dense decoder."""
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    feats = [f[:1] for f in kitti_feats(2, 64, 64)]
+    dense = R.kitti_wave_decoder(feats, sd)
+    sparse = R.kitti_sparse_decoder(feats, sd, -1.0)
+    for s in range(4):
+        assert_close(sparse[("disp", s)], dense[("disp", s)], 5e-6, "disp%d" % s)
+
+
+def test_kitti_baseline_decoder():
+    sd = R.make_state_dict(R.kitti_baseline_param_shapes(R18), seed=4)
+    out = R.kitti_baseline_decoder(kitti_feats(2, 64, 64), sd)
+    check_outputs(out, load_golden("kitti_baseline_r18_64x64.npz"))
+
+
+def test_sparse_primitives():
+    g = load_golden("kitti_sparse_primitives.npz")
+    mask = t(g["mask"])
+    idx = R.mask_to_idxmap(mask)
+    assert np.array_equal(idx.numpy(), g["idxmap"][0, 0])
+    ys, xs = R.mask_coords(mask)
+    assert np.array_equal(torch.stack([ys, xs]).numpy(), g["yx"])
+    cin, cout = 5, 4
+    nnz = int(mask.sum())
+    vals = t(synth.normal((cin * nnz,), "pv", 5)).reshape(cin, nnz)
+    w, b = synth_params("conv", cout, cin, 3, 5)
+    omask = t(g["omask"])
+    for pad in ("reflect", "constant"):
+        comp = R.sparse_conv3x3_ref(vals, idx, omask, w, b, pad)
+        assert_close(comp.reshape(-1), g["sconv_compact_" + pad], TOL, "compact " + pad)
+        assert_close(R.scatter_dense(comp, omask), g["sconv_dense_" + pad], TOL, "dense " + pad)
+        assert R.sparse_conv_ops(cin, cout, int(omask.sum())) == int(g["sconv_ops_" + pad])
+    assert_close(R.sparse_select_ref(vals, idx, omask).reshape(-1), g["select_pad"], 0, "select")
+    skip = t(synth.normal((1, 3, 12, 18), "pskip", 5))
+    up = R.sparse_upsample_ref(vals, idx, skip, t(g["fmask"]))
+    assert_close(up.reshape(-1), g["upsample_vals"], 0, "sparse_upsample")
+
+
+def test_nyu_layers():
+    g = load_golden("nyu_layers.npz")
+    for name, cin, cout, h, w, pad in [("reflection_6_5", 6, 5, 5, 7, "reflection"), ("replicate_19_3", 19, 3, 4, 6, "replicate"),
+                                       ("zero_9_3", 9, 3, 6, 5, "zero")]:
+        wgt, b = synth_params("conv", cout, cin, 3, 7)
+        x = t(synth.normal((2, cin, h, w), "x_" + name, 7))
+        assert_close(R.conv3x3(x, wgt, b, pad), g["nyu_" + name], TOL, name)
+    wgt, b = synth_params("convA.conv", 6, 12, 3, 7)
+    xs = t(synth.normal((2, 7, 3, 4), "ub_x", 7))
+    sk = t(synth.normal((2, 5, 6, 8), "ub_s", 7))
+    y = R.nyu_up_block(xs, sk, {"b.convA.conv.weight": wgt, "b.convA.conv.bias": b}, "b")
+    assert_close(y, g["nyu_upsampleblock"], TOL, "UpSampleBlock")
+
+
+NYU_ENC = [8, 8, 16, 32, 64]
+
+
+def test_nyu_dense_decoder():
+    sd = R.make_state_dict(R.nyu_wave_param_shapes(NYU_ENC), seed=8)
+    out = R.nyu_wave_decoder(nyu_feats(2, 64, 96, NYU_ENC), sd)
+    check_outputs(out, load_golden("nyu_dense_small_64x96.npz"))
+
+
+def test_nyu_dense_decoder_grads():
+    g = load_golden("nyu_dense_small_64x96_grads.npz")
+    sd = R.make_state_dict(R.nyu_wave_param_shapes(NYU_ENC), seed=8)
+    for v in sd.values():
+        v.requires_grad_(True)
+    feats = [f.requires_grad_(True) for f in nyu_feats(2, 64, 96, NYU_ENC)]
+    out = R.nyu_wave_decoder(feats, sd)
+    loss = sum(out[("disp", s)].mean() for s in range(4))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    for k, f in enumerate(feats):
+        if "dfeat%d" % k in g:
+            assert_close(f.grad, g["dfeat%d" % k], 2e-5, "dfeat%d" % k)
+        else:
+            assert f.grad is None  # x_blocks[0] is unused by DecoderWave
+    for name, v in sd.items():
+        assert_close(sample(v.grad.numpy()), g["d|" + name], 2e-5, name)
+
+
+@pytest.mark.parametrize("thr", [-1.0, 0.02, 0.1])
+def test_nyu_sparse_decoder(thr):
+    sd = R.make_state_dict(R.nyu_wave_param_shapes(NYU_ENC), seed=8)
+    feats = [f[:1] for f in nyu_feats(2, 64, 96, NYU_ENC)]
+    out = R.nyu_sparse_wave_decoder(feats, sd, thr)
+    check_outputs(out, load_golden("nyu_sparse_small_64x96_thr%g.npz" % thr))
+
+
+def test_total_ops_known_answers():
+    """Notebook known answers: 17.474 G (KITTI R50 1024x320), 3.560 G (R18 640x192),
+    33.464 G (NYUv2 DenseNet161 640x480) — pure functions of the shapes at full density."""
+    with open(os.path.join(GOLDEN, "kitti_total_ops.json")) as f:
+        known = json.load(f)
+    assert round(known["kitti_r50_1024x320"]["total_ops"] / 1e9, 3) == 17.474
+    assert round(known["kitti_r18_640x192"]["total_ops"] / 1e9, 3) == 3.560
+    # the oracle's op model at a size it finishes in seconds must match the reference exactly
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=6)
+    feats = [t(f) for f in synth.encoder_features(1, 192, 640, R18, seed=6)]
+    with torch.no_grad():
+        out = R.kitti_sparse_decoder(feats, sd, -1.0)
+    assert int(out["total_ops"]) == known["kitti_r18_640x192"]["total_ops"]
+    assert [int(out[("total_ops", s)]) for s in (3, 2, 1, 0)] == known["kitti_r18_640x192"]["per_scale"]
+    with open(os.path.join(GOLDEN, "nyu_total_ops.json")) as f:
+        nyu = json.load(f)
+    assert round(nyu["nyu_densenet161_640x480"]["total_ops"] / 1e9, 3) == 33.464

@@ -1,0 +1,54 @@
+"""Shared helpers for the test-suite (golden loading, deterministic inputs, comparisons)."""
+import os
+
+import numpy as np
+import torch
+
+from wavelet_monodepth_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+R18 = [64, 64, 128, 256, 512]
+R50 = [64, 256, 512, 1024, 2048]
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def key_str(k):
+    return k if isinstance(k, str) else "|".join(str(p) for p in k)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def sample(a, limit=4096):
+    flat = np.asarray(a).reshape(-1)
+    step = max(1, -(-flat.size // limit))
+    return flat[::step]
+
+
+def kitti_feats(batch, h, w, chans=R18, seed=1):
+    return [t(f) for f in synth.encoder_features(batch, h, w, chans, seed=seed)]
+
+
+def nyu_feats(batch, h, w, enc, seed=8, prefix="nyu_feat"):
+    return [t(synth.normal((batch, c, h >> (k + 1), w >> (k + 1)), "%s%d" % (prefix, k), seed)) for k, c in enumerate(enc)]
+
+
+def max_rel(a, b):
+    """max |a-b| / max(|b|, 1e-6 * max|b|) -> a robust scalar relative error"""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    return float(np.abs(a - b).max() / scale)
+
+
+def assert_close(a, b, rtol, what=""):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    err = max_rel(a, b)
+    assert err <= rtol, "%s: max relative error %.3e > %.1e" % (what, err, rtol)

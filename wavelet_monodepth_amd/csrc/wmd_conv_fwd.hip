@@ -1,0 +1,504 @@
+// Dense decoder convolutions on gfx950: implicit GEMM on v_mfma_f32_16x16x4_f32.
+//
+//   out[b,co,y,x] = act( bias[co] + sum_{ci,ky,kx} W[co,ci,ky,kx] * P[b,ci,y+ky-1,x+kx-1] )
+//
+// where P is the *virtual* padded input: channels [0,C1) come from x1 (optionally nearest-upsampled
+// x2), channels [C1,C1+C2) from the skip tensor x2, and the 1-pixel border follows the reference's
+// ReflectionPad2d / ReplicationPad2d / ZeroPad2d.  Neither the upsample, the concat nor the pad is
+// ever materialised (reference: KITTI/layers.py:120-173,233-236; depth_decoder.py:145-150;
+// NYUv2/networks/layers.py:11-32,57-67).
+//
+// GEMM view: M = Cout, N = pixels of a TH x TW tile of one image, K = Cin*k*k.
+//   A (weights)  : read straight from a fragment-ordered global image (wmd_conv_pack_weights) -
+//                  one fully coalesced 256-byte wave load per 16co x 4ci x tap fragment, register
+//                  double-buffered one K-step ahead.
+//   B (pixels)   : a CK-channel halo patch staged global -> registers -> LDS (double-buffered,
+//                  one barrier per CK channels); every lane reads its B element with ds_read_b32
+//                  at a compile-time offset (tap and channel are immediates).
+//   D            : MR x NR accumulator fragments (16x16) per wave; lane (l&15) = pixel,
+//                  (l>>4)*4+r = out-channel inside the fragment.
+// fp32 MFMA issues once per 32 cycles per SIMD, so one A load + one B ds_read per 16 MFMAs keeps the
+// matrix pipe as the only saturated unit; the kernel is MFMA-bound by construction.
+#include <algorithm>
+#include <cstdlib>
+#include "wmd_internal.h"
+
+namespace wmd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvKArgs {
+    const float* x1;
+    const float* x2;
+    const float* wp;
+    const float* bias;
+    float* y;        // final output (ksplit == 1) or split-K partials [ksplit][B,Cout,H,W]
+    int B, H, W, H1, W1;
+    int C1, C2, Cin, Cout, up1;
+    int pad_mode, act;
+    float slope;
+    int tiles_x, tiles_y;
+    int nci4;        // padded number of 4-channel K groups in wp
+    int ncot;        // number of 16-out-channel tiles in wp
+    int nchunks;     // ceil(Cin / CK)
+    int ksplit, chunks_per_split;
+};
+
+template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
+struct ConvTile {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int PH = TH + 2 * HALO;
+    static constexpr int PW = TW + 2 * HALO;
+    static constexpr int NPOSITIONS = PH * PW;
+    // per-channel LDS stride: >= NPOSITIONS and == 16 (mod 32) so that the two k-lanes of a
+    // 32-lane ds_read_b32 group (lanes 0-15 / 16-31) fall on disjoint bank halves
+    static constexpr int PS = ((NPOSITIONS - 16 + 31) / 32) * 32 + 16;
+    static constexpr int NPOS = (NPOSITIONS + NT - 1) / NT;
+    static constexpr int NPIX = TH * TW;
+    static constexpr int LDS_FLOATS = 2 * CK * PS;
+    static_assert(WN * NR * 16 >= NPIX, "tile has more pixels than MFMA columns");
+    static_assert(CK == 8 || CK == 16, "CK must be 8 or 16");
+};
+
+template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a) {
+    using T = ConvTile<TH, TW, MR, NR, WM, WN, CK, TAPS>;
+    constexpr int NT = T::NT, HALO = T::HALO, PW = T::PW, PS = T::PS, NPOS = T::NPOS;
+    constexpr int KSTEPS = CK / 4;
+
+    __shared__ float lds[T::LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ks = blockIdx.z;
+
+    const int H = a.H, W = a.W;
+
+    // ---- staging geometry: each thread owns NPOS patch positions for every channel ----------
+    int off1[NPOS], off2[NPOS];
+    bool live[NPOS];
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const int p = tid + i * NT;
+        const int py = p / PW, px = p % PW;
+        int gy = y0 + py - HALO, gx = x0 + px - HALO;
+        bool ok = p < T::NPOSITIONS;
+        if (HALO) {
+            ok = pad_coord(gy, H, a.pad_mode) && ok;
+            ok = pad_coord(gx, W, a.pad_mode) && ok;
+        }
+        // tile overhang (H % TH != 0): keep the address legal, the result is never stored
+        ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
+        gy = min(max(gy, 0), H - 1);
+        gx = min(max(gx, 0), W - 1);
+        live[i] = ok;
+        off2[i] = gy * W + gx;
+        off1[i] = (a.up1 == 2) ? (gy >> 1) * a.W1 + (gx >> 1) : gy * W + gx;
+    }
+
+    const size_t plane1 = (size_t)a.H1 * a.W1, plane2 = (size_t)H * W;
+    const float* x1b = a.x1 + (size_t)b * a.C1 * plane1;
+    const float* x2b = a.x2 ? a.x2 + (size_t)b * a.C2 * plane2 : nullptr;
+
+    float sv[CK][NPOS];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            const int ci = chunk * CK + j;  // wave-uniform
+            if (ci < a.C1) {
+                const float* src = x1b + (size_t)ci * plane1;
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) sv[j][i] = live[i] ? src[off1[i]] : 0.f;
+            } else if (ci < a.Cin) {
+                const float* src = x2b + (size_t)(ci - a.C1) * plane2;
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) sv[j][i] = live[i] ? src[off2[i]] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) sv[j][i] = 0.f;
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* dst = lds + buf * (CK * PS);
+#pragma unroll
+        for (int j = 0; j < CK; ++j)
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i) {
+                const int p = tid + i * NT;
+                if (NPOS * NT == T::NPOSITIONS || p < T::NPOSITIONS) dst[j * PS + p] = sv[j][i];
+            }
+    };
+
+    // ---- B fragment addressing: lane (l&15) -> pixel q of the tile, (l>>4) -> channel in K-step
+    int boff[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        int q = (wn * NR + n) * 16 + (lane & 15);
+        q = min(q, T::NPIX - 1);
+        boff[n] = (q / TW) * PW + (q % TW) + (lane >> 4) * PS;
+    }
+
+    // ---- A fragment addressing ------------------------------------------------------------
+    const float* wa[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        int cot = (blockIdx.y * WM + wm) * MR + m;
+        cot = min(cot, a.ncot - 1);
+        wa[m] = a.wp + (size_t)cot * a.nci4 * (TAPS * 64) + lane;
+    }
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int c_begin = ks * a.chunks_per_split;
+    const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
+    const int ci4_end = c_end * KSTEPS;
+
+    float af[2][TAPS][MR];
+    auto load_a = [&](float(&dst)[TAPS][MR], int ci4) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) dst[tp][m] = wa[m][(size_t)(ci4 * TAPS + tp) * 64];
+    };
+
+    if (c_begin < c_end) {
+        stage_load(c_begin);
+        load_a(af[0], c_begin * KSTEPS);
+        stage_store(0);
+    }
+    __syncthreads();
+
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        const bool more = (c + 1 < c_end);
+        if (more) stage_load(c + 1);
+        const float* bsrc = lds + buf * (CK * PS);
+
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int ci4 = c * KSTEPS + kk;
+            if (ci4 + 1 < ci4_end) load_a(af[(kk + 1) & 1], ci4 + 1);
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+                const int ky = (TAPS == 9) ? tp / 3 : 0, kx = (TAPS == 9) ? tp % 3 : 0;
+                float bf[NR];
+#pragma unroll
+                for (int n = 0; n < NR; ++n) bf[n] = bsrc[boff[n] + kk * 4 * PS + ky * PW + kx];
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < NR; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][tp][m], bf[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------
+    const bool final_out = (a.ksplit == 1);
+    float* ybase = a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int q = (wn * NR + n) * 16 + (lane & 15);
+        const int oy = y0 + q / TW, ox = x0 + q % TW;
+        const bool pix_ok = q < T::NPIX && oy < H && ox < W;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int co0 = ((blockIdx.y * WM + wm) * MR + m) * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + r;
+                if (pix_ok && co < a.Cout) {
+                    float v = acc[m][n][r];
+                    if (final_out) {
+                        if (a.bias) v += a.bias[co];
+                        v = act_apply(v, a.act, a.slope);
+                    }
+                    ybase[(size_t)co * plane2 + (size_t)oy * W + ox] = v;
+                }
+            }
+        }
+    }
+}
+
+// split-K second stage: y = act(bias + sum_s partial[s])
+__global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                          float* __restrict__ y, size_t n, size_t plane, int Cout, int ksplit,
+                                          int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < ksplit; ++s) v += partial[(size_t)s * n + i];
+        if (bias) v += bias[(i / plane) % Cout];
+        y[i] = act_apply(v, act, slope);
+    }
+}
+
+// weights [Cout,Cin,k,k] -> fragment image [ncot][nci4][taps][64]; lane l holds
+// W[cot*16 + (l&15)][ci4*4 + (l>>4)][tap], zero outside.
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int taps,
+                                 int ncot, int nci4, int dgrad) {
+    const size_t total = (size_t)ncot * nci4 * taps * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int l = i & 63;
+        size_t r = i >> 6;
+        const int tap = r % taps;
+        r /= taps;
+        const int ci4 = r % nci4;
+        const int cot = r / nci4;
+        const int m = cot * 16 + (l & 15);  // GEMM row
+        const int k = ci4 * 4 + (l >> 4);   // GEMM reduction channel
+        float v = 0.f;
+        if (!dgrad) {
+            if (m < Cout && k < Cin) v = w[((size_t)m * Cin + k) * taps + tap];
+        } else {
+            // data gradient: rows are input channels, reduction runs over output channels, taps flipped
+            if (m < Cin && k < Cout) v = w[((size_t)k * Cin + m) * taps + (taps - 1 - tap)];
+        }
+        wp[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: configuration table + selection
+// ------------------------------------------------------------------------------------------------
+struct ConvCfg {
+    int TH, TW, MR, NR, WM, WN, CK, TAPS;
+    int lds_bytes;
+    void (*launch)(const ConvKArgs&, dim3, hipStream_t);
+    const char* name;
+};
+
+template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
+static void launch_cfg(const ConvKArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_fwd_kernel<TH, TW, MR, NR, WM, WN, CK, TAPS>), grid, dim3(WM * WN * 64), 0, s, a);
+}
+
+#define WMD_CFG(TH, TW, MR, NR, WM, WN, CK, TAPS)                                                       \
+    ConvCfg {                                                                                           \
+        TH, TW, MR, NR, WM, WN, CK, TAPS, (int)sizeof(float) * ConvTile<TH, TW, MR, NR, WM, WN, CK, TAPS>::LDS_FLOATS, \
+            &launch_cfg<TH, TW, MR, NR, WM, WN, CK, TAPS>, #TH "x" #TW "_m" #MR "n" #NR "_w" #WM "x" #WN "_k" #CK "_t" #TAPS \
+    }
+
+static const ConvCfg kCfgs[] = {
+    // 3x3, 32-wide rows (W % 32 == 0: 160/320, 1024-wide pyramids)
+    WMD_CFG(8, 32, 2, 4, 1, 4, 8, 9),   // co32  x 256px
+    WMD_CFG(8, 32, 4, 4, 1, 4, 8, 9),   // co64  x 256px
+    WMD_CFG(4, 32, 4, 4, 2, 2, 8, 9),   // co128 x 128px
+    WMD_CFG(4, 32, 4, 2, 1, 4, 8, 9),   // co64  x 128px
+    WMD_CFG(2, 32, 4, 2, 2, 2, 8, 9),   // co128 x 64px
+    WMD_CFG(5, 32, 4, 5, 2, 2, 8, 9),   // co128 x 160px  (H % 5: 10x32 coarsest level of 1024x320)
+    // 3x3, 40-wide rows (W = 40/80/160/320)
+    WMD_CFG(4, 40, 4, 5, 2, 2, 8, 9),   // co128 x 160px
+    WMD_CFG(4, 40, 4, 5, 1, 2, 8, 9),   // co64  x 160px
+    WMD_CFG(2, 40, 4, 5, 1, 1, 8, 9),   // co64  x 80px, single wave
+    WMD_CFG(3, 40, 4, 4, 1, 2, 8, 9),   // co64  x 120px (H = 15/30/60 ...)
+    // 3x3, 20-wide rows (coarsest 640-wide level, NYUv2 15x20)
+    WMD_CFG(6, 20, 4, 4, 2, 2, 8, 9),   // co128 x 120px
+    WMD_CFG(3, 20, 4, 4, 1, 1, 8, 9),   // co64  x 60px, single wave
+    WMD_CFG(5, 20, 4, 7, 1, 1, 8, 9),   // co64  x 100px, single wave
+    // generic small tile (any W)
+    WMD_CFG(4, 16, 4, 4, 1, 1, 8, 9),   // co64 x 64px
+    WMD_CFG(8, 16, 2, 4, 1, 2, 8, 9),   // co32 x 128px
+    // 1x1 on the flattened image (TH = 1)
+    WMD_CFG(1, 256, 4, 4, 1, 4, 8, 1),  // co64  x 256px
+    WMD_CFG(1, 256, 2, 4, 1, 4, 8, 1),  // co32  x 256px
+    WMD_CFG(1, 128, 4, 4, 2, 2, 8, 1),  // co128 x 128px
+    WMD_CFG(1, 64, 4, 4, 1, 1, 8, 1),   // co64  x 64px
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+struct ConvPlan {
+    const ConvCfg* cfg;
+    int ksplit, chunks_per_split, nchunks, tiles_x, tiles_y;
+    int H, W;  // problem as seen by the kernel (1x1 is flattened)
+    size_t workspace_floats;
+};
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size_t ws_floats) {
+    const int taps = g->ksize == 3 ? 9 : 1;
+    const int Cin = g->C1 + g->C2;
+    const int H = taps == 9 ? g->H : 1;
+    const int W = taps == 9 ? g->W : g->H * g->W;
+    const int ncot = (g->Cout + 15) / 16;
+    const int force = env_int("WMD_CONV_CFG", -1);
+    const int force_ks = env_int("WMD_CONV_KSPLIT", 0);
+    double best = 1e300;
+    bool found = false;
+    for (int i = 0; i < kNumCfgs; ++i) {
+        const ConvCfg& c = kCfgs[i];
+        if (c.TAPS != taps) continue;
+        if (force >= 0 && force != i) continue;
+        const int tiles_x = (W + c.TW - 1) / c.TW, tiles_y = (H + c.TH - 1) / c.TH;
+        const long tiles = (long)g->B * tiles_x * tiles_y;
+        const int cob = (ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
+        const long blocks = tiles * cob;
+        const int nchunks = (Cin + c.CK - 1) / c.CK;
+        const int waves = c.WM * c.WN;
+        // blocks resident per CU: LDS (160 KiB) and ~2 waves/SIMD of these register-heavy kernels
+        int bpc = std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, 8 / waves));
+        bpc = std::max(bpc, 1);
+        const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * taps;
+        for (int ks = 1; ks <= 16; ks *= 2) {
+            if (force_ks > 0 && ks != force_ks) continue;
+            if (ks > 1 && (!have_ws || nchunks < 2 * ks)) continue;
+            const int cps = (nchunks + ks - 1) / ks;
+            const int ks_eff = (nchunks + cps - 1) / cps;
+            if (ks > 1 && (size_t)ks_eff * g->B * g->Cout * g->H * g->W > ws_floats) continue;
+            const long nblk = blocks * ks_eff;
+            const long rounds = (nblk + (long)kNumCU * bpc - 1) / ((long)kNumCU * bpc);
+            // waves sharing one CU's four matrix pipes in a full round
+            const double conc = std::min<double>(bpc, (double)nblk / kNumCU) * waves;
+            const double rate = 128.0 * std::min(1.0, conc / 4.0);  // MAC / clk / CU
+            double per_cu_blocks = (double)rounds * std::min<double>(bpc, std::max(1.0, (double)nblk / kNumCU / rounds));
+            double cycles = per_cu_blocks * block_macs_per_chunk * cps / std::max(rate, 1.0);
+            cycles += 3000.0 * rounds;            // prologue/epilogue per block round
+            if (ks_eff > 1) cycles += 6000.0;     // reduce pass launch
+            if (cycles < best) {
+                best = cycles;
+                found = true;
+                plan->cfg = &c;
+                plan->ksplit = ks_eff;
+                plan->chunks_per_split = cps;
+                plan->nchunks = nchunks;
+                plan->tiles_x = tiles_x;
+                plan->tiles_y = tiles_y;
+                plan->H = H;
+                plan->W = W;
+                plan->workspace_floats = ks_eff > 1 ? (size_t)ks_eff * g->B * g->Cout * g->H * g->W : 0;
+            }
+        }
+    }
+    return found;
+}
+
+}  // namespace wmd
+
+using namespace wmd;
+
+extern "C" size_t wmd_conv_packed_weight_floats(int Cout, int Cin, int ksize) {
+    const int taps = ksize == 3 ? 9 : 1;
+    // rows and reduction are both padded to 16, so the forward and the dgrad image have the same size
+    const size_t ncot = (Cout + 15) / 16;
+    const size_t nci4 = ((Cin + 15) / 16) * 4;
+    return ncot * nci4 * taps * 64;
+}
+
+static int pack_common(const float* w, float* wp, int Cout, int Cin, int ksize, int dgrad, void* stream) {
+    if (!w || !wp) return fail(WMD_ERR_BAD_ARG, "wmd_conv_pack_weights: null pointer");
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3))
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_conv_pack_weights: Cout=%d Cin=%d ksize=%d", Cout, Cin, ksize);
+    const int taps = ksize == 3 ? 9 : 1;
+    const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
+    const int ncot = (rows + 15) / 16, nci4 = ((red + 15) / 16) * 4;
+    const size_t total = (size_t)ncot * nci4 * taps * 64;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, taps, ncot,
+                       nci4, dgrad);
+    return check_launch("conv_pack_kernel");
+}
+
+extern "C" int wmd_conv_pack_weights(const float* w, float* wp, int Cout, int Cin, int ksize, void* stream) {
+    return pack_common(w, wp, Cout, Cin, ksize, 0, stream);
+}
+extern "C" int wmd_conv_pack_weights_dgrad(const float* w, float* wp, int Cout, int Cin, int ksize, void* stream) {
+    return pack_common(w, wp, Cout, Cin, ksize, 1, stream);
+}
+
+static int validate_conv(const wmd_conv_args* g, const char* who) {
+    if (!g) return fail(WMD_ERR_BAD_ARG, "%s: null args", who);
+    if (!g->x1 || !g->wp || !g->y) return fail(WMD_ERR_BAD_ARG, "%s: null tensor pointer", who);
+    if (g->C2 > 0 && !g->x2) return fail(WMD_ERR_BAD_ARG, "%s: C2=%d but x2 is null", who, g->C2);
+    if (g->B <= 0 || g->H <= 0 || g->W <= 0 || g->C1 <= 0 || g->C2 < 0 || g->Cout <= 0)
+        return fail(WMD_ERR_BAD_SHAPE, "%s: B=%d H=%d W=%d C1=%d C2=%d Cout=%d", who, g->B, g->H, g->W, g->C1, g->C2,
+                    g->Cout);
+    if (g->ksize != 1 && g->ksize != 3) return fail(WMD_ERR_UNSUPPORTED, "%s: ksize=%d", who, g->ksize);
+    if (g->up1 != 1 && g->up1 != 2) return fail(WMD_ERR_BAD_ARG, "%s: up1=%d", who, g->up1);
+    if (g->up1 == 2 && ((g->H | g->W) & 1)) return fail(WMD_ERR_BAD_SHAPE, "%s: up1=2 needs even H,W", who);
+    if (g->pad_mode < 0 || g->pad_mode > 2) return fail(WMD_ERR_BAD_ARG, "%s: pad_mode=%d", who, g->pad_mode);
+    if (g->act < 0 || g->act > 3) return fail(WMD_ERR_BAD_ARG, "%s: act=%d", who, g->act);
+    // ReflectionPad2d(1) requires every padded dimension to be >= 2 (torch raises otherwise)
+    if (g->ksize == 3 && g->pad_mode == WMD_PAD_REFLECT && (g->H < 2 || g->W < 2))
+        return fail(WMD_ERR_BAD_SHAPE, "%s: reflect padding needs H,W >= 2 (got %dx%d)", who, g->H, g->W);
+    return WMD_OK;
+}
+
+extern "C" size_t wmd_conv_fwd_workspace_floats(const wmd_conv_args* g) {
+    if (!g || g->B <= 0 || g->Cout <= 0) return 0;
+    ConvPlan plan;
+    if (!plan_conv(g, &plan, true, (size_t)-1)) return 0;
+    return plan.workspace_floats;
+}
+
+extern "C" int wmd_conv_fwd(const wmd_conv_args* g, void* stream) {
+    int st = validate_conv(g, "wmd_conv_fwd");
+    if (st) return st;
+    ConvPlan plan;
+    if (!plan_conv(g, &plan, g->workspace != nullptr, g->workspace_floats)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_fwd: no kernel configuration");
+    const ConvCfg& c = *plan.cfg;
+    const int taps = c.TAPS;
+    ConvKArgs a;
+    a.x1 = g->x1;
+    a.x2 = g->C2 > 0 ? g->x2 : nullptr;
+    a.wp = g->wp;
+    a.bias = g->bias;
+    a.B = g->B;
+    a.H = plan.H;
+    a.W = plan.W;
+    a.C1 = g->C1;
+    a.C2 = g->C2;
+    a.Cin = g->C1 + g->C2;
+    a.Cout = g->Cout;
+    a.up1 = taps == 9 ? g->up1 : 1;
+    if (taps == 1 && g->up1 == 2) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_fwd: 1x1 with upsampled input");
+    a.H1 = a.H / a.up1;
+    a.W1 = a.W / a.up1;
+    a.pad_mode = g->pad_mode;
+    a.act = g->act;
+    a.slope = g->slope;
+    a.tiles_x = plan.tiles_x;
+    a.tiles_y = plan.tiles_y;
+    a.nci4 = ((a.Cin + 15) / 16) * 4;
+    a.ncot = (g->Cout + 15) / 16;
+    a.nchunks = plan.nchunks;
+    a.ksplit = plan.ksplit;
+    a.chunks_per_split = plan.chunks_per_split;
+    a.y = plan.ksplit > 1 ? g->workspace : g->y;
+    const int cob = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
+    dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y), (unsigned)cob, (unsigned)plan.ksplit);
+    if (env_int("WMD_CONV_VERBOSE", 0))
+        fprintf(stderr, "[wmd] conv %dx%d C%d+%d->%d k%d: cfg %s grid %u,%u,%u\n", g->H, g->W, g->C1, g->C2, g->Cout,
+                g->ksize, c.name, grid.x, grid.y, grid.z);
+    c.launch(a, grid, (hipStream_t)stream);
+    st = check_launch("conv_fwd_kernel");
+    if (st) return st;
+    if (plan.ksplit > 1) {
+        const size_t n = (size_t)g->B * g->Cout * g->H * g->W;
+        const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->workspace,
+                           g->bias, g->y, n, (size_t)g->H * g->W, g->Cout, plan.ksplit, g->act, g->slope);
+        st = check_launch("conv_splitk_reduce_kernel");
+    }
+    return st;
+}

@@ -1,0 +1,52 @@
+// Internal helpers shared by the HIP translation units of libwmd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/wmd.h"
+
+namespace wmd {
+
+void set_error(const char* fmt, ...);
+
+inline int fail(int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    set_error("%s", buf);
+    return status;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(WMD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return WMD_OK;
+}
+
+constexpr int kNumCU = 256;  // MI355X
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case WMD_ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case WMD_ACT_LEAKY: return v > 0.f ? v : v * slope;
+        case WMD_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// map a padded coordinate g in [-1, n] to a source coordinate; returns false when the tap reads zero
+__device__ __forceinline__ bool pad_coord(int& g, int n, int pad_mode) {
+    if (pad_mode == WMD_PAD_REFLECT) {
+        if (g < 0) g = -g;
+        if (g >= n) g = 2 * n - 2 - g;
+    } else if (pad_mode == WMD_PAD_REPLICATE) {
+        g = g < 0 ? 0 : (g >= n ? n - 1 : g);
+    } else {
+        if (g < 0 || g >= n) return false;
+    }
+    return true;
+}
+
+}  // namespace wmd
