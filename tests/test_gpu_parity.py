@@ -1,0 +1,217 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Tolerance: north_star asks for <= 1e-4 relative on depth maps; single operators are held to 2e-5
+(fp32 accumulation-order noise only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as R
+from wavelet_monodepth_amd import synth
+from util import R18, assert_close, key_str, kitti_feats, load_golden, max_rel, t
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 2e-5
+NET_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def test_library_loads_and_reports_version():
+    from wavelet_monodepth_amd import _lib
+    assert _lib.lib().wmd_version() >= 100
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 2), (2, 1, 6, 20), (3, 2, 12, 40), (12, 1, 96, 320), (1, 1, 5, 7)])
+def test_idwt_forward(dev, shape):
+    from wavelet_monodepth_amd import ops
+    B, C, h, w = shape
+    yl = t(synth.normal((B, C, h, w), "iyl", 1))
+    yh = t(synth.normal((B, C, 3, h, w), "iyh", 1))
+    ref = R.haar_idwt(yl, yh)
+    out, disp = ops.idwt_haar(yl.to(dev), yh.to(dev), disp_scale=0.25, clamp01=True)
+    assert_close(out, ref, 1e-6, "idwt")
+    assert_close(disp, torch.clamp(ref * 0.25, 0, 1), 1e-6, "disp")
+    out2, none = ops.idwt_haar(yl.to(dev), yh.to(dev))
+    assert none is None and torch.equal(out2, out)
+
+
+def test_idwt_vs_pywavelets_golden(dev):
+    from wavelet_monodepth_amd import ops
+    g = load_golden("pywt_haar.npz")
+    for name, (h, w) in {"a": (4, 6), "b": (12, 40), "c": (7, 5), "d": (24, 80)}.items():
+        yl = t(synth.normal((h, w), "pywt_yl_" + name, 11)).reshape(1, 1, h, w)
+        yh = t(synth.normal((3, h, w), "pywt_yh_" + name, 11)).reshape(1, 1, 3, h, w)
+        out, _ = ops.idwt_haar(yl.to(dev), yh.to(dev))
+        assert_close(out[0, 0], g["idwt_" + name], 1e-6, "idwt_" + name)
+
+
+def test_dwt_vs_pywavelets_golden_and_roundtrip(dev):
+    from wavelet_monodepth_amd import ops
+    g = load_golden("pywt_haar.npz")
+    for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4)}.items():
+        x = t(synth.normal((h, w), "pywt_x_" + name, 12)).reshape(1, 1, h, w).to(dev)
+        yl, yh = ops.dwt_haar(x, J)
+        assert_close(yl[0, 0], g["dwt_%s_yl" % name], 2e-6, "yl")
+        for j in range(J):
+            k = "dwt_%s_yh%d" % (name, j)
+            if k in g:
+                assert_close(yh[j][0, 0], g[k], 2e-6, k)
+        rec = yl
+        for j in reversed(range(J)):
+            rec, _ = ops.idwt_haar(rec, yh[j])
+        assert_close(rec, x, 2e-6, "idwt(dwt(x))")
+
+
+def test_idwt_backward(dev):
+    from wavelet_monodepth_amd import ops
+    yl = t(synth.normal((2, 1, 6, 10), "byl", 2)).requires_grad_(True)
+    yh = t(synth.normal((2, 1, 3, 6, 10), "byh", 2)).requires_grad_(True)
+    gw = t(synth.normal((2, 1, 12, 20), "bgw", 2))
+    gd = t(synth.normal((2, 1, 12, 20), "bgd", 2))
+    ref = R.haar_idwt(yl, yh)
+    ((ref * gw).sum() + (torch.clamp(ref * 0.5, 0, 1) * gd).sum()).backward()
+    yl_g = yl.detach().to(dev).requires_grad_(True)
+    yh_g = yh.detach().to(dev).requires_grad_(True)
+    out, disp = ops.idwt_haar(yl_g, yh_g, disp_scale=0.5, clamp01=True)
+    ((out * gw.to(dev)).sum() + (disp * gd.to(dev)).sum()).backward()
+    assert_close(yl_g.grad, yl.grad, 1e-5, "d_yl")
+    assert_close(yh_g.grad, yh.grad, 1e-5, "d_yh")
+
+
+CONV_CASES = [
+    # B, C1, C2, up, Cout, H, W, k, pad, act
+    (2, 3, 0, 1, 5, 6, 10, 3, "reflect", "none"),
+    (2, 19, 0, 1, 7, 5, 8, 3, "zero", "elu"),
+    (1, 37, 0, 1, 32, 8, 12, 3, "reflect", "elu"),
+    (2, 16, 8, 2, 19, 4, 6, 3, "reflect", "elu"),        # fused upsample + concat, ragged Cout
+    (2, 32, 64, 2, 32, 12, 40, 3, "reflect", "elu"),     # upconv(1,1) structure
+    (1, 64, 0, 1, 32, 48, 160, 3, "reflect", "elu"),     # 32-wide tiles
+    (2, 512, 0, 1, 256, 6, 20, 3, "reflect", "elu"),     # coarsest level, split-K territory
+    (1, 256, 256, 2, 256, 12, 40, 3, "reflect", "elu"),
+    (1, 40, 0, 1, 24, 15, 20, 3, "replicate", "none"),   # NYUv2 conv2-like (odd H)
+    (1, 23, 10, 2, 13, 30, 40, 3, "reflect", "leaky"),   # NYUv2 UpSampleBlock-like, odd channels
+    (2, 21, 0, 1, 9, 5, 7, 1, "zero", "none"),           # 1x1
+    (2, 256, 0, 1, 256, 12, 40, 1, "zero", "leaky"),     # head 1x1
+    (1, 32, 0, 1, 32, 96, 320, 1, "zero", "leaky"),
+    (1, 138, 0, 1, 3, 9, 11, 3, "zero", "none"),         # tiny Cout through the MFMA path
+    (3, 8, 0, 1, 16, 2, 2, 3, "reflect", "sigmoid"),     # smallest legal reflect size
+    (1, 5, 0, 1, 4, 1, 9, 3, "zero", "none"),            # H = 1
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_forward(dev, case):
+    from wavelet_monodepth_amd import ops
+    B, C1, C2, up, Cout, H, W, k, pad, act = case
+    x1 = t(synth.normal((B, C1, H // up, W // up), "cx1", 3))
+    x2 = t(synth.normal((B, C2, H, W), "cx2", 3)) if C2 else None
+    w, b = synth.conv_params("cw", Cout, C1 + C2, k, 3)
+    w, b = t(w), t(b)
+    xin = R.up2(x1) if up == 2 else x1
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    ref = R.conv3x3(xin, w, b, pad) if k == 3 else R.conv1x1(xin, w, b)
+    slope = 0.1
+    ref = {"none": lambda v: v, "elu": torch.nn.functional.elu, "leaky": lambda v: torch.nn.functional.leaky_relu(v, slope),
+           "sigmoid": torch.sigmoid}[act](ref)
+    y = ops.conv2d_fused(x1.to(dev), w.to(dev), b.to(dev), x2=None if x2 is None else x2.to(dev), up1=up, pad=pad,
+                         act=act, slope=slope)
+    assert_close(y, ref, OP_TOL, "conv")
+
+
+def test_conv_rejects_bad_input(dev):
+    from wavelet_monodepth_amd import ops, _lib
+    w = torch.zeros(4, 3, 3, 3, device=dev)
+    with pytest.raises(_lib.WmdError):
+        ops.conv2d_fused(torch.zeros(1, 3, 1, 5, device=dev), w, None, pad="reflect")   # reflect needs H >= 2
+    with pytest.raises(_lib.WmdError):
+        ops.conv2d_fused(torch.zeros(1, 2, 4, 4, device=dev), w, None)                   # channel mismatch
+    with pytest.raises(_lib.WmdError):
+        ops.conv2d_fused(torch.zeros(1, 3, 4, 4), w.cpu(), None)                          # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("mode,cout,pad", [(0, 3, "zero"), (0, 1, "replicate"), (1, 1, "reflect"), (2, 3, "reflect")])
+@pytest.mark.parametrize("shape", [(2, 20, 12, 40), (1, 32, 9, 35), (1, 7, 2, 2)])
+def test_head3x3(dev, mode, cout, pad, shape):
+    from wavelet_monodepth_amd import ops
+    B, C, H, W = shape
+    xp = t(synth.normal((B, C, H, W), "hxp", 4))
+    xn = t(synth.normal((B, C, H, W), "hxn", 4))
+    wp, bp = [t(a) for a in synth.conv_params("hwp", cout, C, 3, 4)]
+    wn, bn = [t(a) for a in synth.conv_params("hwn", cout, C, 3, 4)]
+    scale = 4.0
+    cp = R.conv3x3(xp, wp, bp, pad)
+    if mode == 0:
+        ref = scale * cp
+    elif mode == 1:
+        ref = scale * torch.sigmoid(cp)
+    else:
+        ref = scale * torch.sigmoid(cp) - scale * torch.sigmoid(R.conv3x3(xn, wn, bn, pad))
+    y = ops.head3x3(xp.to(dev), wp.to(dev), bp.to(dev), xn.to(dev) if mode == 2 else None,
+                    wn.to(dev) if mode == 2 else None, bn.to(dev) if mode == 2 else None, pad=pad, mode=mode, scale=scale)
+    # differences of sigmoids cancel: compare on the scale of the operands
+    err = float((y.cpu() - ref).abs().max()) / scale
+    assert err < 2e-6, err
+
+
+def _kitti_decoder(dev, seed=1):
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=seed)
+    return dec.to(dev)
+
+
+def test_kitti_dense_decoder_vs_reference_golden(dev):
+    """Identical synth weights + features as tests/golden/make_golden.py fed to the reference module."""
+    gold = load_golden("kitti_dense_r18_64x64.npz")
+    dec = _kitti_decoder(dev)
+    with torch.no_grad():
+        out = dec([f.to(dev) for f in kitti_feats(2, 64, 64)])
+    assert set(key_str(k) for k in out) == set(gold)
+    for k, v in out.items():
+        assert_close(v, gold[key_str(k)], NET_TOL, key_str(k))
+
+
+def test_kitti_dense_decoder_config2_vs_oracle(dev):
+    """BASELINE config 2 shapes (640x192, R18) at batch 2 (the oracle needs ~1 s per sample)."""
+    dec = _kitti_decoder(dev, seed=5)
+    feats = kitti_feats(2, 192, 640, seed=5)
+    sd = {k: v.cpu() for k, v in dec.state_dict().items()}
+    with torch.no_grad():
+        ref = R.kitti_wave_decoder(feats, sd)
+        out = dec([f.to(dev) for f in feats])
+    for k in ref:
+        assert_close(out[k], ref[k], NET_TOL, key_str(k))
+
+
+def test_kitti_dense_decoder_batch12_properties(dev):
+    """Full config-2 batch: per-sample independence (batch 12 == 12 x batch 1 on a subset) and
+    IDWT consistency: disp_s == clamp(idwt chain of the logged coefficients)."""
+    dec = _kitti_decoder(dev, seed=6)
+    feats = [f.to(dev) for f in kitti_feats(12, 192, 640, seed=6)]
+    with torch.no_grad():
+        out = {k: v.clone() for k, v in dec(feats).items()}
+        one = dec([f[7:8] for f in feats])
+    for s in range(4):
+        assert_close(out[("disp", s)][7:8], one[("disp", s)], 1e-6, "batch independence")
+    yl = out[("wavelets", 3, "LL")].cpu()
+    for s in (3, 2, 1, 0):
+        yh = torch.stack([out[("wavelets", s, b)].cpu() for b in ("LH", "HL", "HH")], 2)
+        assert_close(out[("wavelets", s, "LL")].cpu(), yl, 1e-6, "LL chain")
+        yl = R.haar_idwt(yl, yh)
+        assert_close(out[("disp", s)].cpu(), torch.clamp(yl / 2 ** s, 0, 1), 1e-6, "disp%d" % s)
+
+
+def test_kitti_baseline_decoder_vs_reference_golden(dev):
+    from wavelet_monodepth_amd.kitti import DepthDecoder
+    gold = load_golden("kitti_baseline_r18_64x64.npz")
+    dec = synth.fill_state_dict(DepthDecoder(np.array(R18)), seed=4).to(dev)
+    with torch.no_grad():
+        out = dec([f.to(dev) for f in kitti_feats(2, 64, 64)])
+    assert set(key_str(k) for k in out) == set(gold)
+    for k, v in out.items():
+        assert_close(v, gold[key_str(k)], NET_TOL, key_str(k))

@@ -1,0 +1,127 @@
+"""ctypes binding of libwmd_hip.so (C ABI: include/wmd.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, this raises.
+PyTorch is used only as the owner of device memory and of the current HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwmd_hip.so")
+
+PAD = {"zero": 0, "constant": 0, "reflect": 1, "reflection": 1, "replicate": 2}
+ACT = {"none": 0, None: 0, "elu": 1, "leaky": 2, "sigmoid": 3}
+
+
+class WmdError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
+                ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int), ("slope", C.c_float),
+                ("x1", C.c_void_p), ("x2", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+
+
+class ConvDgradArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
+                ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int),
+                ("dz", C.c_void_p), ("wp_dgrad", C.c_void_p), ("dx1", C.c_void_p), ("dx2", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+
+
+class ConvWgradArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
+                ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int),
+                ("x1", C.c_void_p), ("x2", C.c_void_p), ("dz", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("Cout", C.c_int),
+                ("pad_mode", C.c_int), ("mode", C.c_int), ("scale", C.c_float),
+                ("xp", C.c_void_p), ("wgt_p", C.c_void_p), ("bias_p", C.c_void_p),
+                ("xn", C.c_void_p), ("wgt_n", C.c_void_p), ("bias_n", C.c_void_p),
+                ("y", C.c_void_p), ("sig_p", C.c_void_p), ("sig_n", C.c_void_p)]
+
+
+class SparseConvArgs(C.Structure):
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
+                ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int), ("slope", C.c_float),
+                ("Cmid", C.c_int), ("slope_mid", C.c_float),
+                ("vals1", C.c_void_p), ("idxmap1", C.c_void_p), ("x2", C.c_void_p),
+                ("coords_out", C.c_void_p), ("nnz_out", C.c_void_p), ("max_nnz_out", C.c_int),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("w_mid", C.c_void_p), ("bias_mid", C.c_void_p),
+                ("vals_out", C.c_void_p), ("dense_out", C.c_void_p), ("dense_scale", C.c_float)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); the single source for the "library exports what wmd.h declares" test
+SIGNATURES = {
+    "wmd_version": (C.c_int, []),
+    "wmd_last_error": (C.c_char_p, []),
+    "wmd_status_string": (C.c_char_p, [C.c_int]),
+    "wmd_idwt_haar_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]),
+    "wmd_idwt_haar_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]),
+    "wmd_dwt_haar_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "wmd_conv_packed_weight_floats": (C.c_size_t, [C.c_int] * 3),
+    "wmd_conv_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_conv_pack_weights_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_conv_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "wmd_conv_fwd_workspace_floats": (C.c_size_t, [C.POINTER(ConvArgs)]),
+    "wmd_act_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_size_t, C.c_int, C.c_float, C.c_void_p]),
+    "wmd_conv_dgrad_workspace_floats": (C.c_size_t, [C.POINTER(ConvDgradArgs)]),
+    "wmd_conv_dgrad": (C.c_int, [C.POINTER(ConvDgradArgs), C.c_void_p]),
+    "wmd_conv_wgrad_workspace_floats": (C.c_size_t, [C.POINTER(ConvWgradArgs)]),
+    "wmd_conv_wgrad": (C.c_int, [C.POINTER(ConvWgradArgs), C.c_void_p]),
+    "wmd_head3x3_fwd": (C.c_int, [C.POINTER(HeadArgs), C.c_void_p]),
+    "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_mask_dilate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_mask_compact_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "wmd_mask_compact": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wmd_sparse_conv": (C.c_int, [C.POINTER(SparseConvArgs), C.c_void_p]),
+    "wmd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "wmd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "wmd_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),
+    "wmd_comm_destroy": (C.c_int, [C.c_void_p]),
+}
+
+
+def lib():
+    """Load libwmd_hip.so once. Raises WmdError when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WmdError("%s not found: build it with `python -m wavelet_monodepth_amd.build` "
+                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        l = lib()
+        raise WmdError("%s failed: %s (%s)" % (what or "libwmd_hip call", l.wmd_status_string(status).decode(),
+                                               l.wmd_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). The tensor must be fp32/int and contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libwmd_hip expects contiguous tensors"
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,1 @@
+from .depth_decoder import DepthDecoder, DepthWaveProgressiveDecoder  # noqa: F401

@@ -1,0 +1,137 @@
+"""KITTI depth decoders on MI355X, API-compatible with the reference
+(/root/reference/KITTI/networks/decoders/depth_decoder.py):
+
+  DepthDecoder                       :18-69   sigmoid-disparity baseline
+  DepthWaveProgressiveDecoder        :72-168  dense wavelet decoder
+  SparseDepthWaveProgressiveDecoder  :171-428 threshold-gated sparse inference (see sparse_decoder.py)
+
+Same constructor signatures, same `convs` OrderedDict keys / `decoder.N...` state_dict names, same
+output dictionary keys.  All arithmetic runs in libwmd_hip.so; a CPU tensor raises.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layers import Conv1x1, Conv3x3, ConvBlock
+from ..wavelets import IDWT
+
+
+def _wave_head(num_in, num_mid, num_out):
+    # nn.Sequential(Conv1x1, LeakyReLU(0.1), Conv3x3(refl)) — indices 0 and 2 carry parameters
+    return nn.Sequential(Conv1x1(num_in, num_mid), nn.LeakyReLU(0.1, inplace=True), Conv3x3(num_mid, num_out, use_refl=True))
+
+
+def _build_wave_convs(num_ch_enc, num_ch_dec, use_skips):
+    convs = OrderedDict()
+    for i in range(4, 0, -1):
+        num_ch_in = num_ch_enc[-1] if i == 4 else num_ch_dec[i + 1]
+        convs[("upconv", i, 0)] = ConvBlock(num_ch_in, num_ch_dec[i], use_refl=True)
+        num_ch_in = num_ch_dec[i]
+        if use_skips and i > 0:
+            num_ch_in += num_ch_enc[i - 1]
+        convs[("upconv", i, 1)] = ConvBlock(num_ch_in, num_ch_dec[i], use_refl=True)
+        if i == 4:
+            convs[("waveconv", i, 0)] = _wave_head(num_ch_dec[i], num_ch_dec[i] // 4, 1)
+        convs[("waveconv", i, 1)] = _wave_head(num_ch_dec[i], num_ch_dec[i], 3)
+        convs[("waveconv", i, -1)] = _wave_head(num_ch_dec[i], num_ch_dec[i], 3)
+    return convs
+
+
+class DepthWaveProgressiveDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = "nearest"
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.J = 1
+        self.inverse_wt = IDWT(wave="haar", mode="zero")
+        self.convs = _build_wave_convs(self.num_ch_enc, self.num_ch_dec, use_skips)
+        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.sigmoid = nn.Sigmoid()
+        self.tanh = nn.Tanh()
+
+    # -- pieces ------------------------------------------------------------------------------
+    def _head_mid(self, x, key):
+        head = self.convs[key]
+        return head[0](x, act="leaky", slope=0.1)
+
+    def get_coefficients(self, input_features, scale=1, return_ll=False):
+        """(LL, [LH, HL, HH]) from the features of level `scale` (reference :126-136)."""
+        yl = None
+        if return_ll:
+            mid = self._head_mid(input_features, ("waveconv", scale, 0))
+            c3 = self.convs[("waveconv", scale, 0)][2].conv
+            yl = ops.head3x3(mid, c3.weight, c3.bias, pad="reflect", mode=1, scale=2.0 ** scale)
+        mp = self._head_mid(input_features, ("waveconv", scale, 1))
+        mn = self._head_mid(input_features, ("waveconv", scale, -1))
+        cp = self.convs[("waveconv", scale, 1)][2].conv
+        cn = self.convs[("waveconv", scale, -1)][2].conv
+        yh = ops.head3x3(mp, cp.weight, cp.bias, mn, cn.weight, cn.bias, pad="reflect", mode=2,
+                         scale=2.0 ** (scale - 1))
+        return yl, yh.unsqueeze(1)
+
+    def forward(self, input_features):
+        self.outputs = {}
+        x = input_features[-1]
+        yl = None
+        for i in range(4, 0, -1):
+            x = self.convs[("upconv", i, 0)](x)
+            skip = input_features[i - 1] if (self.use_skips and i > 0) else None
+            x = self.convs[("upconv", i, 1)](x, skip=skip, up=2)  # fused upsample + concat
+            if i == 4:
+                yl, yh = self.get_coefficients(x, scale=i, return_ll=True)
+            else:
+                _, yh = self.get_coefficients(x, scale=i, return_ll=False)
+            self.outputs[("wavelets", i - 1, "LL")] = yl
+            self.outputs[("wavelets", i - 1, "LH")] = yh[:, :, 0]
+            self.outputs[("wavelets", i - 1, "HL")] = yh[:, :, 1]
+            self.outputs[("wavelets", i - 1, "HH")] = yh[:, :, 2]
+            yl, disp = ops.idwt_haar(yl, yh, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
+            self.outputs[("disp", i - 1)] = disp
+        return self.outputs
+
+
+class DepthDecoder(nn.Module):
+    """Non-wavelet baseline (reference :18-69): zero-padded ConvBlocks, reflect-padded dispconv + sigmoid."""
+
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = "nearest"
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.convs = OrderedDict()
+        for i in range(4, -1, -1):
+            num_ch_in = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
+            self.convs[("upconv", i, 0)] = ConvBlock(num_ch_in, self.num_ch_dec[i])
+            num_ch_in = self.num_ch_dec[i]
+            if self.use_skips and i > 0:
+                num_ch_in += self.num_ch_enc[i - 1]
+            self.convs[("upconv", i, 1)] = ConvBlock(num_ch_in, self.num_ch_dec[i])
+        for s in self.scales:
+            self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
+        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, input_features):
+        self.outputs = {}
+        x = input_features[-1]
+        for i in range(4, -1, -1):
+            x = self.convs[("upconv", i, 0)](x)
+            skip = input_features[i - 1] if (self.use_skips and i > 0) else None
+            x = self.convs[("upconv", i, 1)](x, skip=skip, up=2)
+            if i in self.scales:
+                c = self.convs[("dispconv", i)]
+                if self.num_output_channels <= 4:
+                    self.outputs[("disp", i)] = ops.head3x3(x, c.conv.weight, c.conv.bias, pad="reflect", mode=1, scale=1.0)
+                else:
+                    self.outputs[("disp", i)] = c(x, act="sigmoid")
+        return self.outputs

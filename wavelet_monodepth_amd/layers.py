@@ -1,0 +1,89 @@
+"""Layer modules with the reference's names, constructor arguments and state_dict keys, executing on
+libwmd_hip.so.  Parameters live in plain nn.Conv2d holders so that checkpoints and the KITTI
+trainer's `group_weight` parameter-group splitter (KITTI/pyt_utils.py:12-28, which asserts every
+parameter belongs to a Conv2d/Linear) keep working; the holders' own forward is never used.
+
+  KITTI flavour: Conv3x3(in, out, use_refl=True), Conv1x1, ConvBlock(in, out, kernel_size, use_refl)
+                 (KITTI/layers.py:120-173)
+  NYUv2 flavour: NyuConv3x3(in, out, padding=...), UpSampleBlock (NYUv2/networks/layers.py:11-32,57-67)
+"""
+import torch.nn as nn
+
+from . import ops
+
+
+class Conv3x3(nn.Module):
+    """Pad (reflect or zero) and convolve — KITTI/layers.py:146-161."""
+
+    def __init__(self, in_channels, out_channels, use_refl=True, stride=1, use_bias=True):
+        super().__init__()
+        if stride != 1:
+            raise NotImplementedError("the decoders only use stride 1")
+        self.pad_mode = "reflect" if use_refl else "zero"
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3, stride=stride, bias=use_bias)
+
+    def forward(self, x, skip=None, up=1, act="none", slope=0.0):
+        return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, x2=skip, up1=up, pad=self.pad_mode, act=act,
+                                slope=slope)
+
+
+class Conv1x1(nn.Module):
+    """KITTI/layers.py:164-173."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 1, stride=1, padding=0)
+
+    def forward(self, x, act="none", slope=0.0):
+        return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, pad="zero", act=act, slope=slope)
+
+
+class ConvBlock(nn.Module):
+    """Convolution followed by ELU — KITTI/layers.py:120-143 (norm_layer is Identity everywhere)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, norm_layer=None, use_refl=False):
+        super().__init__()
+        if norm_layer is not None:
+            raise NotImplementedError("no decoder of the reference passes a norm_layer")
+        if kernel_size == 3:
+            self.conv = Conv3x3(in_channels, out_channels, use_refl=use_refl)
+        elif kernel_size == 1:
+            self.conv = Conv1x1(in_channels, out_channels)
+        else:
+            raise NotImplementedError
+        self.kernel_size = kernel_size
+
+    def forward(self, x, skip=None, up=1):
+        if self.kernel_size == 3:
+            return self.conv(x, skip=skip, up=up, act="elu")
+        return self.conv(x, act="elu")
+
+
+class NyuConv3x3(nn.Module):
+    """NYUv2/networks/layers.py:11-32 (`padding` in {"reflection","replicate","zero"}); the optional
+    depthwise variant (is_depthwise) is a SURVEY §8(f) "next" item."""
+
+    def __init__(self, in_channels, out_channels, padding="zero", stride=1, is_depthwise=False):
+        super().__init__()
+        if is_depthwise:
+            raise NotImplementedError("depthwise decoder variants are not built yet (SURVEY.md §8f rank 4)")
+        if stride != 1:
+            raise NotImplementedError
+        self.pad_mode = {"reflection": "reflect", "replicate": "replicate"}.get(padding, "zero")
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3, stride=stride, padding=0)
+
+    def forward(self, x, skip=None, up=1, act="none", slope=0.0):
+        return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, x2=skip, up1=up, pad=self.pad_mode, act=act,
+                                slope=slope)
+
+
+class UpSampleBlock(nn.Module):
+    """nearest x2 -> cat(skip) -> Conv3x3 -> LeakyReLU(0.2) — NYUv2/networks/layers.py:57-67,
+    executed as one fused kernel."""
+
+    def __init__(self, skip_input, output_features, padding="zero", is_depthwise=False):
+        super().__init__()
+        self.convA = NyuConv3x3(skip_input, output_features, padding=padding, is_depthwise=is_depthwise)
+
+    def forward(self, x, concat_with):
+        return self.convA(x, skip=concat_with, up=2, act="leaky", slope=0.2)

@@ -1,0 +1,286 @@
+"""Operator layer: torch tensors in, torch tensors out, every FLOP in libwmd_hip.so.
+
+Each function mirrors one reference operator group (file:line under /root/reference):
+  conv2d_fused   ConvBlock / Conv3x3 / Conv1x1 + upsample + skip concat
+                 (KITTI/layers.py:120-173,233-236; depth_decoder.py:145-150;
+                  NYUv2/networks/layers.py:11-32,57-67)
+  head3x3        last Conv3x3 of the wavelet heads + sigmoid + 2^(s-1)(s+ - s-)
+                 (depth_decoder.py:104-136; densedepth_decoder.py:106-115)
+  idwt_haar      IDWT(wave="haar", mode="zero") + disparity normalisation (depth_decoder.py:164-166)
+  dwt_haar       DWT(J, "haar", "reflect") on even sizes (NYUv2/train.py:258,289)
+All of them are differentiable (torch.autograd.Function with hand-written HIP backward kernels).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT, PAD, check, current_stream, ptr
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.WmdError("wavelet_monodepth_amd ops run on the MI355X only (got a %s tensor); "
+                                "there is no CPU implementation in the package" % t.device)
+        if t.dtype != torch.float32:
+            raise _lib.WmdError("fp32 tensors expected, got %s" % t.dtype)
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing
+# ---------------------------------------------------------------------------------------------
+
+def pack_weights(weight, dgrad=False):
+    """[Cout,Cin,k,k] -> MFMA fragment image (wmd_conv_pack_weights[_dgrad])."""
+    l = _lib.lib()
+    cout, cin, k, _ = weight.shape
+    n = l.wmd_conv_packed_weight_floats(cout, cin, k)
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    fn = l.wmd_conv_pack_weights_dgrad if dgrad else l.wmd_conv_pack_weights
+    check(fn(ptr(_c(weight.detach())), ptr(wp), cout, cin, k, current_stream()), "wmd_conv_pack_weights")
+    return wp
+
+
+# ---------------------------------------------------------------------------------------------
+# dense convolution
+# ---------------------------------------------------------------------------------------------
+
+def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1):
+    l = _lib.lib()
+    B, C1 = x1.shape[0], x1.shape[1]
+    H, W = x1.shape[2] * up1, x1.shape[3] * up1
+    C2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None and (x2.shape[0] != B or x2.shape[2] != H or x2.shape[3] != W):
+        raise _lib.WmdError("skip tensor %s does not match upsampled input %s" % (tuple(x2.shape), (B, C1, H, W)))
+    y = torch.empty((B, cout, H, W), device=x1.device, dtype=torch.float32)
+    a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad], act=ACT[act],
+                      slope=float(slope), x1=ptr(x1), x2=ptr(x2), wp=ptr(wp), bias=ptr(bias), y=ptr(y),
+                      workspace=None, workspace_floats=0)
+    ws_n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
+    ws = None
+    if ws_n:
+        ws = torch.empty(ws_n, device=x1.device, dtype=torch.float32)
+        a.workspace = ptr(ws)
+        a.workspace_floats = ws_n
+    check(l.wmd_conv_fwd(C.byref(a), current_stream()), "wmd_conv_fwd")
+    return y
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, ksize, pad, act, slope, up1):
+        x1c, x2c = _c(x1), _c(x2)
+        wp = pack_weights(weight)
+        y = _conv_fwd_raw(x1c, x2c, wp, _c(bias), weight.shape[0], ksize, pad, act, slope, up1)
+        ctx.save_for_backward(x1c, x2c, weight, y)
+        ctx.has_x2 = x2 is not None
+        ctx.has_bias = bias is not None
+        ctx.cfg = (ksize, pad, act, slope, up1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        l = _lib.lib()
+        x1, x2, weight, y = ctx.saved_tensors
+        ksize, pad, act, slope, up1 = ctx.cfg
+        s = current_stream()
+        dy = _c(dy)
+        B, cout, H, W = y.shape
+        C1 = x1.shape[1]
+        C2 = 0 if x2 is None else x2.shape[1]
+        if ACT[act] != 0:
+            dz = torch.empty_like(dy)
+            check(l.wmd_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), ACT[act], float(slope), s), "wmd_act_bwd")
+        else:
+            dz = dy
+        need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and x2 is not None, ctx.needs_input_grad[2]
+        dx1 = dx2 = dw = db = None
+        if need_x1 or need_x2:
+            wpd = pack_weights(weight, dgrad=True)
+            dx1 = torch.empty_like(x1) if need_x1 else None
+            dx2 = torch.empty_like(x2) if need_x2 else None
+            a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
+                                   dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=ptr(dx2), workspace=None,
+                                   workspace_floats=0)
+            n = l.wmd_conv_dgrad_workspace_floats(C.byref(a))
+            ws = torch.empty(max(n, 1), device=dy.device, dtype=torch.float32)
+            a.workspace, a.workspace_floats = ptr(ws), n
+            check(l.wmd_conv_dgrad(C.byref(a), s), "wmd_conv_dgrad")
+        if need_w or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw = torch.empty_like(weight)
+            db = torch.empty(cout, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+            a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
+                                   x1=ptr(x1), x2=ptr(x2), dz=ptr(dz), dw=ptr(dw), dbias=ptr(db), workspace=None,
+                                   workspace_floats=0)
+            n = l.wmd_conv_wgrad_workspace_floats(C.byref(a))
+            ws = torch.empty(max(n, 1), device=dy.device, dtype=torch.float32)
+            a.workspace, a.workspace_floats = ptr(ws), n
+            check(l.wmd_conv_wgrad(C.byref(a), s), "wmd_conv_wgrad")
+        return dx1, dx2, dw, db, None, None, None, None, None
+
+
+def conv2d_fused(x1, weight, bias=None, x2=None, up1=1, pad="reflect", act="none", slope=0.0):
+    """act( conv_kxk( pad( cat[ nearest_up(x1, up1), x2 ] ) ) + bias ), k taken from `weight`."""
+    _require_gpu(x1, x2, weight, bias)
+    ksize = weight.shape[-1]
+    cin = x1.shape[1] + (0 if x2 is None else x2.shape[1])
+    if weight.shape[1] != cin:
+        raise _lib.WmdError("weight expects %d input channels, got %d" % (weight.shape[1], cin))
+    return _ConvFn.apply(x1, x2, weight, bias, ksize, pad, act, slope, up1)
+
+
+# ---------------------------------------------------------------------------------------------
+# wavelet heads
+# ---------------------------------------------------------------------------------------------
+
+def _head_raw(xp, wp_, bp, xn, wn, bn, pad, mode, scale, save_sig):
+    l = _lib.lib()
+    B, Cc, H, W = xp.shape
+    cout = wp_.shape[0]
+    y = torch.empty((B, cout, H, W), device=xp.device, dtype=torch.float32)
+    sp = torch.empty_like(y) if (save_sig and mode >= 1) else None
+    sn = torch.empty_like(y) if (save_sig and mode == 2) else None
+    a = _lib.HeadArgs(B=B, H=H, W=W, C=Cc, Cout=cout, pad_mode=PAD[pad], mode=mode, scale=float(scale),
+                      xp=ptr(xp), wgt_p=ptr(wp_), bias_p=ptr(bp), xn=ptr(xn), wgt_n=ptr(wn), bias_n=ptr(bn),
+                      y=ptr(y), sig_p=ptr(sp), sig_n=ptr(sn))
+    check(l.wmd_head3x3_fwd(C.byref(a), current_stream()), "wmd_head3x3_fwd")
+    return y, sp, sn
+
+
+class _HeadFn(torch.autograd.Function):
+    """y = scale*conv(xp) | scale*sigmoid(conv(xp)) | scale*(sigmoid(conv_p(xp)) - sigmoid(conv_n(xn))).
+    Backward reuses the generic MFMA dgrad/wgrad kernels on dz = dy*scale*sigma'(.)"""
+
+    @staticmethod
+    def forward(ctx, xp, wp_, bp, xn, wn, bn, pad, mode, scale):
+        xp, xn = _c(xp), _c(xn)
+        y, sp, sn = _head_raw(xp, _c(wp_), _c(bp), xn, _c(wn), _c(bn), pad, mode, scale,
+                               save_sig=any(ctx.needs_input_grad))
+        ctx.save_for_backward(xp, wp_, xn, wn, sp, sn)
+        ctx.cfg = (pad, mode, scale, bp is not None, bn is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp_, xn, wn, sp, sn = ctx.saved_tensors
+        pad, mode, scale, has_bp, has_bn = ctx.cfg
+        dy = _c(dy)
+        outs = [None] * 9
+        sides = [(xp, wp_, sp, +1.0, 0, has_bp)]
+        if mode == 2:
+            sides.append((xn, wn, sn, -1.0, 3, has_bn))
+        for x, w, sig, sign, base, has_b in sides:
+            if mode == 0:
+                dz = dy * (sign * scale)
+            else:
+                dz = dy * sig * (1.0 - sig) * (sign * scale)
+            dx, dw, db = _conv_backward_raw(x, None, w, dz, 3, pad, 1, has_b,
+                                            ctx.needs_input_grad[base], True)
+            outs[base], outs[base + 1], outs[base + 2] = dx, dw, db
+        return tuple(outs)
+
+
+def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, need_w):
+    """dgrad + wgrad through the C ABI for an already-differentiated pre-activation gradient dz."""
+    l = _lib.lib()
+    s = current_stream()
+    B, cout, H, W = dz.shape
+    C1 = x1.shape[1]
+    C2 = 0 if x2 is None else x2.shape[1]
+    dz = _c(dz)
+    dx1 = dw = db = None
+    if need_x:
+        wpd = pack_weights(weight, dgrad=True)
+        dx1 = torch.empty_like(x1)
+        a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
+                               dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=None, workspace=None, workspace_floats=0)
+        n = l.wmd_conv_dgrad_workspace_floats(C.byref(a))
+        ws = torch.empty(max(n, 1), device=dz.device, dtype=torch.float32)
+        a.workspace, a.workspace_floats = ptr(ws), n
+        check(l.wmd_conv_dgrad(C.byref(a), s), "wmd_conv_dgrad")
+    if need_w:
+        dw = torch.empty_like(weight)
+        db = torch.empty(cout, device=dz.device, dtype=torch.float32) if has_bias else None
+        a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
+                               x1=ptr(x1), x2=ptr(x2), dz=ptr(dz), dw=ptr(dw), dbias=ptr(db), workspace=None,
+                               workspace_floats=0)
+        n = l.wmd_conv_wgrad_workspace_floats(C.byref(a))
+        ws = torch.empty(max(n, 1), device=dz.device, dtype=torch.float32)
+        a.workspace, a.workspace_floats = ptr(ws), n
+        check(l.wmd_conv_wgrad(C.byref(a), s), "wmd_conv_wgrad")
+    return dx1, dw, db
+
+
+def head3x3(xp, weight_p, bias_p, xn=None, weight_n=None, bias_n=None, pad="reflect", mode=0, scale=1.0):
+    _require_gpu(xp, weight_p, bias_p, xn, weight_n, bias_n)
+    return _HeadFn.apply(xp, weight_p, bias_p, xn, weight_n, bias_n, pad, mode, scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# Haar transforms
+# ---------------------------------------------------------------------------------------------
+
+class _IdwtFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, yl, yh, disp_scale, clamp01, want_disp):
+        l = _lib.lib()
+        yl, yh = _c(yl), _c(yh)
+        B, Cc, h, w = yl.shape
+        out = torch.empty((B, Cc, 2 * h, 2 * w), device=yl.device, dtype=torch.float32)
+        disp = torch.empty_like(out) if want_disp else None
+        check(l.wmd_idwt_haar_fwd(ptr(yl), ptr(yh), ptr(out), ptr(disp), B * Cc, h, w, float(disp_scale),
+                                  int(clamp01), current_stream()), "wmd_idwt_haar_fwd")
+        ctx.save_for_backward(out)
+        ctx.cfg = (disp_scale, clamp01, want_disp, tuple(yl.shape), tuple(yh.shape))
+        if want_disp:
+            return out, disp
+        return out, out.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, d_out, d_disp):
+        l = _lib.lib()
+        (out,) = ctx.saved_tensors
+        disp_scale, clamp01, want_disp, sl, sh = ctx.cfg
+        d_yl = torch.empty(sl, device=out.device, dtype=torch.float32)
+        d_yh = torch.empty(sh, device=out.device, dtype=torch.float32)
+        d_out = _c(d_out) if d_out is not None else None
+        d_disp = _c(d_disp) if (want_disp and d_disp is not None) else None
+        check(l.wmd_idwt_haar_bwd(ptr(d_out), ptr(d_disp), ptr(out), ptr(d_yl), ptr(d_yh), sl[0] * sl[1], sl[2], sl[3],
+                                  float(disp_scale), int(clamp01), current_stream()), "wmd_idwt_haar_bwd")
+        return d_yl, d_yh, None, None, None
+
+
+def idwt_haar(yl, yh, disp_scale=None, clamp01=False):
+    """yl [B,C,h,w], yh [B,C,3,h,w] -> (out [B,C,2h,2w], disp or None) with disp = clamp?(out*disp_scale)."""
+    _require_gpu(yl, yh)
+    if yh.dim() != 5 or yh.shape[2] != 3 or yh.shape[:2] != yl.shape[:2] or yh.shape[3:] != yl.shape[2:]:
+        raise _lib.WmdError("idwt_haar: yl %s / yh %s mismatch" % (tuple(yl.shape), tuple(yh.shape)))
+    want = disp_scale is not None
+    out, disp = _IdwtFn.apply(yl, yh, 1.0 if disp_scale is None else disp_scale, clamp01, want)
+    return out, (disp if want else None)
+
+
+def dwt_haar(x, J=1):
+    """J-level Haar analysis of x [B,C,H,W] (H, W divisible by 2^J). Returns (yl, [yh_fine..yh_coarse]).
+    The reference only uses it on ground truth (no gradient, NYUv2/train.py:289)."""
+    _require_gpu(x)
+    l = _lib.lib()
+    ll = _c(x.detach())
+    yh = []
+    for _ in range(J):
+        B, Cc, H, W = ll.shape
+        if H % 2 or W % 2:
+            raise _lib.WmdError("dwt_haar: odd size %dx%d (reference pads by reflection; not needed on its inputs)" % (H, W))
+        nl = torch.empty((B, Cc, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        nh = torch.empty((B, Cc, 3, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        check(l.wmd_dwt_haar_fwd(ptr(ll), ptr(nl), ptr(nh), B * Cc, H // 2, W // 2, current_stream()), "wmd_dwt_haar_fwd")
+        yh.append(nh)
+        ll = nl
+    return ll, yh
