@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Headline benchmark: decoder+IDWT forward frames/sec @640x192, batch 12 per GPU (BASELINE.json).
+
+A "step" = one forward of DepthWaveProgressiveDecoder (ResNet18 channels) over one synthetic batch of
+encoder features already resident in HBM: 8 fused 3x3 MFMA convolutions, 9 wavelet heads, 4 Haar IDWTs
+-> 4 disparity maps + 16 coefficient planes.  N GPUs = N independent shards of the batch dimension
+(weak scaling; the forward path has no exchange step, so no collective is issued).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+R18 = [64, 64, 128, 256, 512]
+HEIGHT, WIDTH, BATCH = 192, 640, 12
+FLOP_PER_FRAME = 6.947e9     # conv MACs x2, SURVEY.md §8(d) / BASELINE.md §2
+PEAK_F32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+
+
+def build_model(dev):
+    from wavelet_monodepth_amd import synth
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=1).to(dev)
+    feats = [torch.from_numpy(f).to(dev) for f in synth.encoder_features(BATCH, HEIGHT, WIDTH, R18, seed=1)]
+    return dec, feats
+
+
+def cpu_baseline(dec, feats, budget_s=20.0):
+    """The CPU oracle (PyTorch-CPU/oneDNN restatement of the reference decoder) on the host cores,
+    on a bounded sample of the same workload.  oneDNN does not scale to every hardware thread of a big
+    host, so a 2-frame probe picks the best thread count first (the baseline gets its best case),
+    then whole 12-frame batches are timed until ~budget_s elapsed."""
+    from oracle import decoder_ref as R
+
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    cf = [f.cpu() for f in feats]
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cands = sorted({c for c in (avail, avail // 2, 64, 32, 16, 8) if 1 <= c <= avail}, reverse=True)
+    probe = [f[:2] for f in cf]
+    best, best_t = cands[-1], float("inf")
+    with torch.no_grad():
+        for c in cands:
+            torch.set_num_threads(c)
+            R.kitti_wave_decoder(probe, sd)
+            t0 = time.perf_counter()
+            R.kitti_wave_decoder(probe, sd)
+            dt = time.perf_counter() - t0
+            if dt < best_t:
+                best, best_t = c, dt
+        torch.set_num_threads(best)
+        R.kitti_wave_decoder(cf, sd)  # warm-up at the full batch
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 30):
+            t0 = time.perf_counter()
+            R.kitti_wave_decoder(cf, sd)
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(BATCH / med, 2), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": "%d timed passes of the same 12x640x192 batch (median %.3f s/pass) after 1 warm-up; torch %s CPU; "
+                      "%d threads = best of %s on a 2-frame probe; host exposes %d hardware threads"
+                      % (len(times), med, torch.__version__, best, cands, avail)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wavelet_monodepth_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+
+    dec, feats = build_model(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            dec(feats)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = dec(feats)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert all(torch.isfinite(v).all() for v in out.values())
+
+    # kernel-level roofline: the same K steps again with hipEvent pairs around every launch
+    roof = None
+    if rank == 0:
+        with torch.no_grad():
+            _lib.profile_begin()
+            for _ in range(args.steps):
+                dec(feats)
+            recs = _lib.profile_end()
+        convs = [r for r in recs if r["kernel"].startswith("conv_fwd_kernel")]
+        dom = max(convs, key=lambda r: r["ms"])
+        tot_ms = sum(r["ms"] for r in recs)
+        conv_ms = sum(r["ms"] for r in convs)
+        conv_fl = sum(r["flops"] for r in convs)
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": None,
+                "kernel": dom["kernel"], "launches_per_step": dom["calls"] // args.steps,
+                "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
+                "flop_per_launch": dom["flops"] / dom["calls"],
+                "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                     "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
+                                     "share_of_gpu_time": round(conv_ms / tot_ms, 3)},
+                "whole_step": {"achieved": round(FLOP_PER_FRAME * BATCH * args.steps / (tot_ms * 1e-3) / 1e12, 2),
+                               "gpu_ms_per_step": round(tot_ms / args.steps, 4)},
+                "kernels_ms_per_step": {r["kernel"]: round(r["ms"] / args.steps, 4) for r in recs}}
+
+    if rank == 0:
+        frames = BATCH * args.steps * world
+        res = {
+            "metric": "decoder+IDWT frames/sec @640x192 bs12",
+            "value": round(frames / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "KITTI ResNet18 640x192 dense wavelet decoder + 4x Haar IDWT, forward, batch 12 per GPU "
+                                   "(BASELINE.json configs[1]); encoder features resident in HBM",
+                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d (independent shards)" % world},
+            "roofline": roof,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(dec, feats),
+        }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

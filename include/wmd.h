@@ -51,6 +51,14 @@ int wmd_version(void);
 const char* wmd_last_error(void);
 const char* wmd_status_string(int status);
 
+/* Opt-in kernel timing (the only process-global state in the library; not thread-safe).
+ * Between begin and end every kernel launch of this library is bracketed by a hipEvent pair on
+ * its launch stream.  wmd_profile_end synchronises and writes a JSON array
+ *   [{"kernel": name, "calls": n, "ms": total, "flops": algorithmic FLOPs, "bytes": algorithmic bytes}, ...]
+ * into buf (truncated to cap); returns the number of bytes needed, or a negative wmd_status.    */
+int wmd_profile_begin(void);
+long wmd_profile_end(char* buf, size_t cap);
+
 /* ------------------------------------------------------------------ *
  * Haar wavelets  (third-party pytorch_wavelets; call sites
  * KITTI/networks/decoders/depth_decoder.py:85,164,372,416,

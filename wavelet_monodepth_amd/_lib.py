@@ -63,6 +63,8 @@ SIGNATURES = {
     "wmd_version": (C.c_int, []),
     "wmd_last_error": (C.c_char_p, []),
     "wmd_status_string": (C.c_char_p, [C.c_int]),
+    "wmd_profile_begin": (C.c_int, []),
+    "wmd_profile_end": (C.c_long, [C.c_char_p, C.c_size_t]),
     "wmd_idwt_haar_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]),
     "wmd_idwt_haar_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]),
     "wmd_dwt_haar_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
@@ -125,3 +127,18 @@ def current_stream():
     import torch
 
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_begin():
+    check(lib().wmd_profile_begin(), "wmd_profile_begin")
+
+
+def profile_end():
+    """-> list of {"kernel", "calls", "ms", "flops", "bytes"} aggregated per kernel name."""
+    import json
+
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().wmd_profile_end(buf, len(buf))
+    if n < 0:
+        check(int(n), "wmd_profile_end")
+    return json.loads(buf.value.decode())

@@ -293,7 +293,8 @@ static void launch_cfg(const ConvKArgs& a, dim3 grid, hipStream_t s) {
 #define WMD_CFG(TH, TW, MR, NR, WM, WN, CK, TAPS)                                                       \
     ConvCfg {                                                                                           \
         TH, TW, MR, NR, WM, WN, CK, TAPS, (int)sizeof(float) * ConvTile<TH, TW, MR, NR, WM, WN, CK, TAPS>::LDS_FLOATS, \
-            &launch_cfg<TH, TW, MR, NR, WM, WN, CK, TAPS>, #TH "x" #TW "_m" #MR "n" #NR "_w" #WM "x" #WN "_k" #CK "_t" #TAPS \
+            &launch_cfg<TH, TW, MR, NR, WM, WN, CK, TAPS>,                                              \
+            "conv_fwd_kernel<" #TH "," #TW "," #MR "," #NR "," #WM "," #WN "," #CK "," #TAPS ">"         \
     }
 
 static const ConvCfg kCfgs[] = {
@@ -414,6 +415,7 @@ static int pack_common(const float* w, float* wp, int Cout, int Cin, int ksize, 
     const int ncot = (rows + 15) / 16, nci4 = ((red + 15) / 16) * 4;
     const size_t total = (size_t)ncot * nci4 * taps * 64;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    ProfScope prof("conv_pack_kernel", 0.0, 8.0 * total, (hipStream_t)stream);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, taps, ncot,
                        nci4, dgrad);
     return check_launch("conv_pack_kernel");
@@ -490,12 +492,20 @@ extern "C" int wmd_conv_fwd(const wmd_conv_args* g, void* stream) {
     if (env_int("WMD_CONV_VERBOSE", 0))
         fprintf(stderr, "[wmd] conv %dx%d C%d+%d->%d k%d: cfg %s grid %u,%u,%u\n", g->H, g->W, g->C1, g->C2, g->Cout,
                 g->ksize, c.name, grid.x, grid.y, grid.z);
-    c.launch(a, grid, (hipStream_t)stream);
+    const double pix = (double)g->B * g->H * g->W;
+    {
+        // algorithmic work: 2*Cin*k*k*Cout FLOP per output pixel; bytes: inputs + weights + outputs once
+        ProfScope prof(c.name, 2.0 * a.Cin * taps * g->Cout * pix,
+                       4.0 * (pix * g->C1 / (a.up1 * a.up1) + pix * g->C2 + (double)a.Cin * taps * g->Cout + pix * g->Cout),
+                       (hipStream_t)stream);
+        c.launch(a, grid, (hipStream_t)stream);
+    }
     st = check_launch("conv_fwd_kernel");
     if (st) return st;
     if (plan.ksplit > 1) {
         const size_t n = (size_t)g->B * g->Cout * g->H * g->W;
         const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+        ProfScope prof("conv_splitk_reduce_kernel", (double)n * plan.ksplit, 4.0 * n * (plan.ksplit + 1), (hipStream_t)stream);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->workspace,
                            g->bias, g->y, n, (size_t)g->H * g->W, g->Cout, plan.ksplit, g->act, g->slope);
         st = check_launch("conv_splitk_reduce_kernel");

@@ -139,6 +139,8 @@ extern "C" int wmd_head3x3_fwd(const wmd_head_args* g, void* stream) {
     const int tiles_x = (g->W + HT_W - 1) / HT_W, tiles_y = (g->H + HT_H - 1) / HT_H;
     dim3 grid((unsigned)((size_t)g->B * tiles_x * tiles_y));
     hipStream_t s = (hipStream_t)stream;
+    const double pix = (double)g->B * g->H * g->W, sides = g->mode == 2 ? 2.0 : 1.0;
+    ProfScope prof("head3x3_kernel", sides * 18.0 * g->C * g->Cout * pix, 4.0 * pix * (sides * g->C + g->Cout), s);
     switch (g->Cout) {
         case 1: hipLaunchKernelGGL(head3x3_kernel<1>, grid, dim3(256), 0, s, *g, tiles_x, tiles_y); break;
         case 2: hipLaunchKernelGGL(head3x3_kernel<2>, grid, dim3(256), 0, s, *g, tiles_x, tiles_y); break;

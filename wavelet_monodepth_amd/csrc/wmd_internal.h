@@ -27,6 +27,21 @@ inline int check_launch(const char* what) {
 
 constexpr int kNumCU = 256;  // MI355X
 
+// Opt-in per-launch timing (wmd_profile_begin/end). Zero cost when off: one predictable branch.
+extern bool g_prof_on;
+int prof_open(const char* name, double flops, double bytes, hipStream_t s);
+void prof_close(int idx, hipStream_t s);
+struct ProfScope {
+    int idx;
+    hipStream_t s;
+    ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : idx(-1), s(stream) {
+        if (g_prof_on) idx = prof_open(name, flops, bytes, stream);
+    }
+    ~ProfScope() {
+        if (idx >= 0) prof_close(idx, s);
+    }
+};
+
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
         case WMD_ACT_ELU: return v > 0.f ? v : expm1f(v);

@@ -9,6 +9,7 @@
 // Algorithmic traffic: 4 coefficient reads + 4 output writes per 2x2 block = 8 B per output pixel
 // (12 B when the normalised `disp` plane is written too).  Each thread handles two horizontally
 // adjacent coefficient positions: float2 coefficient loads, float4 output stores, fully coalesced.
+#include <algorithm>
 #include "wmd_internal.h"
 
 namespace wmd {
@@ -157,6 +158,8 @@ extern "C" int wmd_idwt_haar_fwd(const float* yl, const float* yh, float* out, f
     if (!yl || !yh || !out) return fail(WMD_ERR_BAD_ARG, "wmd_idwt_haar_fwd: null pointer");
     if (N < 0 || h <= 0 || w <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_idwt_haar_fwd: N=%d h=%d w=%d", N, h, w);
     if (N == 0) return WMD_OK;
+    // 8 B moved and 4 FLOP per output pixel (reference op model depth_decoder.py:373), 12 B with disp
+    ProfScope prof("idwt_haar_fwd_kernel", 16.0 * N * h * w, (disp ? 48.0 : 32.0) * N * h * w, (hipStream_t)stream);
     if ((w & 1) == 0) {
         const size_t work = (size_t)N * h * (w / 2);
         hipLaunchKernelGGL(idwt_haar_fwd_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, yl, yh,
@@ -176,6 +179,7 @@ extern "C" int wmd_idwt_haar_bwd(const float* d_out, const float* d_disp, const 
     if (N < 0 || h <= 0 || w <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_idwt_haar_bwd: N=%d h=%d w=%d", N, h, w);
     if (N == 0) return WMD_OK;
     const size_t work = (size_t)N * h * w;
+    ProfScope prof("haar_analysis_kernel", 16.0 * work, (d_out && d_disp ? 64.0 : 32.0) * work, (hipStream_t)stream);
     hipLaunchKernelGGL(haar_analysis_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, d_out,
                        d_disp, out, d_yl, d_yh, N, h, w, disp_scale, clamp01);
     return check_launch("haar_analysis_kernel");
@@ -186,6 +190,7 @@ extern "C" int wmd_dwt_haar_fwd(const float* x, float* yl, float* yh, int N, int
     if (N < 0 || h <= 0 || w <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_dwt_haar_fwd: N=%d h=%d w=%d", N, h, w);
     if (N == 0) return WMD_OK;
     const size_t work = (size_t)N * h * w;
+    ProfScope prof("haar_analysis_kernel", 16.0 * work, 32.0 * work, (hipStream_t)stream);
     hipLaunchKernelGGL(haar_analysis_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        (const float*)nullptr, (const float*)nullptr, yl, yh, N, h, w, 1.f, 0);
     return check_launch("haar_analysis_kernel");
@@ -195,6 +200,7 @@ extern "C" int wmd_act_bwd(const float* dy, const float* y, float* dz, size_t n,
     if (!dy || !y || !dz) return fail(WMD_ERR_BAD_ARG, "wmd_act_bwd: null pointer");
     if (act < 0 || act > 3) return fail(WMD_ERR_BAD_ARG, "wmd_act_bwd: act=%d", act);
     if (n == 0) return WMD_OK;
+    ProfScope prof("act_bwd_kernel", (double)n, 12.0 * n, (hipStream_t)stream);
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dz, n, act,
                        slope);
     return check_launch("act_bwd_kernel");
