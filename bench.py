@@ -34,6 +34,7 @@ def build_model(dev):
     from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
 
     dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=1).to(dev)
+    dec.enable_graph(os.environ.get("WMD_BENCH_GRAPH", "1") != "0")
     feats = [torch.from_numpy(f).to(dev) for f in synth.encoder_features(BATCH, HEIGHT, WIDTH, R18, seed=1)]
     return dec, feats
 
@@ -126,6 +127,8 @@ def main():
     roof = None
     if rank == 0:
         with torch.no_grad():
+            dec.enable_graph(False)   # per-launch hipEvents need eager launches
+            dec(feats)
             _lib.profile_begin()
             for _ in range(args.steps):
                 dec(feats)

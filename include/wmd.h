@@ -117,6 +117,8 @@ typedef struct {
     float* y;           /* [B,Cout,H,W]                                                */
     float* workspace;   /* split-K partial sums; may be NULL -> never split            */
     size_t workspace_floats;
+    int tune_cfg;       /* 0: built-in cost model; k>0: force tile configuration k-1     */
+    int tune_ksplit;    /* 0: cost model; k>0: force k-way split of the Cin reduction    */
 } wmd_conv_args;
 
 /* Fused  upsample(x1) ++ x2  ->  pad  ->  conv kxk  ->  + bias  ->  activation.
@@ -127,6 +129,12 @@ int wmd_conv_fwd(const wmd_conv_args* args, void* stream);
 
 /* Suggested workspace size (floats) for wmd_conv_fwd on this problem. */
 size_t wmd_conv_fwd_workspace_floats(const wmd_conv_args* args);
+
+/* Tile-configuration table (for callers that autotune: wavelet_monodepth_amd/tuner.py).
+ * wmd_conv_config_name returns e.g. "conv_fwd_kernel<8,32,2,4,1,4,8,9>" (the kernel's template
+ * arguments TH,TW,MR,NR,WM,WN,CK,TAPS) or NULL when i is out of range.                        */
+int wmd_conv_num_configs(void);
+const char* wmd_conv_config_name(int i);
 
 /* dz = dy * act'(y)  (y = the activation OUTPUT saved by the forward). In place allowed. */
 int wmd_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, float slope, void* stream);
@@ -178,6 +186,8 @@ typedef struct {
     float* y;           /* [B,Cout,H,W]                                                 */
     float* sig_p;       /* optional [B,Cout,H,W]: sigmoid outputs saved for backward    */
     float* sig_n;
+    size_t xp_bstride;  /* floats between consecutive batch items of xp / xn; 0 = C*H*W (lets xp, xn be  */
+    size_t xn_bstride;  /* channel slices of one stacked [B,Ctot,H,W] tensor)                             */
 } wmd_head_args;
 
 /* Replaces Conv3x3(C,3|1) + Sigmoid + the 2^(s-1)(sigma+ - sigma-) combine of

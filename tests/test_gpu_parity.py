@@ -124,6 +124,46 @@ def test_conv_forward(dev, case):
     assert_close(y, ref, OP_TOL, "conv")
 
 
+def test_conv_every_tile_configuration_and_split(dev):
+    """Force each entry of the library's configuration table (and several K splits) on one ragged problem."""
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib, ops, tuner
+    B, C1, C2, Cout, H, W = 2, 40, 24, 70, 24, 40
+    x1 = t(synth.normal((B, C1, H // 2, W // 2), "tx1", 9))
+    x2 = t(synth.normal((B, C2, H, W), "tx2", 9))
+    names = tuner.config_names()
+    assert len(names) >= 10
+    for k in (3, 1):
+        w, b = [t(a) for a in synth.conv_params("tw%d" % k, Cout, C1 + C2 if k == 3 else C2, k, 9)]
+        if k == 3:
+            ref = torch.nn.functional.elu(R.conv3x3(torch.cat([R.up2(x1), x2], 1), w, b, "reflect"))
+        else:
+            ref = torch.nn.functional.elu(R.conv1x1(x2, w, b))
+        wp = ops.pack_weights(w.to(dev))
+        xa, xb = (x1.to(dev), x2.to(dev)) if k == 3 else (x2.to(dev), None)
+        l = _lib.lib()
+        tested = 0
+        for i, name in enumerate(names):
+            if not name.endswith(",%d>" % (9 if k == 3 else 1)):
+                continue
+            for ks in (1, 2, 3):
+                y = torch.full((B, Cout, H, W), float("nan"), device=dev)
+                a = _lib.ConvArgs(B=B, H=H, W=W, C1=xa.shape[1], up1=2 if k == 3 else 1, C2=0 if xb is None else C2, Cout=Cout,
+                                  ksize=k, pad_mode=1, act=1, slope=0.0, x1=xa.data_ptr(), x2=None if xb is None else xb.data_ptr(),
+                                  wp=wp.data_ptr(), bias=b.to(dev).data_ptr(), y=y.data_ptr(), workspace=None,
+                                  workspace_floats=0, tune_cfg=i + 1, tune_ksplit=ks)
+                n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
+                ws = torch.empty(max(n, 1), device=dev)
+                a.workspace, a.workspace_floats = ws.data_ptr(), n
+                st = l.wmd_conv_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream)
+                if st == -3 and ks > 1:
+                    continue  # this tile's channel chunk leaves fewer than ks chunks to split
+                _lib.check(st, name)
+                assert_close(y, ref, OP_TOL, "%s ksplit %d" % (name, ks))
+                tested += 1
+        assert tested >= (12 if k == 3 else 4)
+
+
 def test_conv_rejects_bad_input(dev):
     from wavelet_monodepth_amd import ops, _lib
     w = torch.zeros(4, 3, 3, 3, device=dev)
@@ -204,6 +244,31 @@ def test_kitti_dense_decoder_batch12_properties(dev):
         assert_close(out[("wavelets", s, "LL")].cpu(), yl, 1e-6, "LL chain")
         yl = R.haar_idwt(yl, yh)
         assert_close(out[("disp", s)].cpu(), torch.clamp(yl / 2 ** s, 0, 1), 1e-6, "disp%d" % s)
+
+
+def test_kitti_dense_decoder_graph_replay_and_grad_mode_paths_agree(dev):
+    """Three execution paths of the same module: eager no_grad (stacked heads), eager with autograd enabled
+    (per-head operators) and hipGraph replay must produce the same maps."""
+    dec = _kitti_decoder(dev, seed=3)
+    feats = [f.to(dev) for f in kitti_feats(2, 64, 96, seed=3)]
+    with torch.no_grad():
+        ref = {k: v.clone() for k, v in dec(feats).items()}
+    with torch.enable_grad():
+        out_g = dec(feats)
+    for k in ref:
+        assert_close(out_g[k], ref[k], 2e-6, "grad-mode path " + key_str(k))
+    dec.enable_graph(True)
+    with torch.no_grad():
+        for _ in range(3):
+            out = dec(feats)
+        for k in ref:
+            assert_close(out[k], ref[k], 2e-6, "graph replay " + key_str(k))
+        feats2 = [f * 0.5 for f in feats]              # new buffers -> new capture
+        a = {k: v.clone() for k, v in dec(feats2).items()}
+        dec.enable_graph(False)
+        b = dec(feats2)
+        for k in a:
+            assert_close(a[k], b[k], 2e-6, "graph vs eager " + key_str(k))
 
 
 def test_kitti_baseline_decoder_vs_reference_golden(dev):

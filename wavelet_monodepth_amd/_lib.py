@@ -21,7 +21,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
                 ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int), ("slope", C.c_float),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -43,7 +43,8 @@ class HeadArgs(C.Structure):
                 ("pad_mode", C.c_int), ("mode", C.c_int), ("scale", C.c_float),
                 ("xp", C.c_void_p), ("wgt_p", C.c_void_p), ("bias_p", C.c_void_p),
                 ("xn", C.c_void_p), ("wgt_n", C.c_void_p), ("bias_n", C.c_void_p),
-                ("y", C.c_void_p), ("sig_p", C.c_void_p), ("sig_n", C.c_void_p)]
+                ("y", C.c_void_p), ("sig_p", C.c_void_p), ("sig_n", C.c_void_p),
+                ("xp_bstride", C.c_size_t), ("xn_bstride", C.c_size_t)]
 
 
 class SparseConvArgs(C.Structure):
@@ -73,6 +74,8 @@ SIGNATURES = {
     "wmd_conv_pack_weights_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wmd_conv_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "wmd_conv_fwd_workspace_floats": (C.c_size_t, [C.POINTER(ConvArgs)]),
+    "wmd_conv_num_configs": (C.c_int, []),
+    "wmd_conv_config_name": (C.c_char_p, [C.c_int]),
     "wmd_act_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_size_t, C.c_int, C.c_float, C.c_void_p]),
     "wmd_conv_dgrad_workspace_floats": (C.c_size_t, [C.POINTER(ConvDgradArgs)]),
     "wmd_conv_dgrad": (C.c_int, [C.POINTER(ConvDgradArgs), C.c_void_p]),

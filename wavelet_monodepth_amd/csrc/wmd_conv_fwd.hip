@@ -58,7 +58,7 @@ struct ConvTile {
     static constexpr int NPIX = TH * TW;
     static constexpr int LDS_FLOATS = 2 * CK * PS;
     static_assert(WN * NR * 16 >= NPIX, "tile has more pixels than MFMA columns");
-    static_assert(CK == 8 || CK == 16, "CK must be 8 or 16");
+    static_assert(CK % 8 == 0, "CK must be a multiple of 8 (an even number of 4-channel K-steps)");
 };
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const int H = a.H, W = a.W;
 
     // ---- staging geometry: each thread owns NPOS patch positions for every channel ----------
-    int off1[NPOS], off2[NPOS];
+    // byte offsets inside one channel plane of x1 / x2 (32-bit: a plane is far below 4 GiB)
+    unsigned ob1[NPOS], ob2[NPOS];
     bool live[NPOS];
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
         live[i] = ok;
-        off2[i] = gy * W + gx;
-        off1[i] = (a.up1 == 2) ? (gy >> 1) * a.W1 + (gx >> 1) : gy * W + gx;
+        ob2[i] = (unsigned)(gy * W + gx) * 4u;
+        ob1[i] = (unsigned)((a.up1 == 2) ? (gy >> 1) * a.W1 + (gx >> 1) : gy * W + gx) * 4u;
     }
 
     const size_t plane1 = (size_t)a.H1 * a.W1, plane2 = (size_t)H * W;
@@ -112,33 +113,53 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const float* x2b = a.x2 ? a.x2 + (size_t)b * a.C2 * plane2 : nullptr;
 
     float sv[CK][NPOS];
+    // Branch-free per element on purpose: every load is unconditional from a clamped (always legal)
+    // address; the pad/overhang/channel-tail zeroing is a select applied when the registers are written to
+    // LDS, i.e. AFTER the MFMA block, so the loads stay in flight behind the matrix work.  (A conditional
+    // load, or a select right after the load, makes hipcc wait vmcnt(0) before the first MFMA of the chunk.)
+    // Addressing is (wave-uniform 64-bit base) + (32-bit per-lane byte offset): one scalar multiply-add per
+    // channel and one global_load per element when the whole chunk comes from one source tensor.
     auto stage_load = [&](int chunk) {
+        const int c0 = chunk * CK;
+        const bool pure1 = c0 + CK <= a.C1 || a.C2 == 0;
+        const bool pure2 = c0 >= a.C1;
+        if (pure1 || pure2) {
+            const char* base = pure1 ? reinterpret_cast<const char*>(x1b + (size_t)c0 * plane1)
+                                     : reinterpret_cast<const char*>(x2b + (size_t)(c0 - a.C1) * plane2);
+            const size_t pstride = (pure1 ? plane1 : plane2) * sizeof(float);
+            const int jmax = a.Cin - 1 - c0;  // channel tail of the last chunk: re-read a legal plane
+            unsigned ob[NPOS];
 #pragma unroll
-        for (int j = 0; j < CK; ++j) {
-            const int ci = chunk * CK + j;  // wave-uniform
-            if (ci < a.C1) {
-                const float* src = x1b + (size_t)ci * plane1;
+            for (int i = 0; i < NPOS; ++i) ob[i] = pure1 ? ob1[i] : ob2[i];
 #pragma unroll
-                for (int i = 0; i < NPOS; ++i) sv[j][i] = live[i] ? src[off1[i]] : 0.f;
-            } else if (ci < a.Cin) {
-                const float* src = x2b + (size_t)(ci - a.C1) * plane2;
+            for (int j = 0; j < CK; ++j) {
+                const char* bj = base + (size_t)min(j, jmax) * pstride;
 #pragma unroll
-                for (int i = 0; i < NPOS; ++i) sv[j][i] = live[i] ? src[off2[i]] : 0.f;
-            } else {
+                for (int i = 0; i < NPOS; ++i) sv[j][i] = *reinterpret_cast<const float*>(bj + ob[i]);
+            }
+        } else {  // the one chunk that straddles the concat seam
 #pragma unroll
-                for (int i = 0; i < NPOS; ++i) sv[j][i] = 0.f;
+            for (int j = 0; j < CK; ++j) {
+                const int ci = min(c0 + j, a.Cin - 1);
+                const bool from_x1 = ci < a.C1;
+                const char* bj = from_x1 ? reinterpret_cast<const char*>(x1b + (size_t)ci * plane1)
+                                         : reinterpret_cast<const char*>(x2b + (size_t)(ci - a.C1) * plane2);
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) sv[j][i] = *reinterpret_cast<const float*>(bj + (from_x1 ? ob1[i] : ob2[i]));
             }
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, int chunk) {
         float* dst = lds + buf * (CK * PS);
 #pragma unroll
-        for (int j = 0; j < CK; ++j)
+        for (int j = 0; j < CK; ++j) {
+            const bool chan_ok = chunk * CK + j < a.Cin;
 #pragma unroll
             for (int i = 0; i < NPOS; ++i) {
                 const int p = tid + i * NT;
-                if (NPOS * NT == T::NPOSITIONS || p < T::NPOSITIONS) dst[j * PS + p] = sv[j][i];
+                if (NPOS * NT == T::NPOSITIONS || p < T::NPOSITIONS) dst[j * PS + p] = (live[i] && chan_ok) ? sv[j][i] : 0.f;
             }
+        }
     };
 
     // ---- B fragment addressing: lane (l&15) -> pixel q of the tile, (l>>4) -> channel in K-step
@@ -174,26 +195,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) dst[tp][m] = wa[m][(size_t)(ci4 * TAPS + tp) * 64];
+            for (int tp = 0; tp < TAPS; ++tp) dst[tp][m] = wa[m][(size_t)(min(ci4, a.nci4 - 1) * TAPS + tp) * 64];
     };
 
     if (c_begin < c_end) {
         stage_load(c_begin);
         load_a(af[0], c_begin * KSTEPS);
-        stage_store(0);
+        stage_store(0, c_begin);
     }
     __syncthreads();
 
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        const bool more = (c + 1 < c_end);
-        if (more) stage_load(c + 1);
+        const int cn = min(c + 1, c_end - 1);  // the last iteration re-fetches its own chunk: no branch
+        stage_load(cn);
+        __builtin_amdgcn_sched_barrier(0);  // keep the patch loads ahead of the MFMA block (hipcc sinks them otherwise)
         const float* bsrc = lds + buf * (CK * PS);
 
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             const int ci4 = c * KSTEPS + kk;
-            if (ci4 + 1 < ci4_end) load_a(af[(kk + 1) & 1], ci4 + 1);
+            load_a(af[(kk + 1) & 1], min(ci4 + 1, ci4_end - 1));  // unconditional: the last prefetch is redundant
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp) {
                 const int ky = (TAPS == 9) ? tp / 3 : 0, kx = (TAPS == 9) ? tp % 3 : 0;
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][tp][m], bf[n], acc[m][n], 0, 0, 0);
             }
         }
-        if (more) stage_store(buf ^ 1);
+        stage_store(buf ^ 1, cn);
         __syncthreads();
     }
 
@@ -299,6 +321,10 @@ static void launch_cfg(const ConvKArgs& a, dim3 grid, hipStream_t s) {
 
 static const ConvCfg kCfgs[] = {
     // 3x3, 32-wide rows (W % 32 == 0: 160/320, 1024-wide pyramids)
+    WMD_CFG(16, 32, 2, 8, 1, 4, 8, 9),  // co32  x 512px
+    WMD_CFG(8, 32, 2, 8, 1, 2, 8, 9),   // co32  x 256px, 2 waves
+    WMD_CFG(8, 32, 4, 4, 1, 4, 16, 9),  // co64  x 256px, 16-channel chunks
+    WMD_CFG(8, 32, 4, 8, 1, 2, 8, 9),   // co64  x 256px, 2 waves of 64x128
     WMD_CFG(8, 32, 2, 4, 1, 4, 8, 9),   // co32  x 256px
     WMD_CFG(8, 32, 4, 4, 1, 4, 8, 9),   // co64  x 256px
     WMD_CFG(4, 32, 4, 4, 2, 2, 8, 9),   // co128 x 128px
@@ -318,10 +344,10 @@ static const ConvCfg kCfgs[] = {
     WMD_CFG(4, 16, 4, 4, 1, 1, 8, 9),   // co64 x 64px
     WMD_CFG(8, 16, 2, 4, 1, 2, 8, 9),   // co32 x 128px
     // 1x1 on the flattened image (TH = 1)
-    WMD_CFG(1, 256, 4, 4, 1, 4, 8, 1),  // co64  x 256px
-    WMD_CFG(1, 256, 2, 4, 1, 4, 8, 1),  // co32  x 256px
-    WMD_CFG(1, 128, 4, 4, 2, 2, 8, 1),  // co128 x 128px
-    WMD_CFG(1, 64, 4, 4, 1, 1, 8, 1),   // co64  x 64px
+    WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
+    WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px
+    WMD_CFG(1, 128, 4, 4, 2, 2, 32, 1),  // co128 x 128px
+    WMD_CFG(1, 64, 4, 4, 1, 1, 32, 1),   // co64  x 64px
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -343,8 +369,8 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
     const int H = taps == 9 ? g->H : 1;
     const int W = taps == 9 ? g->W : g->H * g->W;
     const int ncot = (g->Cout + 15) / 16;
-    const int force = env_int("WMD_CONV_CFG", -1);
-    const int force_ks = env_int("WMD_CONV_KSPLIT", 0);
+    const int force = g->tune_cfg > 0 ? g->tune_cfg - 1 : env_int("WMD_CONV_CFG", -1);
+    const int force_ks = g->tune_ksplit > 0 ? g->tune_ksplit : env_int("WMD_CONV_KSPLIT", 0);
     double best = 1e300;
     bool found = false;
     for (int i = 0; i < kNumCfgs; ++i) {
@@ -361,9 +387,9 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         int bpc = std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, 8 / waves));
         bpc = std::max(bpc, 1);
         const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * taps;
-        for (int ks = 1; ks <= 16; ks *= 2) {
-            if (force_ks > 0 && ks != force_ks) continue;
-            if (ks > 1 && (!have_ws || nchunks < 2 * ks)) continue;
+        for (int ks = 1; ks <= 32; ++ks) {
+            if (force_ks > 0 ? ks != force_ks : (ks & (ks - 1)) != 0 || ks > 16) continue;  // model: powers of two
+            if (ks > 1 && (!have_ws || nchunks < ks)) continue;
             const int cps = (nchunks + ks - 1) / ks;
             const int ks_eff = (nchunks + cps - 1) / cps;
             if (ks > 1 && (size_t)ks_eff * g->B * g->Cout * g->H * g->W > ws_floats) continue;
@@ -397,6 +423,9 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
 }  // namespace wmd
 
 using namespace wmd;
+
+extern "C" int wmd_conv_num_configs(void) { return kNumCfgs; }
+extern "C" const char* wmd_conv_config_name(int i) { return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : nullptr; }
 
 extern "C" size_t wmd_conv_packed_weight_floats(int Cout, int Cin, int ksize) {
     const int taps = ksize == 3 ? 9 : 1;

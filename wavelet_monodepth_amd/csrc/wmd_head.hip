@@ -1,40 +1,61 @@
-// Wavelet-coefficient heads: 3x3 convolutions with 1..4 output channels (HBM/LDS-bound, VALU).
+// Wavelet-coefficient heads: 3x3 convolutions with 1..4 output channels (VALU, LDS-staged).
 //
 // Replaces the trailing Conv3x3(C,3|1) + Sigmoid of the `waveconv` heads and the
 // 2^(s-1)*(sigmoid(+) - sigmoid(-)) combine of get_coefficients
 // (KITTI/networks/decoders/depth_decoder.py:104-136), and the NYUv2 wave1_ll / wave{1,2,3}
 // convolutions (NYUv2/networks/decoders/densedepth_decoder.py:106-115,122-141).
 //
-// With <= 4 output channels an MFMA tile would be > 75 % padding, so this is a direct convolution:
-// one output pixel per thread, 8x32 pixel tiles, CK-channel halo patches staged through LDS and the
-// filter taps read through the scalar cache (wave-uniform addresses).  Output goes straight into the
-// [B,3,H,W] coefficient plane that the IDWT reads, so the sigmoid/scale/subtract never touch HBM.
+// With <= 4 output channels an MFMA tile would be >= 75 % padding, so this is a direct convolution on
+// the vector ALU (same 157 TFLOP/s fp32 peak as the f32 MFMA):
+//   * block = 128 threads = a 16 x 32 pixel tile; each thread owns 4 horizontally adjacent pixels, so one
+//     ds_read_b128 + one ds_read_b64 per patch row feed 12 taps x 4 pixels (6 LDS instructions per 36*COUT FMAs)
+//   * CK-channel halo patches (18 x 36, rows padded to a multiple of 4 floats so the vector reads are aligned)
+//     staged global -> registers -> LDS, double buffered, one barrier per CK channels
+//   * the CK x COUT x 9 filter taps of the chunk sit in LDS too and are read as wave-uniform (broadcast) b128
+//   * epilogue: sigmoid / scale / (sigma+ - sigma-) and a float4 store per channel straight into the
+//     [B,3,H,W] coefficient plane the IDWT reads.
 #include <algorithm>
 #include "wmd_internal.h"
 
 namespace wmd {
 
-constexpr int HT_H = 8, HT_W = 32, H_CK = 8;
-constexpr int H_PH = HT_H + 2, H_PW = HT_W + 2;
-constexpr int H_PS = H_PH * H_PW + 1;  // odd stride: channel planes start on different banks
+constexpr int HT_H = 16, HT_W = 32, H_CK = 8, H_TT = 128;  // H_TT threads cover the tile once (4 px each)
+constexpr int H_PH = HT_H + 2;        // 18 patch rows
+constexpr int H_PWV = HT_W + 2;       // 34 valid patch columns
+constexpr int H_PW = 36;              // row pitch (multiple of 4 floats)
+constexpr int H_PS = H_PH * H_PW + 4; // channel stride 652 = 12 (mod 32): spreads channel planes over banks
+// NG "channel groups" of H_TT threads share a tile: group g convolves channels g*CK/NG .. of every chunk and the
+// partial sums are reduced through LDS.  NG = 4 (512 threads) gives the coarse levels (few pixels, up to 256
+// channels) 4x the parallelism; staging is always cooperative over all NG*H_TT threads.
 
 template <int COUT>
-__device__ __forceinline__ void head_accumulate(const float* __restrict__ x, const float* __restrict__ wgt, int C,
-                                                int H, int W, int b, int y0, int x0, int pad_mode, float* lds,
-                                                float (&acc)[COUT]) {
-    const int tid = threadIdx.x;
-    const int ly = tid / HT_W, lx = tid % HT_W;
-    const size_t plane = (size_t)H * W;
-    const float* xb = x + (size_t)b * C * plane;
+struct HeadSmem {
+    float patch[2][H_CK * H_PS];
+    float wgt[2][H_CK * COUT * 12];   // 9 taps padded to 12 per (ci, co): three aligned float4
+};
 
-    // staging geometry (positions tid and tid+256 of the 10x34 patch)
-    int off[2];
-    bool live[2];
+template <int COUT, int NG>
+__device__ __forceinline__ void head_side(const float* __restrict__ x, size_t bstride, const float* __restrict__ wgt,
+                                          int C, int H, int W, int b, int y0, int x0, int pad_mode,
+                                          HeadSmem<COUT>& sm, float (&acc)[COUT][4]) {
+    constexpr int H_NT = H_TT * NG;
+    constexpr int H_NPOS = (H_PH * H_PWV + H_NT - 1) / H_NT;
+    constexpr int CPG = H_CK / NG;  // channels per group and chunk
+    const int tid = threadIdx.x;
+    const int grp = tid / H_TT, tt = tid % H_TT;
+    const int ty = tt >> 3, tx = tt & 7;  // 16 rows x 8 column groups of 4 pixels
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * bstride;
+
+    int off[H_NPOS];
+    bool live[H_NPOS];
+    int lpos[H_NPOS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int p = tid + i * 256;
-        int gy = y0 + p / H_PW - 1, gx = x0 + p % H_PW - 1;
-        bool ok = p < H_PH * H_PW;
+    for (int i = 0; i < H_NPOS; ++i) {
+        const int p = min(tid + i * H_NT, H_PH * H_PWV - 1);
+        const int py = p / H_PWV, px = p % H_PWV;
+        int gy = y0 + py - 1, gx = x0 + px - 1;
+        bool ok = (tid + i * H_NT) < H_PH * H_PWV;
         ok = pad_coord(gy, H, pad_mode) && ok;
         ok = pad_coord(gx, W, pad_mode) && ok;
         ok = ok && gy >= 0 && gx >= 0 && gy < H && gx < W;
@@ -42,82 +63,170 @@ __device__ __forceinline__ void head_accumulate(const float* __restrict__ x, con
         gx = min(max(gx, 0), W - 1);
         live[i] = ok;
         off[i] = gy * W + gx;
+        lpos[i] = py * H_PW + px;
     }
+    // weights of a chunk: CK*COUT*9 values, thread t fetches elements t, t+128, ...
+    constexpr int WN = H_CK * COUT * 9;
+    constexpr int WPT = (WN + H_NT - 1) / H_NT;
 
-    for (int c0 = 0; c0 < C; c0 += H_CK) {
-        __syncthreads();  // previous chunk (or previous side) fully consumed
+    float sv[H_CK][H_NPOS];
+    float wv[WPT];
+    const int nchunks = (C + H_CK - 1) / H_CK;
+
+    auto stage_load = [&](int chunk) {
 #pragma unroll
         for (int j = 0; j < H_CK; ++j) {
-            const int ci = c0 + j;
+            const int ci = min(chunk * H_CK + j, C - 1);
             const float* src = xb + (size_t)ci * plane;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int p = tid + i * 256;
-                if (p < H_PH * H_PW) lds[j * H_PS + p] = (ci < C && live[i]) ? src[off[i]] : 0.f;
+            for (int i = 0; i < H_NPOS; ++i) sv[j][i] = src[off[i]];
+        }
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const int e = min(tid + k * H_NT, WN - 1);
+            const int t = e % 9, co = (e / 9) % COUT, j = e / (9 * COUT);
+            const int ci = min(chunk * H_CK + j, C - 1);
+            wv[k] = wgt[((size_t)co * C + ci) * 9 + t];
+        }
+    };
+    auto stage_store = [&](int buf, int chunk) {
+#pragma unroll
+        for (int j = 0; j < H_CK; ++j) {
+            const bool chan_ok = chunk * H_CK + j < C;
+#pragma unroll
+            for (int i = 0; i < H_NPOS; ++i)
+                if (tid + i * H_NT < H_PH * H_PWV) sm.patch[buf][j * H_PS + lpos[i]] = (live[i] && chan_ok) ? sv[j][i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const int e = tid + k * H_NT;
+            if (e < WN) {
+                const int t = e % 9, co = (e / 9) % COUT, j = e / (9 * COUT);
+                sm.wgt[buf][(j * COUT + co) * 12 + t] = (chunk * H_CK + j < C) ? wv[k] : 0.f;
             }
         }
-        __syncthreads();
-        const int nj = min(H_CK, C - c0);
-        for (int j = 0; j < nj; ++j) {
-            const float* pt = lds + j * H_PS + ly * H_PW + lx;
-            float v[9];
+    };
+
+    __syncthreads();  // the previous side (or kernel prologue) is done with both buffers
+    stage_load(0);
+    stage_store(0, 0);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const int cn = min(c + 1, nchunks - 1);
+        stage_load(cn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1  // one channel per trip: full unrolling hoists every LDS read and blows the register file
+        for (int jj = 0; jj < CPG; ++jj) {
+            const int j = grp * CPG + jj;
+            const float* pt = &sm.patch[buf][j * H_PS + ty * H_PW + tx * 4];
+            float v[3][6];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) v[t] = pt[(t / 3) * H_PW + (t % 3)];
+            for (int r = 0; r < 3; ++r) {
+                const float4 lo = *reinterpret_cast<const float4*>(pt + r * H_PW);
+                const float2 hi = *reinterpret_cast<const float2*>(pt + r * H_PW + 4);
+                v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y;
+            }
 #pragma unroll
             for (int co = 0; co < COUT; ++co) {
-                const float* wk = wgt + ((size_t)co * C + (c0 + j)) * 9;  // wave-uniform -> scalar loads
+                const float* wk = &sm.wgt[buf][(j * COUT + co) * 12];  // wave-uniform address: broadcast reads
+                const float4 w0 = *reinterpret_cast<const float4*>(wk);
+                const float4 w1 = *reinterpret_cast<const float4*>(wk + 4);
+                const float w8 = wk[8];
+                const float w[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w8};
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc[co] = fmaf(wk[t], v[t], acc[co]);
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[co][q] = fmaf(w[t], v[t / 3][t % 3 + q], acc[co][q]);
             }
+        }
+        stage_store(buf ^ 1, cn);
+        __syncthreads();
+    }
+    if (NG > 1) {
+        // reduce the channel groups' partial sums into group 0 (the patch buffers are free now)
+        float* red = &sm.patch[0][0];
+        if (grp > 0) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[((grp - 1) * COUT * 4 + co * 4 + q) * H_TT + tt] = acc[co][q];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < NG; ++g)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[co][q] += red[((g - 1) * COUT * 4 + co * 4 + q) * H_TT + tt];
         }
     }
 }
 
-template <int COUT>
-__global__ __launch_bounds__(256) void head3x3_kernel(const wmd_head_args a, int tiles_x, int tiles_y) {
-    __shared__ float lds[H_CK * H_PS];
+template <int COUT, int NG>
+__global__ __launch_bounds__(H_TT* NG) void head3x3_kernel(const wmd_head_args a, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) HeadSmem<COUT> sm;
     int t = blockIdx.x;
-    const int tx = t % tiles_x;
+    const int tx_ = t % tiles_x;
     t /= tiles_x;
-    const int ty = t % tiles_y;
+    const int ty_ = t % tiles_y;
     const int b = t / tiles_y;
-    const int y0 = ty * HT_H, x0 = tx * HT_W;
-    const int oy = y0 + threadIdx.x / HT_W, ox = x0 + threadIdx.x % HT_W;
-    const bool ok = oy < a.H && ox < a.W;
+    const int y0 = ty_ * HT_H, x0 = tx_ * HT_W;
+    const int tt_ = threadIdx.x % H_TT;
+    const int oy = y0 + (tt_ >> 3), ox = x0 + (tt_ & 7) * 4;
 
-    float accp[COUT], accn[COUT];
+    float accp[COUT][4], accn[COUT][4];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-        accp[co] = a.bias_p ? a.bias_p[co] : 0.f;
-        accn[co] = 0.f;
-    }
-    head_accumulate<COUT>(a.xp, a.wgt_p, a.C, a.H, a.W, b, y0, x0, a.pad_mode, lds, accp);
-    if (a.mode == 2) {
+    for (int co = 0; co < COUT; ++co)
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) accn[co] = a.bias_n ? a.bias_n[co] : 0.f;
-        head_accumulate<COUT>(a.xn, a.wgt_n, a.C, a.H, a.W, b, y0, x0, a.pad_mode, lds, accn);
-    }
-    if (!ok) return;
+        for (int q = 0; q < 4; ++q) {
+            const bool g0 = threadIdx.x < H_TT;  // the bias enters once, through group 0
+            accp[co][q] = (g0 && a.bias_p) ? a.bias_p[co] : 0.f;
+            accn[co][q] = (g0 && a.mode == 2 && a.bias_n) ? a.bias_n[co] : 0.f;
+        }
+    const size_t plane_ = (size_t)a.H * a.W;
+    head_side<COUT, NG>(a.xp, a.xp_bstride ? a.xp_bstride : a.C * plane_, a.wgt_p, a.C, a.H, a.W, b, y0, x0, a.pad_mode, sm, accp);
+    if (a.mode == 2)
+        head_side<COUT, NG>(a.xn, a.xn_bstride ? a.xn_bstride : a.C * plane_, a.wgt_n, a.C, a.H, a.W, b, y0, x0, a.pad_mode, sm, accn);
+
+    if (threadIdx.x >= H_TT || oy >= a.H || ox >= a.W) return;
     const size_t plane = (size_t)a.H * a.W;
     const size_t o = (size_t)b * COUT * plane + (size_t)oy * a.W + ox;
+    const bool vec = (ox + 3 < a.W) && ((a.W & 3) == 0);
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
-        float r;
-        if (a.mode == 0) {
-            r = a.scale * accp[co];
-        } else {
-            const float sp = 1.f / (1.f + expf(-accp[co]));
-            if (a.sig_p) a.sig_p[o + co * plane] = sp;
-            if (a.mode == 1) {
-                r = a.scale * sp;
+        float r[4], sp[4], sn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (a.mode == 0) {
+                r[q] = a.scale * accp[co][q];
             } else {
-                const float sn = 1.f / (1.f + expf(-accn[co]));
-                if (a.sig_n) a.sig_n[o + co * plane] = sn;
-                // reference order (depth_decoder.py:134-135): 2^(s-1)*sig(+) - 2^(s-1)*sig(-)
-                r = a.scale * sp - a.scale * sn;
+                sp[q] = 1.f / (1.f + expf(-accp[co][q]));
+                if (a.mode == 1) {
+                    r[q] = a.scale * sp[q];
+                } else {
+                    sn[q] = 1.f / (1.f + expf(-accn[co][q]));
+                    // reference order (depth_decoder.py:134-135): 2^(s-1)*sig(+) - 2^(s-1)*sig(-)
+                    r[q] = a.scale * sp[q] - a.scale * sn[q];
+                }
             }
         }
-        a.y[o + co * plane] = r;
+        float* yo = a.y + o + co * plane;
+        if (vec) {
+            *reinterpret_cast<float4*>(yo) = make_float4(r[0], r[1], r[2], r[3]);
+            if (a.mode >= 1 && a.sig_p) *reinterpret_cast<float4*>(a.sig_p + o + co * plane) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            if (a.mode == 2 && a.sig_n) *reinterpret_cast<float4*>(a.sig_n + o + co * plane) = make_float4(sn[0], sn[1], sn[2], sn[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ox + q < a.W) {
+                    yo[q] = r[q];
+                    if (a.mode >= 1 && a.sig_p) a.sig_p[o + co * plane + q] = sp[q];
+                    if (a.mode == 2 && a.sig_n) a.sig_n[o + co * plane + q] = sn[q];
+                }
+        }
     }
 }
 
@@ -141,11 +250,17 @@ extern "C" int wmd_head3x3_fwd(const wmd_head_args* g, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const double pix = (double)g->B * g->H * g->W, sides = g->mode == 2 ? 2.0 : 1.0;
     ProfScope prof("head3x3_kernel", sides * 18.0 * g->C * g->Cout * pix, 4.0 * pix * (sides * g->C + g->Cout), s);
+    // few tiles (coarse pyramid levels): 4 channel groups per tile; otherwise 2
+    const bool wide = (size_t)g->B * tiles_x * tiles_y < 2 * (size_t)kNumCU;
+#define WMD_HEAD_LAUNCH(CO)                                                                                   \
+    if (wide) hipLaunchKernelGGL((head3x3_kernel<CO, 4>), grid, dim3(H_TT * 4), 0, s, *g, tiles_x, tiles_y); \
+    else hipLaunchKernelGGL((head3x3_kernel<CO, 2>), grid, dim3(H_TT * 2), 0, s, *g, tiles_x, tiles_y)
     switch (g->Cout) {
-        case 1: hipLaunchKernelGGL(head3x3_kernel<1>, grid, dim3(256), 0, s, *g, tiles_x, tiles_y); break;
-        case 2: hipLaunchKernelGGL(head3x3_kernel<2>, grid, dim3(256), 0, s, *g, tiles_x, tiles_y); break;
-        case 3: hipLaunchKernelGGL(head3x3_kernel<3>, grid, dim3(256), 0, s, *g, tiles_x, tiles_y); break;
-        default: hipLaunchKernelGGL(head3x3_kernel<4>, grid, dim3(256), 0, s, *g, tiles_x, tiles_y); break;
+        case 1: WMD_HEAD_LAUNCH(1); break;
+        case 2: WMD_HEAD_LAUNCH(2); break;
+        case 3: WMD_HEAD_LAUNCH(3); break;
+        default: WMD_HEAD_LAUNCH(4); break;
     }
+#undef WMD_HEAD_LAUNCH
     return check_launch("head3x3_kernel");
 }

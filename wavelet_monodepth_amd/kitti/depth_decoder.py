@@ -17,6 +17,7 @@ import torch.nn as nn
 from .. import ops
 from ..layers import Conv1x1, Conv3x3, ConvBlock
 from ..wavelets import IDWT
+from ..graphs import GraphCache
 
 
 def _wave_head(num_in, num_mid, num_out):
@@ -55,6 +56,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self.decoder = nn.ModuleList(list(self.convs.values()))
         self.sigmoid = nn.Sigmoid()
         self.tanh = nn.Tanh()
+        self._graph_mode = False
+        self._graphs = GraphCache()
 
     # -- pieces ------------------------------------------------------------------------------
     def _head_mid(self, x, key):
@@ -63,6 +66,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
 
     def get_coefficients(self, input_features, scale=1, return_ll=False):
         """(LL, [LH, HL, HH]) from the features of level `scale` (reference :126-136)."""
+        if not torch.is_grad_enabled():
+            return self._coefficients_stacked(input_features, scale, return_ll)
         yl = None
         if return_ll:
             mid = self._head_mid(input_features, ("waveconv", scale, 0))
@@ -76,7 +81,42 @@ class DepthWaveProgressiveDecoder(nn.Module):
                          scale=2.0 ** (scale - 1))
         return yl, yh.unsqueeze(1)
 
+    def _coefficients_stacked(self, x, scale, return_ll):
+        """Inference path: the 2-3 Conv1x1 of a level run as ONE stacked MFMA GEMM (x is read once) and the 3x3
+        heads read their inputs as channel slices of its output."""
+        order = ([0] if return_ll else []) + [1, -1]
+        heads = [self.convs[("waveconv", scale, j)] for j in order]
+        mid = ops.conv1x1_stacked_nograd(x, [h[0].conv.weight for h in heads], [h[0].conv.bias for h in heads],
+                                         act="leaky", slope=0.1)
+        offs, o = {}, 0
+        for j, h in zip(order, heads):
+            offs[j] = o
+            o += h[0].conv.weight.shape[0]
+        yl = None
+        if return_ll:
+            c3 = heads[0][2].conv
+            yl = ops.head3x3_nograd(mid, c3.weight.shape[1], offs[0], c3.weight, c3.bias, pad="reflect", mode=1,
+                                    scale=2.0 ** scale)
+        cp = self.convs[("waveconv", scale, 1)][2].conv
+        cn = self.convs[("waveconv", scale, -1)][2].conv
+        yh = ops.head3x3_nograd(mid, cp.weight.shape[1], offs[1], cp.weight, cp.bias, offs[-1], cn.weight, cn.bias,
+                                pad="reflect", mode=2, scale=2.0 ** (scale - 1))
+        return yl, yh.unsqueeze(1)
+
     def forward(self, input_features):
+        if self._graph_mode and not torch.is_grad_enabled():
+            self.outputs = self._graphs.run(self._forward_impl, input_features, self.parameters())
+            return self.outputs
+        return self._forward_impl(input_features)
+
+    def enable_graph(self, on=True):
+        """Inference only: capture the whole forward (≈45 kernel launches) into one hipGraph per input
+        signature and replay it.  Outputs then live in static buffers that the next call overwrites."""
+        self._graph_mode = bool(on)
+        self._graphs.clear()
+        return self
+
+    def _forward_impl(self, input_features):
         self.outputs = {}
         x = input_features[-1]
         yl = None

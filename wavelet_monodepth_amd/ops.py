@@ -14,7 +14,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, tuner
 from ._lib import ACT, PAD, check, current_stream, ptr
 
 
@@ -62,14 +62,33 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1):
     y = torch.empty((B, cout, H, W), device=x1.device, dtype=torch.float32)
     a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad], act=ACT[act],
                       slope=float(slope), x1=ptr(x1), x2=ptr(x2), wp=ptr(wp), bias=ptr(bias), y=ptr(y),
-                      workspace=None, workspace_floats=0)
-    ws_n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
-    ws = None
-    if ws_n:
-        ws = torch.empty(ws_n, device=x1.device, dtype=torch.float32)
-        a.workspace = ptr(ws)
-        a.workspace_floats = ws_n
-    check(l.wmd_conv_fwd(C.byref(a), current_stream()), "wmd_conv_fwd")
+                      workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0)
+    stream = current_stream()
+    keep = []
+
+    def launch(cfg, ks):
+        a.tune_cfg, a.tune_ksplit = cfg, ks
+        a.workspace, a.workspace_floats = None, 0
+        n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
+        if n:
+            ws = torch.empty(n, device=x1.device, dtype=torch.float32)
+            keep.append(ws)
+            a.workspace, a.workspace_floats = ptr(ws), n
+        elif ks > 1:
+            return -3
+        return l.wmd_conv_fwd(C.byref(a), stream)
+
+    choice = (0, 0)
+    if tuner.enabled:
+        key = "conv|%d|%d|%d|%d|%d|%d|%d|%d" % (B, H, W, C1, up1, C2, cout, ksize)  # str: JSON-cacheable
+        choice = tuner.lookup(key)
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                choice = (0, 0)  # cannot time inside a capture: the library's cost model decides
+            else:
+                choice = tuner.tune(key, 9 if ksize == 3 else 1, launch)
+                keep.clear()
+    check(launch(*choice), "wmd_conv_fwd")
     return y
 
 
@@ -221,6 +240,49 @@ def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, ne
 def head3x3(xp, weight_p, bias_p, xn=None, weight_n=None, bias_n=None, pad="reflect", mode=0, scale=1.0):
     _require_gpu(xp, weight_p, bias_p, xn, weight_n, bias_n)
     return _HeadFn.apply(xp, weight_p, bias_p, xn, weight_n, bias_n, pad, mode, scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# inference-only fast paths (no autograd): stacked 1x1 heads + head3x3 on channel slices
+# ---------------------------------------------------------------------------------------------
+
+def conv1x1_stacked_nograd(x, weights, biases, act="leaky", slope=0.1):
+    """Several 1x1 convolutions of the SAME input as one launch: their packed weight images are simply
+    concatenated along the out-channel-tile axis (every Cout is a multiple of 16), so x is read once.
+    Returns [B, sum(Cout_k), H, W]."""
+    l = _lib.lib()
+    x = _c(x)
+    cin = x.shape[1]
+    couts = [w.shape[0] for w in weights]
+    if any(c % 16 for c in couts[:-1]):
+        raise _lib.WmdError("stacked heads need out-channel counts that are multiples of 16")
+    sizes = [l.wmd_conv_packed_weight_floats(c, cin, 1) for c in couts]
+    wp = torch.empty(sum(sizes), device=x.device, dtype=torch.float32)
+    s = current_stream()
+    off = 0
+    for w, n, c in zip(weights, sizes, couts):
+        check(l.wmd_conv_pack_weights(ptr(_c(w.detach())), wp.data_ptr() + 4 * off, c, cin, 1, s), "wmd_conv_pack_weights")
+        off += n
+    bias = torch.cat([b.detach() for b in biases])
+    return _conv_fwd_raw(x, None, wp, bias, sum(couts), 1, "zero", act, slope, 1)
+
+
+def head3x3_nograd(x_full, cin, off_p, weight_p, bias_p, off_n=None, weight_n=None, bias_n=None, pad="reflect", mode=0,
+                   scale=1.0):
+    """head3x3 reading its cin-channel input(s) as channel slices [off, off+cin) of one [B,Ctot,H,W] tensor."""
+    l = _lib.lib()
+    B, Ctot, H, W = x_full.shape
+    cout = weight_p.shape[0]
+    y = torch.empty((B, cout, H, W), device=x_full.device, dtype=torch.float32)
+    plane = H * W
+    base = x_full.data_ptr()
+    a = _lib.HeadArgs(B=B, H=H, W=W, C=cin, Cout=cout, pad_mode=PAD[pad], mode=mode, scale=float(scale),
+                      xp=base + 4 * off_p * plane, wgt_p=ptr(_c(weight_p.detach())), bias_p=ptr(bias_p),
+                      xn=None if off_n is None else base + 4 * off_n * plane,
+                      wgt_n=None if weight_n is None else ptr(_c(weight_n.detach())), bias_n=ptr(bias_n),
+                      y=ptr(y), sig_p=None, sig_n=None, xp_bstride=Ctot * plane, xn_bstride=Ctot * plane)
+    check(l.wmd_head3x3_fwd(C.byref(a), current_stream()), "wmd_head3x3_fwd")
+    return y
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,88 @@
+"""Per-shape autotuning of the MFMA convolution (tile configuration x split-K), MIOpen-"find" style.
+
+The C library is stateless: it exposes its configuration table (wmd_conv_num_configs/_config_name) and
+lets the caller force a choice through wmd_conv_args.tune_cfg / tune_ksplit.  This module times the
+candidates once per problem signature on the live GPU and remembers the winner for the process
+(optionally across processes: WMD_TUNE_CACHE=/path/to/file.json).  WMD_AUTOTUNE=0 falls back to the
+library's built-in cost model.
+"""
+import json
+import os
+
+import torch
+
+enabled = os.environ.get("WMD_AUTOTUNE", "1") != "0"
+_cache = {}
+_cache_file = os.environ.get("WMD_TUNE_CACHE")
+_loaded = False
+KSPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
+
+
+def _load():
+    global _loaded
+    if _loaded:
+        return
+    _loaded = True
+    if _cache_file and os.path.exists(_cache_file):
+        with open(_cache_file) as f:
+            for k, v in json.load(f).items():
+                _cache[k] = tuple(v)
+
+
+def _save():
+    if _cache_file:
+        with open(_cache_file, "w") as f:
+            json.dump({k: list(v) for k, v in _cache.items()}, f, indent=0)
+
+
+def config_names():
+    from . import _lib
+    l = _lib.lib()
+    return [l.wmd_conv_config_name(i).decode() for i in range(l.wmd_conv_num_configs())]
+
+
+def lookup(key):
+    _load()
+    return _cache.get(key)
+
+
+def _time(launch, cfg, ks, reps, e0, e1):
+    t = float("inf")
+    for _ in range(reps):
+        e0.record()
+        launch(cfg, ks)
+        e1.record()
+        e1.synchronize()
+        t = min(t, e0.elapsed_time(e1))
+    return t
+
+
+def tune(key, taps, launch):
+    """launch(cfg1, ks) -> status int (0 ok). Returns (cfg1, ks) with the smallest GPU time:
+    a coarse sweep (min of 2 runs each) followed by a 6-run play-off between the five best."""
+    names = config_names()
+    cands = [i + 1 for i, n in enumerate(names) if n.endswith(",%d>" % taps)]
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    results = []
+    best_t = float("inf")
+    for cfg in cands:
+        for ks in KSPLITS:
+            if launch(cfg, ks) != 0:      # invalid combination for this shape (planner refuses)
+                continue
+            t = _time(launch, cfg, ks, 2, e0, e1)
+            results.append((t, cfg, ks))
+            best_t = min(best_t, t)
+            if ks == 1 and t > 4.0 * best_t:
+                break  # hopeless tile shape for this problem: do not sweep its splits
+    if not results:
+        _cache[key] = (0, 0)
+        return (0, 0)
+    results.sort()
+    final = sorted((_time(launch, cfg, ks, 6, e0, e1), cfg, ks) for _, cfg, ks in results[:5])
+    t, cfg, ks = final[0]
+    _cache[key] = (cfg, ks)
+    _save()
+    if os.environ.get("WMD_TUNE_VERBOSE"):
+        print("[wmd tuner] %s -> %s ksplit %d (%.1f us)" % (key, names[cfg - 1], ks, t * 1e3))
+    return (cfg, ks)
