@@ -1,0 +1,442 @@
+// Backward of the fused decoder convolution (autograd of ConvBlock/Conv3x3/Conv1x1 + upsample + cat + pad;
+// the reference gets it implicitly from torch.autograd, KITTI/trainer.py:211, NYUv2/train.py:327).
+//
+//   forward:  z = W * P(x1, x2),   P = pad o concat o nearest-upsample   (a linear gather)
+//   dgrad:    dP = W^T (*) dz on the padded (H+2)x(W+2) domain  -> conv_fwd_kernel fed with dz, the
+//             transposed+flipped weight image and shift1 = 1;   dx = P^T dP  -> conv_dgrad_fold_kernel
+//             (reflect/replicate border accumulation, channel split, 2x2 sum for the upsampled source)
+//   wgrad:    dW[co,ci,t] = sum_{b,y,x} dz[b,co,y,x] * P[b,ci,y+ky,x+kx]  -> conv_wgrad_kernel: an MFMA GEMM
+//             with M = co, N = (ci,tap), K = pixels; every block owns a (co-tile, ci-tile) pair and a slice
+//             of the pixel tiles, accumulates in registers and writes ONE partial; a second kernel sums the
+//             partials (deterministic two-stage reduction, no atomics).
+//   dbias:    per-channel sum of dz (conv_bias_grad_kernel).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "wmd_internal.h"
+
+namespace wmd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stream);
+
+// ------------------------------------------------------------------------------------------------
+// dgrad stage 2: adjoint of pad + concat + upsample
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fold_rows(int y, int n, int pad_mode, int halo, int (&rows)[3]) {
+    // padded-domain indices (0 .. n+1) whose forward source is logical index y
+    int cnt = 0;
+    rows[cnt++] = y + halo;
+    if (!halo) return cnt;
+    if (pad_mode == WMD_PAD_REFLECT) {
+        if (y == 1) rows[cnt++] = 0;
+        if (y == n - 2) rows[cnt++] = n + 1;
+    } else if (pad_mode == WMD_PAD_REPLICATE) {
+        if (y == 0) rows[cnt++] = 0;
+        if (y == n - 1) rows[cnt++] = n + 1;
+    }
+    return cnt;
+}
+
+__global__ void conv_dgrad_fold_kernel(const float* __restrict__ g, float* __restrict__ dx1, float* __restrict__ dx2,
+                                       int B, int C1, int C2, int H, int W, int up1, int pad_mode, int halo) {
+    const int Hp = H + 2 * halo, Wp = W + 2 * halo;
+    const int H1 = H / up1, W1 = W / up1;
+    const size_t n1 = dx1 ? (size_t)B * C1 * H1 * W1 : 0;
+    const size_t n2 = dx2 ? (size_t)B * C2 * H * W : 0;
+    const int Cin = C1 + C2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
+        const bool first = i < n1;
+        size_t r = first ? i : i - n1;
+        const int w_ = first ? W1 : W, h_ = first ? H1 : H, c_ = first ? C1 : C2;
+        const int x = r % w_;
+        r /= w_;
+        const int y = r % h_;
+        r /= h_;
+        const int c = r % c_;
+        const int b = r / c_;
+        const int ch = first ? c : C1 + c;
+        const int u = first ? up1 : 1;
+        const float* gp = g + ((size_t)b * Cin + ch) * Hp * Wp;
+        float acc = 0.f;
+        for (int dy = 0; dy < u; ++dy) {
+            int rows[3];
+            const int nr = fold_rows(y * u + dy, H, pad_mode, halo, rows);
+            for (int dx = 0; dx < u; ++dx) {
+                int cols[3];
+                const int nc = fold_rows(x * u + dx, W, pad_mode, halo, cols);
+                for (int a = 0; a < nr; ++a)
+                    for (int q = 0; q < nc; ++q) acc += gp[(size_t)rows[a] * Wp + cols[q]];
+            }
+        }
+        (first ? dx1 : dx2)[first ? i : i - n1] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad
+// ------------------------------------------------------------------------------------------------
+struct WgradKArgs {
+    const float* x1;
+    const float* x2;
+    const float* dz;
+    float* partial;  // [nsplit][Cout][Cin][taps]
+    int B, H, W, H1, W1, C1, C2, Cin, Cout, up1, pad_mode;
+    int tiles_x, tiles_y, ntiles;  // pixel tiles per image / total (B * tiles_x * tiles_y)
+    int nsplit;
+};
+
+// Block = WM x WN waves. Wave (wm, wn) owns MR out-channel tiles (16 each) x one 16-input-channel group x TAPS.
+// Pixel tile = TH x TW (TW % 4 == 0): the MFMA K index walks 4 consecutive pixels of a row.
+template <int TH, int TW, int MR, int WM, int WN, int TAPS>
+struct WgradTile {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    static constexpr int NPIX = TH * TW;
+    static constexpr int COT = WM * MR * 16;   // out channels per block
+    static constexpr int CIT = WN * 16;        // in channels per block
+    // strides == 2 (mod 32): lanes (i = l&15, k = l>>4) of a 32-lane group hit banks 2i + k, all distinct
+    static constexpr int SA = ((NPIX - 2 + 31) / 32) * 32 + 2;
+    static constexpr int SB = ((PH * PW - 2 + 31) / 32) * 32 + 2;
+    static constexpr int LDS_FLOATS = COT * SA + CIT * SB;
+    static_assert(TW % 4 == 0, "pixel quads must not straddle rows");
+};
+
+template <int TH, int TW, int MR, int WM, int WN, int TAPS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const WgradKArgs a) {
+    using T = WgradTile<TH, TW, MR, WM, WN, TAPS>;
+    constexpr int NT = T::NT, HALO = T::HALO, PW = T::PW, SA = T::SA, SB = T::SB, NPIX = T::NPIX;
+    __shared__ float lds[T::LDS_FLOATS];
+    float* ldsA = lds;                 // dz tile   [COT][SA]
+    float* ldsB = lds + T::COT * SA;   // x patch   [CIT][SB]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int co0 = blockIdx.y * T::COT, ci0 = blockIdx.x * T::CIT;
+    const int split = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const size_t plane = (size_t)H * W, plane1 = (size_t)a.H1 * a.W1;
+
+    f32x4 acc[MR][TAPS];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this split's share of the pixel tiles
+    const int per = (a.ntiles + a.nsplit - 1) / a.nsplit;
+    const int t_begin = split * per, t_end = min(t_begin + per, a.ntiles);
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int b = t / a.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage dz tile: rows = out channels, NPIX pixels (zero outside the image / channel range)
+        for (int e = tid; e < T::COT * NPIX; e += NT) {
+            const int c = e / NPIX, p = e % NPIX;
+            const int oy = y0 + p / TW, ox = x0 + p % TW;
+            const int co = co0 + c;
+            float v = 0.f;
+            if (co < a.Cout && oy < H && ox < W) v = a.dz[((size_t)b * a.Cout + co) * plane + (size_t)oy * W + ox];
+            ldsA[c * SA + p] = v;
+        }
+        // ---- stage the input patch of CIT channels through the pad/upsample/concat gather
+        for (int e = tid; e < T::CIT * T::PH * PW; e += NT) {
+            const int c = e / (T::PH * PW), p = e % (T::PH * PW);
+            int gy = y0 + p / PW - HALO, gx = x0 + p % PW - HALO;
+            const int ci = ci0 + c;
+            bool ok = ci < a.Cin;
+            if (HALO) {
+                ok = pad_coord(gy, H, a.pad_mode) && ok;
+                ok = pad_coord(gx, W, a.pad_mode) && ok;
+            }
+            ok = ok && gy >= 0 && gx >= 0 && gy < H && gx < W;
+            float v = 0.f;
+            if (ok) {
+                if (ci < a.C1)
+                    v = a.x1[((size_t)b * a.C1 + ci) * plane1 + (size_t)(gy / a.up1) * a.W1 + gx / a.up1];
+                else
+                    v = a.x2[((size_t)b * a.C2 + (ci - a.C1)) * plane + (size_t)gy * W + gx];
+            }
+            ldsB[c * SB + p] = v;
+        }
+        __syncthreads();
+
+        // ---- MFMA over the tile's pixels: K-step = 4 consecutive pixels of one row
+        const float* pa = ldsA + (wm * MR * 16 + (lane & 15)) * SA + (lane >> 4);
+        const float* pb = ldsB + (wn * 16 + (lane & 15)) * SB + (lane >> 4);
+#pragma unroll 2
+        for (int q = 0; q < NPIX; q += 4) {
+            const int py = q / TW, px = q % TW;
+            float af[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) af[m] = pa[m * 16 * SA + q];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                const float bf = pb[(py + ky) * PW + px + kx];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf, acc[m][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- write this block's partial: D row = out channel (lane>>4)*4+r, D col = input channel lane&15
+    float* out = a.partial + (size_t)split * a.Cout * a.Cin * TAPS;
+    const int ci = ci0 + wn * 16 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + (wm * MR + m) * 16 + (lane >> 4) * 4 + r;
+            if (co < a.Cout && ci < a.Cin) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) out[((size_t)co * a.Cin + ci) * TAPS + t] = acc[m][t][r];
+            }
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t n, int nsplit) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += partial[(size_t)s * n + i];
+        dw[i] = v;
+    }
+}
+
+// one block per output channel: db[co] = sum_{b,y,x} dz[b,co,y,x]
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ db,
+                                                              int B, int Cout, size_t plane) {
+    const int co = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = dz + ((size_t)b * Cout + co) * plane;
+        for (size_t i = threadIdx.x; i < plane; i += 256) s += p[i];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[co] = red[0];
+}
+
+struct WgradCfg {
+    int TH, TW, MR, WM, WN, TAPS;
+    void (*launch)(const WgradKArgs&, dim3, hipStream_t);
+    const char* name;
+};
+
+template <int TH, int TW, int MR, int WM, int WN, int TAPS>
+static void launch_wgrad(const WgradKArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<TH, TW, MR, WM, WN, TAPS>), grid, dim3(WM * WN * 64), 0, s, a);
+}
+#define WMD_WCFG(TH, TW, MR, WM, WN, TAPS) \
+    WgradCfg { TH, TW, MR, WM, WN, TAPS, &launch_wgrad<TH, TW, MR, WM, WN, TAPS>, "conv_wgrad_kernel<" #TH "," #TW "," #MR "," #WM "," #WN "," #TAPS ">" }
+
+static const WgradCfg kWCfgs[] = {
+    WMD_WCFG(4, 32, 1, 4, 1, 9),  // co64 x ci16
+    WMD_WCFG(4, 32, 1, 2, 2, 9),  // co32 x ci32
+    WMD_WCFG(4, 20, 1, 4, 1, 9),  // 20-wide rows (coarsest 640-wide level, NYUv2 15x20)
+    WMD_WCFG(4, 20, 1, 2, 2, 9),
+    WMD_WCFG(1, 256, 1, 4, 1, 1),  // 1x1: co64 x ci16 over 256 flattened pixels
+    WMD_WCFG(1, 256, 1, 2, 2, 1),  // 1x1: co32 x ci32
+};
+constexpr int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
+
+struct WgradPlan {
+    const WgradCfg* cfg;
+    int H, W, tiles_x, tiles_y, ntiles, nsplit;
+    dim3 grid;
+};
+
+static bool plan_wgrad(const wmd_conv_wgrad_args* g, WgradPlan* p) {
+    const int taps = g->ksize == 3 ? 9 : 1;
+    const int Cin = g->C1 + g->C2;
+    const int H = taps == 9 ? g->H : 1, W = taps == 9 ? g->W : g->H * g->W;
+    double best = 1e300;
+    bool found = false;
+    for (int i = 0; i < kNumWCfgs; ++i) {
+        const WgradCfg& c = kWCfgs[i];
+        if (c.TAPS != taps) continue;
+        const int TH = c.TH, TW = c.TW;
+        const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+        const int cot = c.WM * c.MR * 16, cit = c.WN * 16;
+        const int gx = (Cin + cit - 1) / cit, gy = (g->Cout + cot - 1) / cot;
+        const long ntiles = (long)g->B * tx * ty;
+        // padded MACs: every block sweeps all pixel tiles of its split
+        const double waste = ((double)gx * cit / Cin) * ((double)gy * cot / g->Cout) * ((double)tx * TW * ty * TH / ((double)H * W));
+        int nsplit = (int)std::min<long>(ntiles, std::max<long>(1, (3L * kNumCU + (long)gx * gy - 1) / ((long)gx * gy)));
+        const double rounds = std::ceil((double)gx * gy * nsplit / (2.0 * kNumCU));
+        const double cost = waste * rounds * 2.0 * kNumCU / ((double)gx * gy * nsplit);
+        if (cost < best) {
+            best = cost;
+            found = true;
+            p->cfg = &c;
+            p->H = H;
+            p->W = W;
+            p->tiles_x = tx;
+            p->tiles_y = ty;
+            p->ntiles = (int)ntiles;
+            p->nsplit = nsplit;
+            p->grid = dim3((unsigned)gx, (unsigned)gy, (unsigned)nsplit);
+        }
+    }
+    return found;
+}
+
+}  // namespace wmd
+
+using namespace wmd;
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static int validate_bwd(int B, int H, int W, int C1, int up1, int C2, int Cout, int ksize, int pad_mode, const char* who) {
+    if (B <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0)
+        return fail(WMD_ERR_BAD_SHAPE, "%s: B=%d H=%d W=%d C1=%d C2=%d Cout=%d", who, B, H, W, C1, C2, Cout);
+    if (ksize != 1 && ksize != 3) return fail(WMD_ERR_UNSUPPORTED, "%s: ksize=%d", who, ksize);
+    if (up1 != 1 && up1 != 2) return fail(WMD_ERR_BAD_ARG, "%s: up1=%d", who, up1);
+    if (up1 == 2 && ((H | W) & 1)) return fail(WMD_ERR_BAD_SHAPE, "%s: up1=2 needs even H,W", who);
+    if (pad_mode < 0 || pad_mode > 2) return fail(WMD_ERR_BAD_ARG, "%s: pad_mode=%d", who, pad_mode);
+    if (ksize == 3 && pad_mode == WMD_PAD_REFLECT && (H < 2 || W < 2))
+        return fail(WMD_ERR_BAD_SHAPE, "%s: reflect padding needs H,W >= 2", who);
+    return WMD_OK;
+}
+
+static void dgrad_conv_args(const wmd_conv_dgrad_args* g, wmd_conv_args* c, float* gbuf, float* ws, size_t ws_floats) {
+    const int halo = g->ksize == 3 ? 1 : 0;
+    memset(c, 0, sizeof(*c));
+    c->B = g->B;
+    c->H = g->H + 2 * halo;
+    c->W = g->W + 2 * halo;
+    c->C1 = g->Cout;  // the reduction runs over the forward's output channels
+    c->up1 = 1;
+    c->C2 = 0;
+    c->Cout = g->C1 + g->C2;  // rows = forward input channels
+    c->ksize = g->ksize;
+    c->pad_mode = WMD_PAD_ZERO;
+    c->act = WMD_ACT_NONE;
+    c->x1 = g->dz;
+    c->wp = g->wp_dgrad;
+    c->y = gbuf;
+    c->workspace = ws;
+    c->workspace_floats = ws_floats;
+}
+
+static bool dgrad_direct(const wmd_conv_dgrad_args* g) {
+    // 1x1 without upsample/concat: the GEMM output IS dx1
+    return g->ksize == 1 && g->up1 == 1 && g->C2 == 0 && g->dx1;
+}
+
+extern "C" size_t wmd_conv_dgrad_workspace_floats(const wmd_conv_dgrad_args* g) {
+    if (!g || g->B <= 0) return 0;
+    const int halo = g->ksize == 3 ? 1 : 0;
+    const size_t gsz = dgrad_direct(g) ? 0 : (size_t)g->B * (g->C1 + g->C2) * (g->H + 2 * halo) * (g->W + 2 * halo);
+    wmd_conv_args c;
+    dgrad_conv_args(g, &c, nullptr, nullptr, 0);
+    return gsz + wmd_conv_fwd_workspace_floats(&c);
+}
+
+extern "C" int wmd_conv_dgrad(const wmd_conv_dgrad_args* g, void* stream) {
+    if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_conv_dgrad: null args");
+    if (!g->dz || !g->wp_dgrad) return fail(WMD_ERR_BAD_ARG, "wmd_conv_dgrad: null tensor pointer");
+    if (!g->dx1 && !g->dx2) return WMD_OK;
+    if (g->dx2 && g->C2 <= 0) return fail(WMD_ERR_BAD_ARG, "wmd_conv_dgrad: dx2 given but C2=%d", g->C2);
+    int st = validate_bwd(g->B, g->H, g->W, g->C1, g->up1, g->C2, g->Cout, g->ksize, g->pad_mode, "wmd_conv_dgrad");
+    if (st) return st;
+    if (g->ksize == 1 && g->up1 == 2) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_dgrad: 1x1 with upsampled input");
+    const int halo = g->ksize == 3 ? 1 : 0;
+    const size_t gsz = dgrad_direct(g) ? 0 : (size_t)g->B * (g->C1 + g->C2) * (g->H + 2 * halo) * (g->W + 2 * halo);
+    if (g->workspace_floats < gsz || (gsz && !g->workspace))
+        return fail(WMD_ERR_WORKSPACE, "wmd_conv_dgrad: workspace %zu < %zu floats", g->workspace_floats, gsz);
+    float* gbuf = dgrad_direct(g) ? g->dx1 : g->workspace;
+    wmd_conv_args c;
+    dgrad_conv_args(g, &c, gbuf, g->workspace ? g->workspace + gsz : nullptr, g->workspace_floats - gsz);
+    if (c.workspace_floats == 0) c.workspace = nullptr;
+    st = run_conv(&c, halo, g->H, g->W, stream);
+    if (st || dgrad_direct(g)) return st;
+    const size_t n = (g->dx1 ? (size_t)g->B * g->C1 * (g->H / g->up1) * (g->W / g->up1) : 0) +
+                     (g->dx2 ? (size_t)g->B * g->C2 * g->H * g->W : 0);
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 16);
+    ProfScope prof("conv_dgrad_fold_kernel", (double)n, 4.0 * (gsz + n), (hipStream_t)stream);
+    hipLaunchKernelGGL(conv_dgrad_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gbuf, g->dx1, g->dx2, g->B,
+                       g->C1, g->C2, g->H, g->W, g->up1, g->pad_mode, halo);
+    return check_launch("conv_dgrad_fold_kernel");
+}
+
+extern "C" size_t wmd_conv_wgrad_workspace_floats(const wmd_conv_wgrad_args* g) {
+    if (!g || g->B <= 0 || g->Cout <= 0) return 0;
+    WgradPlan p;
+    if (!plan_wgrad(g, &p)) return 0;
+    const int taps = g->ksize == 3 ? 9 : 1;
+    return (size_t)p.nsplit * g->Cout * (g->C1 + g->C2) * taps;
+}
+
+extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
+    if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_conv_wgrad: null args");
+    if (!g->x1 || !g->dz || !g->dw) return fail(WMD_ERR_BAD_ARG, "wmd_conv_wgrad: null tensor pointer");
+    if (g->C2 > 0 && !g->x2) return fail(WMD_ERR_BAD_ARG, "wmd_conv_wgrad: C2=%d but x2 is null", g->C2);
+    int st = validate_bwd(g->B, g->H, g->W, g->C1, g->up1, g->C2, g->Cout, g->ksize, g->pad_mode, "wmd_conv_wgrad");
+    if (st) return st;
+    if (g->ksize == 1 && g->up1 == 2) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: 1x1 with upsampled input");
+    WgradPlan p;
+    if (!plan_wgrad(g, &p)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: no kernel configuration");
+    const int taps = g->ksize == 3 ? 9 : 1;
+    const int Cin = g->C1 + g->C2;
+    const size_t nw = (size_t)g->Cout * Cin * taps;
+    if (!g->workspace || g->workspace_floats < nw * p.nsplit)
+        return fail(WMD_ERR_WORKSPACE, "wmd_conv_wgrad: workspace %zu < %zu floats", g->workspace_floats, nw * p.nsplit);
+    WgradKArgs a;
+    a.x1 = g->x1;
+    a.x2 = g->x2;
+    a.dz = g->dz;
+    a.partial = g->workspace;
+    a.B = g->B;
+    a.H = p.H;
+    a.W = p.W;
+    a.up1 = taps == 9 ? g->up1 : 1;
+    a.H1 = p.H / a.up1;
+    a.W1 = p.W / a.up1;
+    a.C1 = g->C1;
+    a.C2 = g->C2;
+    a.Cin = Cin;
+    a.Cout = g->Cout;
+    a.pad_mode = g->pad_mode;
+    a.tiles_x = p.tiles_x;
+    a.tiles_y = p.tiles_y;
+    a.ntiles = p.ntiles;
+    a.nsplit = p.nsplit;
+    hipStream_t s = (hipStream_t)stream;
+    const double pix = (double)g->B * g->H * g->W;
+    {
+        ProfScope prof(p.cfg->name, 2.0 * Cin * taps * g->Cout * pix, 4.0 * (pix * (Cin + g->Cout) + (double)nw), s);
+        p.cfg->launch(a, p.grid, s);
+    }
+    st = check_launch("conv_wgrad_kernel");
+    if (st) return st;
+    {
+        ProfScope prof("wgrad_reduce_kernel", (double)nw * p.nsplit, 4.0 * nw * (p.nsplit + 1), s);
+        const int blocks = (int)std::min<size_t>((nw + 255) / 256, (size_t)kNumCU * 8);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, g->workspace, g->dw, nw, p.nsplit);
+    }
+    st = check_launch("wgrad_reduce_kernel");
+    if (st) return st;
+    if (g->dbias) {
+        ProfScope prof("conv_bias_grad_kernel", pix * g->Cout, 4.0 * pix * g->Cout, s);
+        hipLaunchKernelGGL(conv_bias_grad_kernel, dim3(g->Cout), dim3(256), 0, s, g->dz, g->dbias, g->B, g->Cout,
+                           (size_t)g->H * g->W);
+        st = check_launch("conv_bias_grad_kernel");
+    }
+    return st;
+}

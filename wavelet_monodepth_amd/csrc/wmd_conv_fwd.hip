@@ -35,6 +35,8 @@ struct ConvKArgs {
     float* y;        // final output (ksplit == 1) or split-K partials [ksplit][B,Cout,H,W]
     int B, H, W, H1, W1;
     int C1, C2, Cin, Cout, up1;
+    int shift1;      // x1 is read at (y - shift1, x - shift1), zero outside its H1 x W1 extent (dgrad: the
+                     // "full" correlation is a zero-padded one over a 1-pixel-extended gradient image)
     int pad_mode, act;
     float slope;
     int tiles_x, tiles_y;
@@ -103,9 +105,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
-        live[i] = ok;
         ob2[i] = (unsigned)(gy * W + gx) * 4u;
-        ob1[i] = (unsigned)((a.up1 == 2) ? (gy >> 1) * a.W1 + (gx >> 1) : gy * W + gx) * 4u;
+        int sy = gy - a.shift1, sx = gx - a.shift1;
+        if (a.up1 == 2) {
+            sy = gy >> 1;
+            sx = gx >> 1;
+        }
+        ok = ok && sy >= 0 && sx >= 0 && sy < a.H1 && sx < a.W1;
+        sy = min(max(sy, 0), a.H1 - 1);
+        sx = min(max(sx, 0), a.W1 - 1);
+        live[i] = ok;
+        ob1[i] = (unsigned)(sy * a.W1 + sx) * 4u;
     }
 
     const size_t plane1 = (size_t)a.H1 * a.W1, plane2 = (size_t)H * W;
@@ -482,9 +492,20 @@ extern "C" size_t wmd_conv_fwd_workspace_floats(const wmd_conv_args* g) {
     return plan.workspace_floats;
 }
 
+namespace wmd {
+int run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stream);
+}
+
 extern "C" int wmd_conv_fwd(const wmd_conv_args* g, void* stream) {
     int st = validate_conv(g, "wmd_conv_fwd");
     if (st) return st;
+    return run_conv(g, 0, g->H / g->up1, g->W / g->up1, stream);
+}
+
+// Shared by the forward pass and by the data-gradient pass (which feeds dz through the same kernel with
+// transposed/flipped weights, shift1 = 1 and an (H+2) x (W+2) logical extent).
+int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stream) {
+    int st = WMD_OK;
     ConvPlan plan;
     if (!plan_conv(g, &plan, g->workspace != nullptr, g->workspace_floats)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_fwd: no kernel configuration");
     const ConvCfg& c = *plan.cfg;
@@ -503,8 +524,9 @@ extern "C" int wmd_conv_fwd(const wmd_conv_args* g, void* stream) {
     a.Cout = g->Cout;
     a.up1 = taps == 9 ? g->up1 : 1;
     if (taps == 1 && g->up1 == 2) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_fwd: 1x1 with upsampled input");
-    a.H1 = a.H / a.up1;
-    a.W1 = a.W / a.up1;
+    a.shift1 = shift1;
+    a.H1 = taps == 9 ? H1 : 1;
+    a.W1 = taps == 9 ? W1 : H1 * W1;
     a.pad_mode = g->pad_mode;
     a.act = g->act;
     a.slope = g->slope;

@@ -5,10 +5,6 @@ using namespace wmd;
 
 #define WMD_TODO(name) return fail(WMD_ERR_UNSUPPORTED, #name ": not implemented yet")
 
-extern "C" size_t wmd_conv_dgrad_workspace_floats(const wmd_conv_dgrad_args*) { return 0; }
-extern "C" int wmd_conv_dgrad(const wmd_conv_dgrad_args*, void*) { WMD_TODO(wmd_conv_dgrad); }
-extern "C" size_t wmd_conv_wgrad_workspace_floats(const wmd_conv_wgrad_args*) { return 0; }
-extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args*, void*) { WMD_TODO(wmd_conv_wgrad); }
 extern "C" int wmd_minmax(const float*, size_t, float*, void*, size_t, void*) { WMD_TODO(wmd_minmax); }
 extern "C" int wmd_mask_threshold(const float*, const float*, float, int, uint8_t*, int, int, void*) { WMD_TODO(wmd_mask_threshold); }
 extern "C" int wmd_mask_dilate(const uint8_t*, uint8_t*, int, int, int, int, void*) { WMD_TODO(wmd_mask_dilate); }

@@ -11,6 +11,7 @@ Each function mirrors one reference operator group (file:line under /root/refere
 All of them are differentiable (torch.autograd.Function with hand-written HIP backward kernels).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -37,14 +38,32 @@ def _c(t):
 # weight packing
 # ---------------------------------------------------------------------------------------------
 
+_PACK_CACHE = os.environ.get("WMD_PACK_CACHE", "1") != "0"
+
+
 def pack_weights(weight, dgrad=False):
-    """[Cout,Cin,k,k] -> MFMA fragment image (wmd_conv_pack_weights[_dgrad])."""
+    """[Cout,Cin,k,k] -> MFMA fragment image (wmd_conv_pack_weights[_dgrad]).
+
+    The image is memoised ON the weight tensor object, keyed by its autograd version counter and storage
+    pointer, so it is rebuilt whenever the weight is updated in place (optimizer step, load_state_dict) and
+    reused while it is constant (inference).  WMD_PACK_CACHE=0 disables the memo."""
     l = _lib.lib()
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    slot = "_wmd_pack_d" if dgrad else "_wmd_pack_f"
+    if _PACK_CACHE:
+        hit = getattr(weight, slot, None)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
     cout, cin, k, _ = weight.shape
     n = l.wmd_conv_packed_weight_floats(cout, cin, k)
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
     fn = l.wmd_conv_pack_weights_dgrad if dgrad else l.wmd_conv_pack_weights
     check(fn(ptr(_c(weight.detach())), ptr(wp), cout, cin, k, current_stream()), "wmd_conv_pack_weights")
+    if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
+        try:
+            setattr(weight, slot, (tag, wp))
+        except AttributeError:
+            pass
     return wp
 
 
@@ -256,14 +275,24 @@ def conv1x1_stacked_nograd(x, weights, biases, act="leaky", slope=0.1):
     couts = [w.shape[0] for w in weights]
     if any(c % 16 for c in couts[:-1]):
         raise _lib.WmdError("stacked heads need out-channel counts that are multiples of 16")
-    sizes = [l.wmd_conv_packed_weight_floats(c, cin, 1) for c in couts]
-    wp = torch.empty(sum(sizes), device=x.device, dtype=torch.float32)
-    s = current_stream()
-    off = 0
-    for w, n, c in zip(weights, sizes, couts):
-        check(l.wmd_conv_pack_weights(ptr(_c(w.detach())), wp.data_ptr() + 4 * off, c, cin, 1, s), "wmd_conv_pack_weights")
-        off += n
-    bias = torch.cat([b.detach() for b in biases])
+    tag = tuple((w._version, w.data_ptr(), b._version, b.data_ptr()) for w, b in zip(weights, biases))
+    hit = getattr(weights[0], "_wmd_pack_stack", None) if _PACK_CACHE else None
+    if hit is not None and hit[0] == tag:
+        wp, bias = hit[1], hit[2]
+    else:
+        sizes = [l.wmd_conv_packed_weight_floats(c, cin, 1) for c in couts]
+        wp = torch.empty(sum(sizes), device=x.device, dtype=torch.float32)
+        s = current_stream()
+        off = 0
+        for w, n, c in zip(weights, sizes, couts):
+            check(l.wmd_conv_pack_weights(ptr(_c(w.detach())), wp.data_ptr() + 4 * off, c, cin, 1, s), "wmd_conv_pack_weights")
+            off += n
+        bias = torch.cat([b.detach() for b in biases])
+        if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
+            try:
+                weights[0]._wmd_pack_stack = (tag, wp, bias)
+            except AttributeError:
+                pass
     return _conv_fwd_raw(x, None, wp, bias, sum(couts), 1, "zero", act, slope, 1)
 
 
