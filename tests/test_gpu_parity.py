@@ -280,3 +280,53 @@ def test_kitti_baseline_decoder_vs_reference_golden(dev):
     assert set(key_str(k) for k in out) == set(gold)
     for k, v in out.items():
         assert_close(v, gold[key_str(k)], NET_TOL, key_str(k))
+
+
+NYU_ENC = [8, 8, 16, 32, 64]
+
+
+def _nyu_decoder(dev, enc=NYU_ENC, seed=8):
+    from wavelet_monodepth_amd.nyu import DecoderWave
+    return synth.fill_state_dict(DecoderWave(enc_features=enc), seed=seed).to(dev)
+
+
+def test_nyu_dense_decoder_vs_reference_golden(dev):
+    from util import nyu_feats
+    gold = load_golden("nyu_dense_small_64x96.npz")
+    dec = _nyu_decoder(dev)
+    with torch.no_grad():
+        out = dec([f.to(dev) for f in nyu_feats(2, 64, 96, NYU_ENC)])
+    assert set(key_str(k) for k in out) == set(gold)
+    for k, v in out.items():
+        assert_close(v, gold[key_str(k)], NET_TOL, key_str(k))
+
+
+def test_nyu_dense_decoder_gradients_vs_reference_golden(dev):
+    from util import nyu_feats, sample
+    g = load_golden("nyu_dense_small_64x96_grads.npz")
+    dec = _nyu_decoder(dev)
+    feats = [f.to(dev).requires_grad_(True) for f in nyu_feats(2, 64, 96, NYU_ENC)]
+    out = dec(feats)
+    loss = sum(out[("disp", s)].mean() for s in range(4))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    for k, f in enumerate(feats):
+        if "dfeat%d" % k in g:
+            assert_close(f.grad, g["dfeat%d" % k], NET_TOL, "dfeat%d" % k)
+    for name, p in dec.named_parameters():
+        assert_close(sample(p.grad.cpu().numpy()), g["d|" + name], NET_TOL, name)
+
+
+def test_nyu_dense_decoder_densenet161_shapes_vs_oracle(dev):
+    """BASELINE config 5 shapes (DenseNet161 features of a 640x480 image), batch 1, with the ragged
+    channel counts 2208/1104/552/276/138."""
+    from util import nyu_feats
+    enc = [96, 96, 192, 384, 2208]
+    dec = _nyu_decoder(dev, enc, seed=9)
+    feats = nyu_feats(1, 480, 640, enc, seed=9, prefix="nyu_big")
+    sd = {k: v.cpu() for k, v in dec.state_dict().items()}
+    with torch.no_grad():
+        ref = R.nyu_wave_decoder(feats, sd)
+        out = dec([f.to(dev) for f in feats])
+    for k in ref:
+        assert_close(out[k], ref[k], NET_TOL, key_str(k))

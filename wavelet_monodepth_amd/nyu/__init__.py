@@ -1,0 +1,1 @@
+from .densedepth_decoder import DecoderWave  # noqa: F401
