@@ -197,49 +197,68 @@ int wmd_head3x3_fwd(const wmd_head_args* args, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Sparse (threshold-gated) decoder path, batch 1
+ *
+ * Layout decision: activations stay DENSE [C,H,W] (zero-initialised by the caller); sparsity lives in
+ *   - uint8 masks [H,W] (the reference's lowres/upconv0/upsample/upconv1/wavelet masks), and
+ *   - compacted raster-order lists of active pixel indices (y*W+x) with a device-side count,
+ * so no kernel needs a host-visible nnz and no index map is ever materialised.  The reference's
+ * compact-tensor semantics are kept exactly: a neighbour that is not in the input mask reads 0
+ * (KITTI/layers.py:439-453), index-map padding becomes coordinate padding followed by the mask test.
  * ------------------------------------------------------------------ */
 
-/* min and max of x[0..n) -> out2[0]=min, out2[1]=max  (depth_decoder.py:308 yl.max()-yl.min()) */
-int wmd_minmax(const float* x, size_t n, float* out2, void* workspace, size_t workspace_floats, void* stream);
+/* out2[0] = min(x), out2[1] = max(x)   (depth_decoder.py:308 `yl.max() - yl.min()`), n >= 1. */
+int wmd_minmax(const float* x, size_t n, float* out2, void* stream);
 
-/* mask[y,x] = max_b |yh[b,y,x]| > (minmax[1]-minmax[0])*thresh_ratio   (depth_decoder.py:308-309)
- * yh [3,h,w]; mask uint8 [h,w].  thresh_ratio < 0 or force_all != 0 -> all ones.        */
-int wmd_mask_threshold(const float* yh, const float* minmax, float thresh_ratio, int force_all,
-                       uint8_t* mask, int h, int w, void* stream);
-
-/* out[y,x] = max over the (2r+1)^2 window of in[(y,x)/up]  (MaxPool2d(2r+1,1,r) of an optionally
- * nearest-upsampled mask, depth_decoder.py:311-319).  in [h,w]; out [h*up, w*up].      */
-int wmd_mask_dilate(const uint8_t* in, uint8_t* out, int h, int w, int up, int radius, void* stream);
-
-/* Raster-order stream compaction (mask2idxmap, KITTI/layers.py:382-389): idx[p] = rank of p among
- * active pixels or -1; *nnz_dev = count.  Wavefront ballot + popcount prefix sums.
- * workspace: >= wmd_mask_compact_workspace_bytes(h*w) bytes.                            */
-size_t wmd_mask_compact_workspace_bytes(int npix);
-int wmd_mask_compact(const uint8_t* mask, int32_t* idxmap, int32_t* coords /* [nnz] packed y*w+x, may be NULL */,
-                     int32_t* nnz_dev, int npix, void* workspace, size_t workspace_bytes, void* stream);
+/* mask[p] = (max_b |yh[b,p]| > (minmax[1]-minmax[0]) * thresh_ratio) ? 1 : 0   (depth_decoder.py:308-309).
+ * yh [3,h,w] planes.  The comparison is done exactly as the reference does it in fp32.            */
+int wmd_mask_threshold(const float* yh, const float* minmax, float thresh_ratio, uint8_t* mask,
+                       int h, int w, void* stream);
 
 typedef struct {
-    int H, W;           /* resolution of the output mask                                */
-    int C1, up1;        /* compact source 1: vals1 [nnz1, C1] pixel-major, idxmap1 [H/up1, W/up1] */
-    int C2;             /* dense skip source [C2,H,W] (may be 0)                        */
-    int Cout, ksize, pad_mode, act; float slope;
-    int Cmid;           /* >0: a fused leading 1x1 (C1->Cmid, LeakyReLU(slope_mid)) before the kxk, as
-                           sparse_conv3x3 does for nn.Sequential heads (layers.py:426-431) */
-    float slope_mid;
-    const float* vals1; const int32_t* idxmap1;
+    int up;          /* 1 or 2: nearest-upsample the input mask first (depth_decoder.py:311)       */
+    int radius;      /* 0,1,2 ...: MaxPool2d(2r+1, stride 1, padding r) (:313-319)                 */
+    uint8_t* out;    /* [h*up, w*up]                                                               */
+} wmd_dilate_spec;
+/* All dilated variants of one mask in a single launch (n <= 8). */
+int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wmd_dilate_spec* specs, int n, void* stream);
+
+typedef struct {
+    const uint8_t* mask;   /* [npix]                                                               */
+    int npix;
+    int32_t* coords;       /* [npix] capacity; receives the active pixel indices in raster order   */
+    int32_t* nnz;          /* device scalar                                                        */
+} wmd_compact_spec;
+/* Stream compaction (mask2idxmap / mask2yx, KITTI/layers.py:371-389) of up to 8 masks in one launch:
+ * one workgroup per mask, wavefront ballot + popcount prefix sums, raster order preserved.        */
+int wmd_mask_compact_multi(const wmd_compact_spec* specs, int n, void* stream);
+
+typedef struct {
+    int H, W;              /* output resolution                                                    */
+    int C1, up1;           /* source 1: dense [C1tot, H/up1, W/up1]; channels [c1_off, c1_off+C1) used */
+    int C1tot, c1_off;
+    int C2;                /* source 2 (skip): dense [C2,H,W]; 0 if none                           */
+    int Cout, ksize, pad_mode, act;
+    float slope;
+    const float* x1;
     const float* x2;
-    const int32_t* coords_out; const int32_t* nnz_out;   /* active output pixels         */
-    int max_nnz_out;    /* launch bound (capacity of coords_out / vals_out)             */
-    const float* w; const float* bias;                   /* [Cout, C1+C2 (or Cmid), k, k] */
-    const float* w_mid; const float* bias_mid;           /* [Cmid, C1]                   */
-    float* vals_out;    /* compact [nnz_out, Cout]                                      */
-    float* dense_out;   /* optional dense scatter target [Cout,H,W] (pre-zeroed)        */
-    float dense_scale;
+    const uint8_t* in_mask;      /* [H,W] support of the virtual input; NULL = everywhere          */
+    const int32_t* out_coords;   /* active output pixels                                          */
+    const int32_t* out_nnz;
+    int max_out;                 /* launch bound: capacity of out_coords                          */
+    const float* wp;             /* packed weights [Cout, C1+C2, k, k] (wmd_conv_pack_weights)     */
+    const float* bias;
+    /* dual-head mode (wp2 != NULL, Cout <= 16): a second filter over channels [c1_off2, c1_off2+C1)
+     * of x1; y = out_scale*act(conv) - out_scale*act(conv2)   (depth_decoder.py:276-290)          */
+    const float* wp2;
+    const float* bias2;
+    int c1_off2;
+    float out_scale;             /* y = out_scale * act(conv + bias)                              */
+    float* y;                    /* dense [Cout,H,W]; written at the active pixels only            */
 } wmd_sparse_conv_args;
 
-/* Gather-GEMM convolution on active pixels (sparse_conv3x3 / sparse_conv1x1 / sparse_upsample /
- * sparse_select, KITTI/layers.py:337-507): neighbours outside the input mask read zero, the
- * index map is padded reflect/constant/replicate on indices (layers.py:444).            */
+/* Gather-GEMM convolution on the active pixels (sparse_conv3x3 / sparse_conv1x1 / sparse_upsample /
+ * sparse_select, KITTI/layers.py:337-507) on fp32 MFMA: one wavefront = 16 active pixels x up to 64
+ * output channels; the B operand is gathered per lane through the coordinate-padding + mask test.  */
 int wmd_sparse_conv(const wmd_sparse_conv_args* args, void* stream);
 
 /* ------------------------------------------------------------------ *

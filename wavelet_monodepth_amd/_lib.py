@@ -47,14 +47,21 @@ class HeadArgs(C.Structure):
                 ("xp_bstride", C.c_size_t), ("xn_bstride", C.c_size_t)]
 
 
+class DilateSpec(C.Structure):
+    _fields_ = [("up", C.c_int), ("radius", C.c_int), ("out", C.c_void_p)]
+
+
+class CompactSpec(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("npix", C.c_int), ("coords", C.c_void_p), ("nnz", C.c_void_p)]
+
+
 class SparseConvArgs(C.Structure):
-    _fields_ = [("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
-                ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int), ("slope", C.c_float),
-                ("Cmid", C.c_int), ("slope_mid", C.c_float),
-                ("vals1", C.c_void_p), ("idxmap1", C.c_void_p), ("x2", C.c_void_p),
-                ("coords_out", C.c_void_p), ("nnz_out", C.c_void_p), ("max_nnz_out", C.c_int),
-                ("w", C.c_void_p), ("bias", C.c_void_p), ("w_mid", C.c_void_p), ("bias_mid", C.c_void_p),
-                ("vals_out", C.c_void_p), ("dense_out", C.c_void_p), ("dense_scale", C.c_float)]
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C1tot", C.c_int), ("c1_off", C.c_int),
+                ("C2", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int),
+                ("slope", C.c_float), ("x1", C.c_void_p), ("x2", C.c_void_p), ("in_mask", C.c_void_p),
+                ("out_coords", C.c_void_p), ("out_nnz", C.c_void_p), ("max_out", C.c_int),
+                ("wp", C.c_void_p), ("bias", C.c_void_p), ("wp2", C.c_void_p), ("bias2", C.c_void_p),
+                ("c1_off2", C.c_int), ("out_scale", C.c_float), ("y", C.c_void_p)]
 
 
 _lib = None
@@ -82,11 +89,10 @@ SIGNATURES = {
     "wmd_conv_wgrad_workspace_floats": (C.c_size_t, [C.POINTER(ConvWgradArgs)]),
     "wmd_conv_wgrad": (C.c_int, [C.POINTER(ConvWgradArgs), C.c_void_p]),
     "wmd_head3x3_fwd": (C.c_int, [C.POINTER(HeadArgs), C.c_void_p]),
-    "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "wmd_mask_dilate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "wmd_mask_compact_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "wmd_mask_compact": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),
+    "wmd_mask_compact_multi": (C.c_int, [C.POINTER(CompactSpec), C.c_int, C.c_void_p]),
     "wmd_sparse_conv": (C.c_int, [C.POINTER(SparseConvArgs), C.c_void_p]),
     "wmd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wmd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),

@@ -1,0 +1,177 @@
+"""SparseDepthWaveProgressiveDecoder on MI355X — API-compatible with the reference class
+(/root/reference/KITTI/networks/decoders/depth_decoder.py:171-428): same constructor, parameters and
+state_dict keys as the dense decoder (checkpoints are interchangeable), `forward(input_features,
+thresh_ratio=0.05, sparse_scales=[0,1,2,3])`, same output keys incl. the five mask families and the
+`total_ops` op model.  Batch 1, inference only.
+
+Differences that are not observable in the outputs: activations stay dense and zero-initialised instead of
+being compacted (see include/wmd.h), there is ONE host synchronisation per forward (to turn the device-side
+pixel counts into the python-int `total_ops`), and nothing is printed (the reference prints 'sparse: i').
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops, sparse_ops as S
+from ..wavelets import IDWT
+from .depth_decoder import _build_wave_convs
+
+
+def _conv_ops(cin, cout, npix, k):
+    # dense layers: (1 + k*k*cin*npix) * cout — the "1 +" sits inside the pixel product (reference :386-398)
+    return (1 + k * k * cin * npix) * cout
+
+
+def _sparse_conv_ops(cin, cout, nnz_out, mid=None):
+    ops_ = 0
+    if mid is not None:                       # fused leading 1x1 (layers.py:405)
+        cin_mid, cmid, nnz_in = mid
+        ops_ += nnz_in * cin_mid * cmid + nnz_in * cmid
+    ops_ += cin * 9 * nnz_out                 # gathered elements (layers.py:462)
+    ops_ += (1 + 9 * cin) * nnz_out * cout    # layers.py:469
+    return ops_
+
+
+class SparseDepthWaveProgressiveDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = "nearest"
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.J = 1
+        self.inverse_wt = IDWT(wave="haar", mode="zero")
+        self.convs = _build_wave_convs(self.num_ch_enc, self.num_ch_dec, use_skips)
+        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.sigmoid = nn.Sigmoid()
+
+    # ------------------------------------------------------------------------------------------
+    def _dense_coefficients(self, x, i, with_ll):
+        heads = ([0] if with_ll else []) + [1, -1]
+        mods = [self.convs[("waveconv", i, j)] for j in heads]
+        mid = ops.conv1x1_stacked_nograd(x, [m[0].conv.weight for m in mods], [m[0].conv.bias for m in mods],
+                                         act="leaky", slope=0.1)
+        offs, o = {}, 0
+        for j, m in zip(heads, mods):
+            offs[j] = o
+            o += m[0].conv.weight.shape[0]
+        yl = None
+        if with_ll:
+            c3 = mods[0][2].conv
+            yl = ops.head3x3_nograd(mid, c3.weight.shape[1], offs[0], c3.weight, c3.bias, pad="reflect", mode=1,
+                                    scale=2.0 ** i)
+        cp, cn = self.convs[("waveconv", i, 1)][2].conv, self.convs[("waveconv", i, -1)][2].conv
+        yh = ops.head3x3_nograd(mid, cp.weight.shape[1], offs[1], cp.weight, cp.bias, offs[-1], cn.weight, cn.bias,
+                                pad="reflect", mode=2, scale=2.0 ** (i - 1))
+        return yl, yh.unsqueeze(1)
+
+    @torch.no_grad()
+    def forward(self, input_features, thresh_ratio=0.05, sparse_scales=[0, 1, 2, 3], _force_masks=None):
+        self.outputs = out = {}
+        x = input_features[-1]
+        assert x.shape[0] == 1, "works with single input only"
+        dev = x.device
+        sparse_scales = list(sparse_scales)
+        counters = []          # (level, nnz tensor [3]) resolved into python ints once, at the end
+        static_ops = {}
+        yl = yh = None
+        xbuf = None            # dense [C,h,w] activations carried between sparse levels
+        x = x.contiguous()
+        for i in range(4, -1, -1):
+            scale_ops = 0
+            h, w = x.shape[-2:] if xbuf is None else xbuf.shape[-2:]
+            if i == 4:
+                mask = torch.ones((h, w), device=dev, dtype=torch.uint8)
+            else:
+                mm = S.minmax(yl)
+                mask = S.mask_threshold(yh, mm, thresh_ratio)
+                scale_ops += 3 * h * w
+            if _force_masks is not None and i in _force_masks:
+                mask = _force_masks[i].to(dev).reshape(h, w).to(torch.uint8).contiguous()
+            lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask, [(1, 1), (1, 2), (2, 2), (2, 1), (2, 0)])
+            scale_ops += 25 * h * w + 100 * h * w
+            H2, W2 = 2 * h, 2 * w
+            b = lambda m: m.view(torch.bool).reshape(1, 1, *m.shape)
+            out[("lowres_mask", i - 1)] = b(lowres)
+            out[("upconv0_mask", i - 1)] = b(upconv0)
+            out[("upsample_mask", i - 1)] = b(upsample_m)
+            out[("upconv1_mask", i - 1)] = b(upconv1)
+            out[("wavelet_mask", i - 1)] = b(wavelet)
+            c0 = self.convs[("upconv", i, 0)].conv.conv if i > 0 else None
+            c1 = self.convs[("upconv", i, 1)].conv.conv if i > 0 else None
+
+            if i in sparse_scales:
+                assert self.use_skips and i > 0 and yl is not None
+                scale_ops += 2 * h * w + 2 * H2 * W2          # four mask2idxmap calls (layers.py:388)
+                (co0, co1, cow), nnz = S.compact_multi([upconv0, upconv1, wavelet])
+                src = xbuf if xbuf is not None else x[0]
+                C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
+                x0 = torch.zeros((C0, h, w), device=dev)
+                S.sparse_conv(x0, src, ops.pack_weights(c0.weight), c0.bias, C0, 3, co0, nnz.data_ptr(), h * w,
+                              in_mask=lowres, pad="reflect", act="elu")
+                skip = input_features[i - 1][0].contiguous()
+                x1 = torch.zeros((C1_, H2, W2), device=dev)
+                S.sparse_conv(x1, x0, ops.pack_weights(c1.weight), c1.bias, C1_, 3, co1, nnz.data_ptr() + 4, H2 * W2,
+                              x2=skip, up1=2, in_mask=upsample_m, pad="reflect", act="elu")
+                # heads: stacked 1x1 + LeakyReLU on the upconv1 support, dual 3x3 + sigmoid on the wavelet mask
+                hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
+                wstack, bstack = ops.stacked_pack([hp[0].conv.weight, hn[0].conv.weight], [hp[0].conv.bias, hn[0].conv.bias])
+                Cm = hp[0].conv.weight.shape[0]
+                mid = torch.zeros((2 * Cm, H2, W2), device=dev)
+                S.sparse_conv(mid, x1, wstack, bstack, 2 * Cm, 1, co1, nnz.data_ptr() + 4, H2 * W2, act="leaky", slope=0.1)
+                yh_d = torch.zeros((1, 3, H2, W2), device=dev)
+                S.sparse_conv(yh_d[0], mid, ops.pack_weights(hp[2].conv.weight), hp[2].conv.bias, 3, 3, cow,
+                              nnz.data_ptr() + 8, H2 * W2, in_mask=upconv1, pad="reflect", act="sigmoid",
+                              out_scale=2.0 ** (i - 1), c1=Cm, c1_off=0, wp2=ops.pack_weights(hn[2].conv.weight),
+                              bias2=hn[2].conv.bias, c1_off2=Cm)
+                yh = yh_d.unsqueeze(1)
+                counters.append((i, nnz, (c0.weight.shape[1], C0), (c1.weight.shape[1], C1_),
+                                 (hp[0].conv.weight.shape[1], Cm), (hp[2].conv.weight.shape[1], 3)))
+                xbuf = x1
+            else:
+                src = xbuf.unsqueeze(0) if xbuf is not None else x
+                scale_ops += _conv_ops(src.shape[1], c0.weight.shape[0], h * w, 3)
+                xd = ops.conv2d_fused(src, c0.weight, c0.bias, pad="reflect", act="elu")
+                skip = input_features[i - 1] if (self.use_skips and i > 0) else None
+                cin1 = xd.shape[1] + (0 if skip is None else skip.shape[1])
+                scale_ops += _conv_ops(cin1, c1.weight.shape[0], H2 * W2, 3)
+                ux = ops.conv2d_fused(xd, c1.weight, c1.bias, x2=skip, up1=2, pad="reflect", act="elu")
+                for j in ([0] if i == 4 else []) + [-1, 1]:
+                    hd = self.convs[("waveconv", i, j)]
+                    scale_ops += _conv_ops(hd[0].conv.weight.shape[1], hd[0].conv.weight.shape[0], H2 * W2, 1)
+                    scale_ops += _conv_ops(hd[2].conv.weight.shape[1], hd[2].conv.weight.shape[0], H2 * W2, 3)
+                ll_new, yh = self._dense_coefficients(ux, i, with_ll=(i == 4))
+                if i == 4:
+                    yl = ll_new
+                else:
+                    yh = yh * wavelet.reshape(1, 1, 1, H2, W2)   # reference :272 (all ones at i == 4)
+                xbuf = ux[0]
+
+            out[("wavelets", i - 1, "LL")] = yl
+            out[("wavelets", i - 1, "LH")] = yh[:, :, 0]
+            out[("wavelets", i - 1, "HL")] = yh[:, :, 1]
+            out[("wavelets", i - 1, "HH")] = yh[:, :, 2]
+            yl, disp = ops.idwt_haar(yl, yh, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
+            scale_ops += 4 * yl.shape[2] * yl.shape[3]
+            out[("disp", i - 1)] = disp
+            static_ops[i] = scale_ops
+            if i == 1:
+                break
+
+        # ---- the reference's op model needs the pixel counts as python ints: one sync for the whole forward
+        total_ops = 0
+        resolved = {lvl: [int(v) for v in nnz.tolist()] for (lvl, nnz, *_rest) in counters}
+        for i in sorted(static_ops, reverse=True):
+            scale_ops = static_ops[i]
+            for (lvl, _nnz, (ci0, co0_), (ci1, co1_), (cim, cm), (ci3, co3)) in counters:
+                if lvl != i:
+                    continue
+                n0, n1, nw = resolved[lvl]
+                scale_ops += _sparse_conv_ops(ci0, co0_, n0) + _sparse_conv_ops(ci1, co1_, n1)
+                scale_ops += 2 * _sparse_conv_ops(ci3, co3, nw, mid=(cim, cm, n1))
+            out[("total_ops", i - 1)] = scale_ops
+            total_ops += scale_ops
+        out["total_ops"] = total_ops
+        return out

@@ -265,34 +265,40 @@ def head3x3(xp, weight_p, bias_p, xn=None, weight_n=None, bias_n=None, pad="refl
 # inference-only fast paths (no autograd): stacked 1x1 heads + head3x3 on channel slices
 # ---------------------------------------------------------------------------------------------
 
-def conv1x1_stacked_nograd(x, weights, biases, act="leaky", slope=0.1):
-    """Several 1x1 convolutions of the SAME input as one launch: their packed weight images are simply
-    concatenated along the out-channel-tile axis (every Cout is a multiple of 16), so x is read once.
-    Returns [B, sum(Cout_k), H, W]."""
+def stacked_pack(weights, biases):
+    """Packed image + bias of several [Cout_k, Cin, 1, 1] filters stacked along Cout (memoised on weights[0])."""
     l = _lib.lib()
-    x = _c(x)
-    cin = x.shape[1]
+    cin = weights[0].shape[1]
     couts = [w.shape[0] for w in weights]
     if any(c % 16 for c in couts[:-1]):
         raise _lib.WmdError("stacked heads need out-channel counts that are multiples of 16")
     tag = tuple((w._version, w.data_ptr(), b._version, b.data_ptr()) for w, b in zip(weights, biases))
     hit = getattr(weights[0], "_wmd_pack_stack", None) if _PACK_CACHE else None
     if hit is not None and hit[0] == tag:
-        wp, bias = hit[1], hit[2]
-    else:
-        sizes = [l.wmd_conv_packed_weight_floats(c, cin, 1) for c in couts]
-        wp = torch.empty(sum(sizes), device=x.device, dtype=torch.float32)
-        s = current_stream()
-        off = 0
-        for w, n, c in zip(weights, sizes, couts):
-            check(l.wmd_conv_pack_weights(ptr(_c(w.detach())), wp.data_ptr() + 4 * off, c, cin, 1, s), "wmd_conv_pack_weights")
-            off += n
-        bias = torch.cat([b.detach() for b in biases])
-        if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
-            try:
-                weights[0]._wmd_pack_stack = (tag, wp, bias)
-            except AttributeError:
-                pass
+        return hit[1], hit[2]
+    sizes = [l.wmd_conv_packed_weight_floats(c, cin, 1) for c in couts]
+    wp = torch.empty(sum(sizes), device=weights[0].device, dtype=torch.float32)
+    s = current_stream()
+    off = 0
+    for w, n, c in zip(weights, sizes, couts):
+        check(l.wmd_conv_pack_weights(ptr(_c(w.detach())), wp.data_ptr() + 4 * off, c, cin, 1, s), "wmd_conv_pack_weights")
+        off += n
+    bias = torch.cat([b.detach() for b in biases])
+    if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
+        try:
+            weights[0]._wmd_pack_stack = (tag, wp, bias)
+        except AttributeError:
+            pass
+    return wp, bias
+
+
+def conv1x1_stacked_nograd(x, weights, biases, act="leaky", slope=0.1):
+    """Several 1x1 convolutions of the SAME input as one launch: their packed weight images are simply
+    concatenated along the out-channel-tile axis (every Cout is a multiple of 16), so x is read once.
+    Returns [B, sum(Cout_k), H, W]."""
+    x = _c(x)
+    couts = [w.shape[0] for w in weights]
+    wp, bias = stacked_pack(weights, biases)
     return _conv_fwd_raw(x, None, wp, bias, sum(couts), 1, "zero", act, slope, 1)
 
 
