@@ -124,3 +124,39 @@ def test_sparse_equals_dense_at_negative_threshold(dev):
     for s in range(4):
         assert_close(a[("disp", s)], b[("disp", s)], 2e-5, "disp%d" % s)
     assert a["total_ops"] == 3560015775      # notebook known answer for R18 640x192
+
+
+NYU_ENC = [8, 8, 16, 32, 64]
+
+
+def _nyu(dev):
+    from wavelet_monodepth_amd.nyu import SparseDecoderWave
+    return synth.fill_state_dict(SparseDecoderWave(enc_features=NYU_ENC), seed=8).to(dev)
+
+
+def _check_nyu(out, gold, tol=NET_TOL):
+    assert set(key_str(k) for k in out) == set(gold), set(gold) ^ set(key_str(k) for k in out)
+    for k, v in out.items():
+        ks = key_str(k)
+        if torch.is_tensor(v):
+            assert_close(v, gold[ks], tol, ks)
+        else:
+            assert int(v) == int(gold[ks]), "%s: %d vs %d" % (ks, int(v), int(gold[ks]))
+
+
+@pytest.mark.parametrize("thr", [-1.0, 0.02])
+def test_nyu_sparse_decoder_full_density_vs_reference_golden(dev, thr):
+    from util import nyu_feats
+    gold = load_golden("nyu_sparse_small_64x96_thr%g.npz" % thr)
+    out = _nyu(dev)([f[:1].to(dev) for f in nyu_feats(2, 64, 96, NYU_ENC)], thr)
+    _check_nyu(out, gold)
+
+
+def test_nyu_sparse_decoder_vs_reference_golden_with_reference_masks(dev):
+    from util import nyu_feats
+    gold = load_golden("nyu_sparse_small_64x96_thr0.1.npz")
+    dens = [float(gold["wavelet_mask|%d" % s].mean()) for s in (1, 0)]
+    assert min(dens) < 0.9, "fixture should exercise a non-trivial mask: %s" % dens
+    force = {lvl: t(gold["wavelet_mask|%d" % (1 - lvl)])[0, 0, ::2, ::2] for lvl in (0, 1)}
+    out = _nyu(dev)([f[:1].to(dev) for f in nyu_feats(2, 64, 96, NYU_ENC)], 0.1, _force_masks=force)
+    _check_nyu(out, gold)

@@ -1,1 +1,1 @@
-from .densedepth_decoder import DecoderWave  # noqa: F401
+from .densedepth_decoder import DecoderWave, SparseDecoderWave  # noqa: F401

@@ -11,7 +11,7 @@ Decoder/Decoder224/DecoderWave224 classes are SURVEY §8(f) "next" items.
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, sparse_ops as S
 from ..layers import NyuConv3x3, UpSampleBlock
 from ..wavelets import IDWT
 from ..graphs import GraphCache
@@ -84,3 +84,82 @@ class DecoderWave(nn.Module):
         ll, _ = ops.idwt_haar(ll, h)
         outputs[("disp", 0)] = ll
         return outputs
+
+
+def _sparse_conv_ops(cin, cout, nnz_out):
+    # ops returned by sparse_conv3x3 (NYUv2/networks/layers.py: gathered elements + (1 + 9 cin) * nnz * cout)
+    return cin * 9 * nnz_out + (1 + 9 * cin) * nnz_out * cout
+
+
+class SparseDecoderWave(DecoderWave):
+    """SparseDecoderWave (reference densedepth_decoder.py:224-409): dense down to scale 2, then two
+    threshold-gated levels that only use up{2,3}.convA and wave{2,3}.  `forward(x_blocks, thresh_ratio=0.1)`,
+    batch 1, inference only; returns the reference's keys incl. ("wavelet_mask", s) and "total_ops".
+    (The reference prints "Using Sparse DenseDepth Decoder" on construction; this class does not.)"""
+
+    def __init__(self, enc_features=[96, 96, 192, 384, 2208], decoder_width=0.5):
+        super().__init__(enc_features=enc_features, decoder_width=decoder_width)
+
+    @torch.no_grad()
+    def forward(self, x_blocks, thresh_ratio=0.1, _force_masks=None):
+        out = {}
+        xb = x_blocks
+        assert xb[-1].shape[0] == 1, "works with single input only"
+        dev = xb[-1].device
+        total_ops = 0
+        w2 = self.conv2.conv.weight
+        total_ops += (1 + 9 * xb[-1].shape[1]) * xb[-1].shape[2] * xb[-1].shape[3] * w2.shape[0]
+        x_d0 = self.conv2(xb[-1])
+        x_d1 = self.up1(x_d0, xb[-2])
+        chn = x_d0.shape[1] + xb[-2].shape[1]
+        total_ops += (1 + 9 * chn) * x_d1.shape[2] * x_d1.shape[3] * x_d1.shape[1]
+        ll = self._wave(self.wave1_ll, x_d1, 2.0 ** 3)
+        out[("disp", 3)] = ll / (2 ** 3)
+        h = self._wave(self.wave1, x_d1, 2.0 ** 2).unsqueeze(1)
+        total_ops += (1 + 9 * x_d1.shape[1]) * x_d1.shape[2] * x_d1.shape[3] * 4
+        out[("wavelet_mask", 2)] = torch.ones_like(h[:, 0])
+        out[("wavelets", 2, "LL")] = ll
+        out[("wavelets", 2, "LH")], out[("wavelets", 2, "HL")], out[("wavelets", 2, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+        ll, disp = ops.idwt_haar(ll, h, disp_scale=0.25, clamp01=False)
+        total_ops += ll.shape[2] * ll.shape[3]
+        out[("disp", 2)] = disp
+
+        src = x_d1[0].contiguous()       # dense [C,h,w]; later: the previous level's convA output buffer
+        pending = []
+        for level, (up, wave, skip, scale) in enumerate(((self.up2, self.wave2, xb[-3], 2.0), (self.up3, self.wave3, xb[-4], 1.0))):
+            mh, mw = src.shape[-2:]
+            mask = S.mask_threshold(h, S.minmax(ll), thresh_ratio)
+            if _force_masks is not None and level in _force_masks:
+                mask = _force_masks[level].to(dev).reshape(mh, mw).to(torch.uint8).contiguous()
+            total_ops += 3 * mh * mw
+            up_mask, conva_mask, wave_mask, wavelet_mask = S.dilate_multi(mask, [(1, 2), (2, 2), (2, 1), (2, 0)])
+            total_ops += 25 * mh * mw + 100 * mh * mw
+            # mask2idxmap calls: wavelet, conva, wave (fine) + up (coarse) (+ a repeated `wave` at the 2nd level, :374-375)
+            total_ops += 3 * 4 * mh * mw + mh * mw + (4 * mh * mw if level == 1 else 0)
+            H2, W2 = 2 * mh, 2 * mw
+            s = 1 - level
+            out[("wavelet_mask", s)] = wavelet_mask.to(torch.float32).reshape(1, 1, H2, W2)
+            (co_wave, co_wl), nnz = S.compact_multi([wave_mask, wavelet_mask])
+            ca = up.convA.conv
+            Ca = ca.weight.shape[0]
+            xa = torch.zeros((Ca, H2, W2), device=dev)
+            # sparse_upsample (coarse values on up_mask are a subset test away: conva_mask lies inside up2(up_mask))
+            # + convA + LeakyReLU(0.2), reflect index padding, outputs on wave_mask
+            S.sparse_conv(xa, src, ops.pack_weights(ca.weight), ca.bias, Ca, 3, co_wave, nnz.data_ptr(), H2 * W2,
+                          x2=skip[0].contiguous(), up1=2, in_mask=conva_mask, pad="reflect", act="leaky", slope=0.2)
+            cw = wave.conv
+            hd = torch.zeros((1, 3, H2, W2), device=dev)
+            S.sparse_conv(hd[0], xa, ops.pack_weights(cw.weight), cw.bias, 3, 3, co_wl, nnz.data_ptr() + 4, H2 * W2,
+                          in_mask=wave_mask, pad="zero", act="none", out_scale=scale)
+            h = hd.unsqueeze(1)
+            out[("wavelets", s, "LH")], out[("wavelets", s, "HL")], out[("wavelets", s, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+            ll, disp = ops.idwt_haar(ll, h, disp_scale=0.5 if level == 0 else 1.0, clamp01=False)
+            total_ops += ll.shape[2] * ll.shape[3]
+            out[("disp", s)] = disp if level == 0 else ll
+            pending.append((nnz, ca.weight.shape[1], Ca, cw.weight.shape[1]))
+            src = xa
+        for nnz, cin_a, ca_, cin_w in pending:           # one host sync for the python-int op model
+            n_wave, n_wl = [int(v) for v in nnz.tolist()]
+            total_ops += _sparse_conv_ops(cin_a, ca_, n_wave) + _sparse_conv_ops(cin_w, 3, n_wl)
+        out["total_ops"] = total_ops
+        return out
