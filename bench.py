@@ -79,12 +79,83 @@ def cpu_baseline(dec, feats, budget_s=20.0):
                       % (len(times), med, torch.__version__, best, cands, avail)}
 
 
+def train_main(args, rank, local_rank, world, dev):
+    """Secondary workload (BASELINE.json configs[2]): KITTI ResNet50 1024x320 training step, batch 8 per GPU —
+    torch encoder + HIP decoder forward/backward, gradient all-reduce through RCCL (decoder bucket first, on a
+    side stream), Adam.  Reported for scaling studies; the headline metric stays the forward workload."""
+    import torch.distributed as dist
+    from wavelet_monodepth_amd import synth
+    from wavelet_monodepth_amd.ddp import GradientExchange, monodepth_groups
+    from wavelet_monodepth_amd.encoders import ResnetEncoder
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+
+    H, W, B = args.height, args.width, args.batch
+    torch.manual_seed(0)
+    enc = ResnetEncoder(args.num_layers).to(dev)
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(enc.num_ch_enc), seed=1).to(dev)
+    params = list(enc.parameters()) + list(dec.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-5)
+    gx = GradientExchange(monodepth_groups(enc, dec), world=world, rank=rank, backend="rccl" if world > 1 else "torch") \
+        if world > 1 else None
+    img = torch.from_numpy(synth.uniform((B, 3, H, W), "img%d" % rank, 0, 0.0, 1.0)).to(dev)
+    target = [torch.from_numpy(synth.uniform((B, 1, H >> s, W >> s), "tgt%d" % s, rank, 0.05, 0.95)).to(dev) for s in range(4)]
+
+    def step():
+        if gx is not None:
+            gx.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        out = dec(enc(img))
+        loss = sum((out[("disp", s)] - target[s]).abs().mean() for s in range(4))
+        loss.backward()
+        if gx is not None:
+            gx.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(loss)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training frames/sec (encoder + wavelet decoder fwd+bwd + Adam) @%dx%d bs%d/GPU" % (W, H, B),
+            "value": round(B * args.steps * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "KITTI ResNet%d %dx%d training step, batch %d per GPU, loss = sum_s mean|disp_s - target_s| "
+                                   "(BASELINE.json configs[2])" % (args.num_layers, W, H, B),
+                       "global_batch": B * world, "parallelism": "dp%d, RCCL bucketed all-reduce" % world},
+            "gradient_bytes": None if gx is None else gx.message_bytes()}))
+    if gx is not None:
+        gx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["fwd", "train"], default="fwd")
+    ap.add_argument("--num-layers", type=int, default=50)
+    ap.add_argument("--height", type=int, default=320)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,6 +171,12 @@ def main():
 
     from wavelet_monodepth_amd import _lib
     _lib.lib()  # fail loudly if the HIP library is missing
+
+    if args.workload == "train":
+        train_main(args, rank, local_rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     dec, feats = build_model(dev)
 
