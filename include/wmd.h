@@ -188,12 +188,15 @@ typedef struct {
     float* sig_n;
     size_t xp_bstride;  /* floats between consecutive batch items of xp / xn; 0 = C*H*W (lets xp, xn be  */
     size_t xn_bstride;  /* channel slices of one stacked [B,Ctot,H,W] tensor)                             */
+    float* workspace;   /* optional (wmd_head3x3_workspace_floats): lets coarse levels split the channel  */
+    size_t workspace_floats; /* loop over several workgroups (two-stage, deterministic)                   */
 } wmd_head_args;
 
 /* Replaces Conv3x3(C,3|1) + Sigmoid + the 2^(s-1)(sigma+ - sigma-) combine of
  * DepthWaveProgressiveDecoder.get_coefficients (depth_decoder.py:126-136) and the
  * NYUv2 wave1_ll/wave{1,2,3} convolutions (densedepth_decoder.py:106-115).             */
 int wmd_head3x3_fwd(const wmd_head_args* args, void* stream);
+size_t wmd_head3x3_workspace_floats(const wmd_head_args* args);
 
 /* ------------------------------------------------------------------ *
  * Sparse (threshold-gated) decoder path, batch 1

@@ -1,0 +1,27 @@
+"""Time the wavelet heads of config 2 level by level (development aid)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from wavelet_monodepth_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+B = 12
+for C, H, W in [(256, 12, 40), (128, 24, 80), (64, 48, 160), (32, 96, 320)]:
+    mid = torch.randn(B, 2 * C, H, W, device=dev)
+    wp = torch.randn(3, C, 3, 3, device=dev) * 0.05
+    wn = torch.randn(3, C, 3, 3, device=dev) * 0.05
+    b = torch.randn(3, device=dev)
+    for _ in range(3):
+        ops.head3x3_nograd(mid, C, 0, wp, b, C, wn, b, mode=2, scale=2.0)
+    torch.cuda.synchronize()
+    _lib.profile_begin()
+    for _ in range(20):
+        ops.head3x3_nograd(mid, C, 0, wp, b, C, wn, b, mode=2, scale=2.0)
+    recs = _lib.profile_end()
+    us = recs[0]["ms"] / recs[0]["calls"] * 1e3
+    fl = 2 * 2 * 27 * C * B * H * W
+    print("head3x3 C=%3d %3dx%-3d: %7.1f us  %5.1f TFLOP/s" % (C, H, W, us, fl / us / 1e6))

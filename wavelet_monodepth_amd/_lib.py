@@ -44,7 +44,8 @@ class HeadArgs(C.Structure):
                 ("xp", C.c_void_p), ("wgt_p", C.c_void_p), ("bias_p", C.c_void_p),
                 ("xn", C.c_void_p), ("wgt_n", C.c_void_p), ("bias_n", C.c_void_p),
                 ("y", C.c_void_p), ("sig_p", C.c_void_p), ("sig_n", C.c_void_p),
-                ("xp_bstride", C.c_size_t), ("xn_bstride", C.c_size_t)]
+                ("xp_bstride", C.c_size_t), ("xn_bstride", C.c_size_t),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
 
 
 class DilateSpec(C.Structure):
@@ -89,6 +90,7 @@ SIGNATURES = {
     "wmd_conv_wgrad_workspace_floats": (C.c_size_t, [C.POINTER(ConvWgradArgs)]),
     "wmd_conv_wgrad": (C.c_int, [C.POINTER(ConvWgradArgs), C.c_void_p]),
     "wmd_head3x3_fwd": (C.c_int, [C.POINTER(HeadArgs), C.c_void_p]),
+    "wmd_head3x3_workspace_floats": (C.c_size_t, [C.POINTER(HeadArgs)]),
     "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),

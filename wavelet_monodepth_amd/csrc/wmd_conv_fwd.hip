@@ -58,10 +58,29 @@ struct ConvTile {
     static constexpr int PS = ((NPOSITIONS - 16 + 31) / 32) * 32 + 16;
     static constexpr int NPOS = (NPOSITIONS + NT - 1) / NT;
     static constexpr int NPIX = TH * TW;
-    static constexpr int LDS_FLOATS = 2 * CK * PS;
+    // weight tile of one chunk: (WM*MR) out-channel tiles x (CK/4) K-steps x TAPS fragments of 64 floats, in the
+    // packed image's own order (a straight copy of WM*MR contiguous global runs)
+    static constexpr int A_RUN = (CK / 4) * TAPS * 64;
+    static constexpr int A_FLOATS = WM * MR * A_RUN;
+    static constexpr int B_FLOATS = CK * PS;
+    static constexpr int NAV = (A_FLOATS / 4 + NT - 1) / NT;  // 16-byte weight pieces per thread and chunk
+    static constexpr int LDS_FLOATS = 2 * B_FLOATS + 2 * A_FLOATS;
     static_assert(WN * NR * 16 >= NPIX, "tile has more pixels than MFMA columns");
     static_assert(CK % 8 == 0, "CK must be a multiple of 8 (an even number of 4-channel K-steps)");
+    static_assert((A_FLOATS / 4) % 64 == 0, "the weight tile must be a whole number of 64-lane 16-byte pieces");
+    static_assert(TW % 4 == 0, "four consecutive pixels of an accumulator row must not straddle image rows");
 };
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// LDS-DMA wrappers.  They are deliberately NOT templates: inside a dependent context hipcc's host pass rejects
+// the 16-byte form (a gfx950 feature check against the host target) and silently drops the kernel's host stub.
+__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+}
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a) {
@@ -69,7 +88,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     constexpr int NT = T::NT, HALO = T::HALO, PW = T::PW, PS = T::PS, NPOS = T::NPOS;
     constexpr int KSTEPS = CK / 4;
 
-    __shared__ float lds[T::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    float* ldsA = lds + 2 * T::B_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,13 +104,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const int b = t / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     const int ks = blockIdx.z;
-
     const int H = a.H, W = a.W;
 
     // ---- staging geometry: each thread owns NPOS patch positions for every channel ----------
-    // byte offsets inside one channel plane of x1 / x2 (32-bit: a plane is far below 4 GiB)
+    // Staging is LDS-DMA (buffer_load ... lds): a wavefront instruction gathers 64 arbitrary global dwords
+    // (descriptor base + wave-uniform SGPR channel offset + 32-bit per-lane byte offset) straight into 64
+    // CONSECUTIVE LDS dwords — the patch is position-linear, so no VGPR round trip, no ds_write, no select.
+    // A position that must read zero (zero padding, tile overhang, dgrad extension, channel tail) gets an
+    // out-of-range byte offset: the descriptor's range check makes the load return 0.
+    constexpr unsigned kOOB = 0x80000000u;  // >= any num_records (< 2^31) and cannot wrap when an SGPR offset is added
     unsigned ob1[NPOS], ob2[NPOS];
-    bool live[NPOS];
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
         const int p = tid + i * NT;
@@ -101,78 +124,73 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
             ok = pad_coord(gy, H, a.pad_mode) && ok;
             ok = pad_coord(gx, W, a.pad_mode) && ok;
         }
-        // tile overhang (H % TH != 0): keep the address legal, the result is never stored
-        ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
+        ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;  // tile overhang (H % TH != 0)
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
-        ob2[i] = (unsigned)(gy * W + gx) * 4u;
+        ob2[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
         int sy = gy - a.shift1, sx = gx - a.shift1;
         if (a.up1 == 2) {
             sy = gy >> 1;
             sx = gx >> 1;
         }
-        ok = ok && sy >= 0 && sx >= 0 && sy < a.H1 && sx < a.W1;
-        sy = min(max(sy, 0), a.H1 - 1);
-        sx = min(max(sx, 0), a.W1 - 1);
-        live[i] = ok;
-        ob1[i] = (unsigned)(sy * a.W1 + sx) * 4u;
+        const bool ok1 = ok && sy >= 0 && sx >= 0 && sy < a.H1 && sx < a.W1;
+        ob1[i] = ok1 ? (unsigned)(sy * a.W1 + sx) * 4u : kOOB;
     }
 
     const size_t plane1 = (size_t)a.H1 * a.W1, plane2 = (size_t)H * W;
     const float* x1b = a.x1 + (size_t)b * a.C1 * plane1;
-    const float* x2b = a.x2 ? a.x2 + (size_t)b * a.C2 * plane2 : nullptr;
+    const float* x2b = a.x2 ? a.x2 + (size_t)b * a.C2 * plane2 : a.x1;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x1b), 0, (int)(a.C1 * plane1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x2b), 0, (int)(a.C2 * plane2 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wp), 0, (int)((size_t)a.ncot * a.nci4 * TAPS * 64 * 4), 0x00020000);
+    const unsigned pb1 = (unsigned)(plane1 * 4), pb2 = (unsigned)(plane2 * 4);
 
-    float sv[CK][NPOS];
-    // Branch-free per element on purpose: every load is unconditional from a clamped (always legal)
-    // address; the pad/overhang/channel-tail zeroing is a select applied when the registers are written to
-    // LDS, i.e. AFTER the MFMA block, so the loads stay in flight behind the matrix work.  (A conditional
-    // load, or a select right after the load, makes hipcc wait vmcnt(0) before the first MFMA of the chunk.)
-    // Addressing is (wave-uniform 64-bit base) + (32-bit per-lane byte offset): one scalar multiply-add per
-    // channel and one global_load per element when the whole chunk comes from one source tensor.
-    auto stage_load = [&](int chunk) {
+    // A (weights): the packed image keeps, for every out-channel tile, the chunk's (K-step, tap) fragments
+    // contiguous, so the block's weight tile is WM*MR straight runs of A_RUN floats, DMA'd as 16-byte pieces.
+    // (Loading the fragments from global in every wave costs ~30 % of the MFMA rate: tools/probes/mfma_probe.hip.)
+    unsigned aoff[T::NAV];
+#pragma unroll
+    for (int v = 0; v < T::NAV; ++v) {
+        const int e = tid + v * NT;  // 16-byte piece index inside the block's weight tile
+        const int run = (e * 4) / T::A_RUN, rem = (e * 4) % T::A_RUN;
+        const int cot = min((int)blockIdx.y * WM * MR + run, a.ncot - 1);
+        aoff[v] = (unsigned)(((size_t)cot * a.nci4 * TAPS * 64 + rem) * 4);
+    }
+
+    // issue the DMA of one chunk (patch + weights) into LDS buffer `buf`; completion = vmcnt(0) + barrier
+    auto stage = [&](int chunk, int buf) {
         const int c0 = chunk * CK;
-        const bool pure1 = c0 + CK <= a.C1 || a.C2 == 0;
-        const bool pure2 = c0 >= a.C1;
-        if (pure1 || pure2) {
-            const char* base = pure1 ? reinterpret_cast<const char*>(x1b + (size_t)c0 * plane1)
-                                     : reinterpret_cast<const char*>(x2b + (size_t)(c0 - a.C1) * plane2);
-            const size_t pstride = (pure1 ? plane1 : plane2) * sizeof(float);
-            const int jmax = a.Cin - 1 - c0;  // channel tail of the last chunk: re-read a legal plane
-            unsigned ob[NPOS];
-#pragma unroll
-            for (int i = 0; i < NPOS; ++i) ob[i] = pure1 ? ob1[i] : ob2[i];
-#pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                const char* bj = base + (size_t)min(j, jmax) * pstride;
-#pragma unroll
-                for (int i = 0; i < NPOS; ++i) sv[j][i] = *reinterpret_cast<const float*>(bj + ob[i]);
-            }
-        } else {  // the one chunk that straddles the concat seam
-#pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                const int ci = min(c0 + j, a.Cin - 1);
-                const bool from_x1 = ci < a.C1;
-                const char* bj = from_x1 ? reinterpret_cast<const char*>(x1b + (size_t)ci * plane1)
-                                         : reinterpret_cast<const char*>(x2b + (size_t)(ci - a.C1) * plane2);
-#pragma unroll
-                for (int i = 0; i < NPOS; ++i) sv[j][i] = *reinterpret_cast<const float*>(bj + (from_x1 ? ob1[i] : ob2[i]));
-            }
-        }
-    };
-    auto stage_store = [&](int buf, int chunk) {
-        float* dst = lds + buf * (CK * PS);
+        float* dstB = lds + buf * T::B_FLOATS + wave * 64;  // + lane*4 bytes is added by the hardware
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
-            const bool chan_ok = chunk * CK + j < a.Cin;
+            const int ci = c0 + j;  // wave-uniform
+            const bool from_x1 = ci < a.C1;
+            const bool chan_ok = ci < a.Cin;
+            const unsigned soff = from_x1 ? (unsigned)ci * pb1 : (unsigned)max(ci - a.C1, 0) * pb2;
 #pragma unroll
             for (int i = 0; i < NPOS; ++i) {
-                const int p = tid + i * NT;
-                if (NPOS * NT == T::NPOSITIONS || p < T::NPOSITIONS) dst[j * PS + p] = (live[i] && chan_ok) ? sv[j][i] : 0.f;
+                if (NPOS * NT == T::NPOSITIONS || tid + i * NT < T::NPOSITIONS) {  // partial last wave: exec-masked
+                    const unsigned vo = chan_ok ? (from_x1 ? ob1[i] : ob2[i]) : kOOB;
+                    lds_ptr_t d = (lds_ptr_t)(dstB + j * PS + i * NT);
+                    if (from_x1) lds_dma4(r1, d, vo, soff);
+                    else lds_dma4(r2, d, vo, soff);
+                }
             }
+        }
+        const unsigned soffA = (unsigned)chunk * (unsigned)(T::A_RUN * 4);  // K-steps of a chunk are contiguous
+        float* dstA = ldsA + buf * T::A_FLOATS + wave * 256;
+#pragma unroll
+        for (int v = 0; v < T::NAV; ++v) {
+            if (T::NAV * NT * 4 == T::A_FLOATS || (tid + v * NT) * 4 < T::A_FLOATS)  // whole waves by construction
+                lds_dma16(rw, (lds_ptr_t)(dstA + v * NT * 4), aoff[v], soffA);
         }
     };
 
-    // ---- B fragment addressing: lane (l&15) -> pixel q of the tile, (l>>4) -> channel in K-step
+    // ---- operand fragments: both from LDS at immediate offsets ------------------------------------
+    // MFMA roles are swapped w.r.t. the GEMM view: the 16 PIXELS are the row operand and the 16 OUT CHANNELS
+    // the column operand, so a lane's 4 accumulator registers are 4 consecutive pixels of ONE channel ->
+    // 16-byte stores in the epilogue.
     int boff[NR];
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
@@ -180,15 +198,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         q = min(q, T::NPIX - 1);
         boff[n] = (q / TW) * PW + (q % TW) + (lane >> 4) * PS;
     }
-
-    // ---- A fragment addressing ------------------------------------------------------------
-    const float* wa[MR];
-#pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        int cot = (blockIdx.y * WM + wm) * MR + m;
-        cot = min(cot, a.ncot - 1);
-        wa[m] = a.wp + (size_t)cot * a.nci4 * (TAPS * 64) + lane;
-    }
+    const int a_lane = (wm * MR) * T::A_RUN + lane;
 
     f32x4 acc[MR][NR];
 #pragma unroll
@@ -198,73 +208,61 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 
     const int c_begin = ks * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
-    const int ci4_end = c_end * KSTEPS;
 
-    float af[2][TAPS][MR];
-    auto load_a = [&](float(&dst)[TAPS][MR], int ci4) {
-#pragma unroll
-        for (int m = 0; m < MR; ++m)
-#pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) dst[tp][m] = wa[m][(size_t)(min(ci4, a.nci4 - 1) * TAPS + tp) * 64];
-    };
-
-    if (c_begin < c_end) {
-        stage_load(c_begin);
-        load_a(af[0], c_begin * KSTEPS);
-        stage_store(0, c_begin);
-    }
-    __syncthreads();
+    if (c_begin < c_end) stage(c_begin, 0);
+    __syncthreads();  // (hipcc drains the DMA with vmcnt(0) ahead of the barrier)
 
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        const int cn = min(c + 1, c_end - 1);  // the last iteration re-fetches its own chunk: no branch
-        stage_load(cn);
-        __builtin_amdgcn_sched_barrier(0);  // keep the patch loads ahead of the MFMA block (hipcc sinks them otherwise)
-        const float* bsrc = lds + buf * (CK * PS);
-
+        if (c + 1 < c_end) stage(c + 1, buf ^ 1);  // wave-uniform branch; the other buffer was released by the last barrier
+        const float* bsrc = lds + buf * T::B_FLOATS;
+        const float* asrc = ldsA + buf * T::A_FLOATS + a_lane;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int ci4 = c * KSTEPS + kk;
-            load_a(af[(kk + 1) & 1], min(ci4 + 1, ci4_end - 1));  // unconditional: the last prefetch is redundant
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp) {
                 const int ky = (TAPS == 9) ? tp / 3 : 0, kx = (TAPS == 9) ? tp % 3 : 0;
-                float bf[NR];
+                float pf[NR], wf[MR];
 #pragma unroll
-                for (int n = 0; n < NR; ++n) bf[n] = bsrc[boff[n] + kk * 4 * PS + ky * PW + kx];
+                for (int m = 0; m < MR; ++m) wf[m] = asrc[m * T::A_RUN + (kk * TAPS + tp) * 64];
+#pragma unroll
+                for (int n = 0; n < NR; ++n) pf[n] = bsrc[boff[n] + kk * 4 * PS + ky * PW + kx];
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
                     for (int n = 0; n < NR; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][tp][m], bf[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[n], wf[m], acc[m][n], 0, 0, 0);
             }
         }
-        stage_store(buf ^ 1, cn);
         __syncthreads();
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
+    // ---- epilogue: lane = (channel lane&15, pixel quad lane>>4) ----------------------------------------
     const bool final_out = (a.ksplit == 1);
     float* ybase = a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
+    const bool vec_ok = (W & 3) == 0;
 #pragma unroll
-    for (int n = 0; n < NR; ++n) {
-        const int q = (wn * NR + n) * 16 + (lane & 15);
-        const int oy = y0 + q / TW, ox = x0 + q % TW;
-        const bool pix_ok = q < T::NPIX && oy < H && ox < W;
+    for (int m = 0; m < MR; ++m) {
+        const int co = ((blockIdx.y * WM + wm) * MR + m) * 16 + (lane & 15);
+        const float bv = (final_out && a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const int co0 = ((blockIdx.y * WM + wm) * MR + m) * 16 + (lane >> 4) * 4;
+        for (int n = 0; n < NR; ++n) {
+            const int q = (wn * NR + n) * 16 + (lane >> 4) * 4;  // first of this lane's 4 consecutive pixels
+            const int oy = y0 + q / TW, ox = x0 + q % TW;
+            if (co >= a.Cout || q >= T::NPIX || oy >= H || ox >= W) continue;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + r;
-                if (pix_ok && co < a.Cout) {
-                    float v = acc[m][n][r];
-                    if (final_out) {
-                        if (a.bias) v += a.bias[co];
-                        v = act_apply(v, a.act, a.slope);
-                    }
-                    ybase[(size_t)co * plane2 + (size_t)oy * W + ox] = v;
-                }
+                v[r] = acc[m][n][r];
+                if (final_out) v[r] = act_apply(v[r] + bv, a.act, a.slope);
+            }
+            float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
+            if (vec_ok && ox + 3 < W) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ox + r < W) dst[r] = v[r];
             }
         }
     }
@@ -336,6 +334,8 @@ static const ConvCfg kCfgs[] = {
     WMD_CFG(8, 32, 4, 4, 1, 4, 16, 9),  // co64  x 256px, 16-channel chunks
     WMD_CFG(8, 32, 4, 8, 1, 2, 8, 9),   // co64  x 256px, 2 waves of 64x128
     WMD_CFG(8, 32, 2, 4, 1, 4, 8, 9),   // co32  x 256px
+    WMD_CFG(8, 32, 2, 4, 1, 4, 16, 9),  // co32  x 256px, 16-channel chunks
+    WMD_CFG(16, 32, 2, 8, 1, 4, 16, 9), // co32  x 512px, 16-channel chunks
     WMD_CFG(8, 32, 4, 4, 1, 4, 8, 9),   // co64  x 256px
     WMD_CFG(4, 32, 4, 4, 2, 2, 8, 9),   // co128 x 128px
     WMD_CFG(4, 32, 4, 2, 1, 4, 8, 9),   // co64  x 128px

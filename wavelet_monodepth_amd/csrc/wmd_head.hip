@@ -15,6 +15,7 @@
 //   * epilogue: sigmoid / scale / (sigma+ - sigma-) and a float4 store per channel straight into the
 //     [B,3,H,W] coefficient plane the IDWT reads.
 #include <algorithm>
+#include <cstdlib>
 #include "wmd_internal.h"
 
 namespace wmd {
@@ -32,12 +33,13 @@ template <int COUT>
 struct HeadSmem {
     float patch[2][H_CK * H_PS];
     float wgt[2][H_CK * COUT * 12];   // 9 taps padded to 12 per (ci, co): three aligned float4
+    float dump[64];                    // target of the unconditional stores of lanes past the end of a patch
 };
 
 template <int COUT, int NG>
 __device__ __forceinline__ void head_side(const float* __restrict__ x, size_t bstride, const float* __restrict__ wgt,
-                                          int C, int H, int W, int b, int y0, int x0, int pad_mode,
-                                          HeadSmem<COUT>& sm, float (&acc)[COUT][4]) {
+                                          int C, int c_begin, int c_end, int H, int W, int b, int y0, int x0,
+                                          int pad_mode, HeadSmem<COUT>& sm, float (&acc)[COUT][4]) {
     constexpr int H_NT = H_TT * NG;
     constexpr int H_NPOS = (H_PH * H_PWV + H_NT - 1) / H_NT;
     constexpr int CPG = H_CK / NG;  // channels per group and chunk
@@ -63,7 +65,7 @@ __device__ __forceinline__ void head_side(const float* __restrict__ x, size_t bs
         gx = min(max(gx, 0), W - 1);
         live[i] = ok;
         off[i] = gy * W + gx;
-        lpos[i] = py * H_PW + px;
+        lpos[i] = (tid + i * H_NT) < H_PH * H_PWV ? py * H_PW + px : -1;
     }
     // weights of a chunk: CK*COUT*9 values, thread t fetches elements t, t+128, ...
     constexpr int WN = H_CK * COUT * 9;
@@ -71,12 +73,12 @@ __device__ __forceinline__ void head_side(const float* __restrict__ x, size_t bs
 
     float sv[H_CK][H_NPOS];
     float wv[WPT];
-    const int nchunks = (C + H_CK - 1) / H_CK;
+    const int nchunks = (c_end - c_begin + H_CK - 1) / H_CK;  // this block's slice of the input channels
 
     auto stage_load = [&](int chunk) {
 #pragma unroll
         for (int j = 0; j < H_CK; ++j) {
-            const int ci = min(chunk * H_CK + j, C - 1);
+            const int ci = min(c_begin + chunk * H_CK + j, c_end - 1);
             const float* src = xb + (size_t)ci * plane;
 #pragma unroll
             for (int i = 0; i < H_NPOS; ++i) sv[j][i] = src[off[i]];
@@ -85,25 +87,27 @@ __device__ __forceinline__ void head_side(const float* __restrict__ x, size_t bs
         for (int k = 0; k < WPT; ++k) {
             const int e = min(tid + k * H_NT, WN - 1);
             const int t = e % 9, co = (e / 9) % COUT, j = e / (9 * COUT);
-            const int ci = min(chunk * H_CK + j, C - 1);
+            const int ci = min(c_begin + chunk * H_CK + j, c_end - 1);
             wv[k] = wgt[((size_t)co * C + ci) * 9 + t];
         }
     };
     auto stage_store = [&](int buf, int chunk) {
 #pragma unroll
         for (int j = 0; j < H_CK; ++j) {
-            const bool chan_ok = chunk * H_CK + j < C;
+            const bool chan_ok = c_begin + chunk * H_CK + j < c_end;
 #pragma unroll
-            for (int i = 0; i < H_NPOS; ++i)
-                if (tid + i * H_NT < H_PH * H_PWV) sm.patch[buf][j * H_PS + lpos[i]] = (live[i] && chan_ok) ? sv[j][i] : 0.f;
+            for (int i = 0; i < H_NPOS; ++i) {
+                float* q = lpos[i] >= 0 ? &sm.patch[buf][j * H_PS + lpos[i]] : &sm.dump[tid & 63];
+                *q = (live[i] && chan_ok) ? sv[j][i] : 0.f;
+            }
         }
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
             const int e = tid + k * H_NT;
-            if (e < WN) {
-                const int t = e % 9, co = (e / 9) % COUT, j = e / (9 * COUT);
-                sm.wgt[buf][(j * COUT + co) * 12 + t] = (chunk * H_CK + j < C) ? wv[k] : 0.f;
-            }
+            const int ec = min(e, WN - 1);
+            const int t = ec % 9, co = (ec / 9) % COUT, j = ec / (9 * COUT);
+            float* q = e < WN ? &sm.wgt[buf][(j * COUT + co) * 12 + t] : &sm.dump[tid & 63];
+            *q = (c_begin + chunk * H_CK + j < c_end) ? wv[k] : 0.f;
         }
     };
 
@@ -166,7 +170,8 @@ __device__ __forceinline__ void head_side(const float* __restrict__ x, size_t bs
 }
 
 template <int COUT, int NG>
-__global__ __launch_bounds__(H_TT* NG) void head3x3_kernel(const wmd_head_args a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(H_TT* NG) void head3x3_kernel(const wmd_head_args a, int tiles_x, int tiles_y, int csplit,
+                                                            int cper, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) HeadSmem<COUT> sm;
     int t = blockIdx.x;
     const int tx_ = t % tiles_x;
@@ -182,17 +187,35 @@ __global__ __launch_bounds__(H_TT* NG) void head3x3_kernel(const wmd_head_args a
     for (int co = 0; co < COUT; ++co)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool g0 = threadIdx.x < H_TT;  // the bias enters once, through group 0
+            // the bias enters once: through group 0 of an unsplit block, or in the finalize pass
+            const bool g0 = threadIdx.x < H_TT && csplit == 1;
             accp[co][q] = (g0 && a.bias_p) ? a.bias_p[co] : 0.f;
             accn[co][q] = (g0 && a.mode == 2 && a.bias_n) ? a.bias_n[co] : 0.f;
         }
     const size_t plane_ = (size_t)a.H * a.W;
-    head_side<COUT, NG>(a.xp, a.xp_bstride ? a.xp_bstride : a.C * plane_, a.wgt_p, a.C, a.H, a.W, b, y0, x0, a.pad_mode, sm, accp);
+    const int cs = blockIdx.y;
+    const int c_begin = cs * cper, c_end = min(a.C, c_begin + cper);
+    head_side<COUT, NG>(a.xp, a.xp_bstride ? a.xp_bstride : a.C * plane_, a.wgt_p, a.C, c_begin, c_end, a.H, a.W, b, y0,
+                        x0, a.pad_mode, sm, accp);
     if (a.mode == 2)
-        head_side<COUT, NG>(a.xn, a.xn_bstride ? a.xn_bstride : a.C * plane_, a.wgt_n, a.C, a.H, a.W, b, y0, x0, a.pad_mode, sm, accn);
+        head_side<COUT, NG>(a.xn, a.xn_bstride ? a.xn_bstride : a.C * plane_, a.wgt_n, a.C, c_begin, c_end, a.H, a.W, b,
+                            y0, x0, a.pad_mode, sm, accn);
 
     if (threadIdx.x >= H_TT || oy >= a.H || ox >= a.W) return;
     const size_t plane = (size_t)a.H * a.W;
+    if (csplit > 1) {
+        // raw partial sums [cs][b][side][co][H][W]; bias, sigmoid and the combine happen in head_finalize_kernel
+        float* pp = partial + (((size_t)cs * a.B + b) * 2 * COUT) * plane + (size_t)oy * a.W + ox;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ox + q < a.W) {
+                    pp[(size_t)co * plane + q] = accp[co][q];
+                    if (a.mode == 2) pp[(size_t)(COUT + co) * plane + q] = accn[co][q];
+                }
+        return;
+    }
     const size_t o = (size_t)b * COUT * plane + (size_t)oy * a.W + ox;
     const bool vec = (ox + 3 < a.W) && ((a.W & 3) == 0);
 #pragma unroll
@@ -230,9 +253,63 @@ __global__ __launch_bounds__(H_TT* NG) void head3x3_kernel(const wmd_head_args a
     }
 }
 
+// second stage of a channel-split head: sum the slices, add the bias, apply sigmoid / scale / (s+ - s-)
+__global__ void head_finalize_kernel(const wmd_head_args a, const float* __restrict__ partial, int csplit) {
+    const size_t plane = (size_t)a.H * a.W;
+    const size_t n = (size_t)a.B * a.Cout * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % plane;
+        const int co = (i / plane) % a.Cout;
+        const int b = i / (plane * a.Cout);
+        float p = a.bias_p ? a.bias_p[co] : 0.f, q = (a.mode == 2 && a.bias_n) ? a.bias_n[co] : 0.f;
+        for (int cs = 0; cs < csplit; ++cs) {
+            const float* pp = partial + (((size_t)cs * a.B + b) * 2 * a.Cout) * plane + pix;
+            p += pp[(size_t)co * plane];
+            if (a.mode == 2) q += pp[(size_t)(a.Cout + co) * plane];
+        }
+        float r;
+        if (a.mode == 0) {
+            r = a.scale * p;
+        } else {
+            const float sp = 1.f / (1.f + expf(-p));
+            if (a.sig_p) a.sig_p[i] = sp;
+            if (a.mode == 1) {
+                r = a.scale * sp;
+            } else {
+                const float sn = 1.f / (1.f + expf(-q));
+                if (a.sig_n) a.sig_n[i] = sn;
+                r = a.scale * sp - a.scale * sn;
+            }
+        }
+        a.y[i] = r;
+    }
+}
+
+static void head_plan(const wmd_head_args* g, int* tiles_x, int* tiles_y, int* csplit, int* cper) {
+    *tiles_x = (g->W + HT_W - 1) / HT_W;
+    *tiles_y = (g->H + HT_H - 1) / HT_H;
+    const long tiles = (long)g->B * *tiles_x * *tiles_y;
+    // few tiles (coarse pyramid levels, up to 256 channels each): slice the channel loop over blocks so that
+    // ~3 blocks per CU are in flight; a slice is at least two 8-channel chunks
+    int cs = (int)std::min<long>((3L * kNumCU + tiles - 1) / tiles, std::max(1, g->C / 16));
+    if (const char* e = getenv("WMD_HEAD_CSPLIT")) cs = std::max(1, atoi(e));
+    cs = std::max(1, std::min(cs, (g->C + H_CK - 1) / H_CK));
+    int per = (g->C + cs - 1) / cs;
+    per = ((per + H_CK - 1) / H_CK) * H_CK;
+    *cper = per;
+    *csplit = (g->C + per - 1) / per;
+}
+
 }  // namespace wmd
 
 using namespace wmd;
+
+extern "C" size_t wmd_head3x3_workspace_floats(const wmd_head_args* g) {
+    if (!g || g->B <= 0 || g->C <= 0 || g->Cout <= 0) return 0;
+    int tx, ty, cs, per;
+    head_plan(g, &tx, &ty, &cs, &per);
+    return cs > 1 ? (size_t)cs * g->B * 2 * g->Cout * g->H * g->W : 0;
+}
 
 extern "C" int wmd_head3x3_fwd(const wmd_head_args* g, void* stream) {
     if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_head3x3_fwd: null args");
@@ -245,16 +322,22 @@ extern "C" int wmd_head3x3_fwd(const wmd_head_args* g, void* stream) {
     if (g->pad_mode < 0 || g->pad_mode > 2) return fail(WMD_ERR_BAD_ARG, "wmd_head3x3_fwd: pad_mode=%d", g->pad_mode);
     if (g->pad_mode == WMD_PAD_REFLECT && (g->H < 2 || g->W < 2))
         return fail(WMD_ERR_BAD_SHAPE, "wmd_head3x3_fwd: reflect padding needs H,W >= 2");
-    const int tiles_x = (g->W + HT_W - 1) / HT_W, tiles_y = (g->H + HT_H - 1) / HT_H;
-    dim3 grid((unsigned)((size_t)g->B * tiles_x * tiles_y));
+    int tiles_x, tiles_y, csplit, cper;
+    head_plan(g, &tiles_x, &tiles_y, &csplit, &cper);
+    if (csplit > 1 && (!g->workspace || g->workspace_floats < (size_t)csplit * g->B * 2 * g->Cout * g->H * g->W)) {
+        csplit = 1;  // no (or too small a) workspace: run unsplit
+        cper = ((g->C + H_CK - 1) / H_CK) * H_CK;
+    }
+    dim3 grid((unsigned)((size_t)g->B * tiles_x * tiles_y), (unsigned)csplit);
     hipStream_t s = (hipStream_t)stream;
     const double pix = (double)g->B * g->H * g->W, sides = g->mode == 2 ? 2.0 : 1.0;
     ProfScope prof("head3x3_kernel", sides * 18.0 * g->C * g->Cout * pix, 4.0 * pix * (sides * g->C + g->Cout), s);
     // few tiles (coarse pyramid levels): 4 channel groups per tile; otherwise 2
-    const bool wide = (size_t)g->B * tiles_x * tiles_y < 2 * (size_t)kNumCU;
+    bool wide = (size_t)g->B * tiles_x * tiles_y * csplit < 2 * (size_t)kNumCU;
+    if (const char* e = getenv("WMD_HEAD_NG")) wide = atoi(e) == 4;
 #define WMD_HEAD_LAUNCH(CO)                                                                                   \
-    if (wide) hipLaunchKernelGGL((head3x3_kernel<CO, 4>), grid, dim3(H_TT * 4), 0, s, *g, tiles_x, tiles_y); \
-    else hipLaunchKernelGGL((head3x3_kernel<CO, 2>), grid, dim3(H_TT * 2), 0, s, *g, tiles_x, tiles_y)
+    if (wide) hipLaunchKernelGGL((head3x3_kernel<CO, 4>), grid, dim3(H_TT * 4), 0, s, *g, tiles_x, tiles_y, csplit, cper, g->workspace); \
+    else hipLaunchKernelGGL((head3x3_kernel<CO, 2>), grid, dim3(H_TT * 2), 0, s, *g, tiles_x, tiles_y, csplit, cper, g->workspace)
     switch (g->Cout) {
         case 1: WMD_HEAD_LAUNCH(1); break;
         case 2: WMD_HEAD_LAUNCH(2); break;
@@ -262,5 +345,10 @@ extern "C" int wmd_head3x3_fwd(const wmd_head_args* g, void* stream) {
         default: WMD_HEAD_LAUNCH(4); break;
     }
 #undef WMD_HEAD_LAUNCH
-    return check_launch("head3x3_kernel");
+    int st = check_launch("head3x3_kernel");
+    if (st || csplit == 1) return st;
+    const size_t n = (size_t)g->B * g->Cout * g->H * g->W;
+    hipLaunchKernelGGL(head_finalize_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, *g,
+                       g->workspace, csplit);
+    return check_launch("head_finalize_kernel");
 }

@@ -188,8 +188,16 @@ def _head_raw(xp, wp_, bp, xn, wn, bn, pad, mode, scale, save_sig):
     a = _lib.HeadArgs(B=B, H=H, W=W, C=Cc, Cout=cout, pad_mode=PAD[pad], mode=mode, scale=float(scale),
                       xp=ptr(xp), wgt_p=ptr(wp_), bias_p=ptr(bp), xn=ptr(xn), wgt_n=ptr(wn), bias_n=ptr(bn),
                       y=ptr(y), sig_p=ptr(sp), sig_n=ptr(sn))
-    check(l.wmd_head3x3_fwd(C.byref(a), current_stream()), "wmd_head3x3_fwd")
+    _head_launch(l, a, xp.device)
     return y, sp, sn
+
+
+def _head_launch(l, a, device):
+    n = l.wmd_head3x3_workspace_floats(C.byref(a))
+    if n:
+        ws = torch.empty(n, device=device, dtype=torch.float32)
+        a.workspace, a.workspace_floats = ptr(ws), n
+    check(l.wmd_head3x3_fwd(C.byref(a), current_stream()), "wmd_head3x3_fwd")
 
 
 class _HeadFn(torch.autograd.Function):
@@ -316,7 +324,7 @@ def head3x3_nograd(x_full, cin, off_p, weight_p, bias_p, off_n=None, weight_n=No
                       xn=None if off_n is None else base + 4 * off_n * plane,
                       wgt_n=None if weight_n is None else ptr(_c(weight_n.detach())), bias_n=ptr(bias_n),
                       y=ptr(y), sig_p=None, sig_n=None, xp_bstride=Ctot * plane, xn_bstride=Ctot * plane)
-    check(l.wmd_head3x3_fwd(C.byref(a), current_stream()), "wmd_head3x3_fwd")
+    _head_launch(l, a, x_full.device)
     return y
 
 
