@@ -148,6 +148,8 @@ typedef struct {
     float* dx2;         /* [B,C2,H,W] or NULL                                           */
     float* workspace;   /* needs wmd_conv_dgrad_workspace_floats                        */
     size_t workspace_floats;
+    int tune_cfg;       /* as in wmd_conv_args: 0 = cost model, k > 0 forces configuration k-1 */
+    int tune_ksplit;
 } wmd_conv_dgrad_args;
 
 size_t wmd_conv_dgrad_workspace_floats(const wmd_conv_dgrad_args* args);

@@ -1,0 +1,44 @@
+"""Per-kernel time of one decoder training step (fwd + bwd) on synthetic config-2/3 shapes (development aid)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from wavelet_monodepth_amd import _lib, synth
+from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--chans", default="64,64,128,256,512")
+ap.add_argument("--height", type=int, default=192)
+ap.add_argument("--width", type=int, default=640)
+ap.add_argument("--batch", type=int, default=12)
+args = ap.parse_args()
+chans = [int(c) for c in args.chans.split(",")]
+dev = torch.device("cuda:0")
+dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
+feats = [torch.from_numpy(f).to(dev).requires_grad_(True) for f in synth.encoder_features(args.batch, args.height, args.width, chans, seed=1)]
+
+
+def step():
+    out = dec(feats)
+    loss = sum(out[("disp", s)].mean() for s in range(4))
+    loss.backward()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+_lib.profile_begin()
+n = 5
+for _ in range(n):
+    step()
+recs = _lib.profile_end()
+tot = sum(r["ms"] for r in recs) / n
+print("decoder fwd+bwd: %.3f ms of library kernels per step (batch %d, %dx%d)" % (tot, args.batch, args.width, args.height))
+for r in sorted(recs, key=lambda r: -r["ms"]):
+    print("  %-44s calls/step %3d  %8.3f ms/step  %6.1f TFLOP/s" % (r["kernel"], r["calls"] // n, r["ms"] / n,
+                                                                   r["flops"] / max(r["ms"], 1e-9) / 1e9))

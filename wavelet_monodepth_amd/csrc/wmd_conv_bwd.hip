@@ -9,7 +9,7 @@
 //             with M = co, N = (ci,tap), K = pixels; every block owns a (co-tile, ci-tile) pair and a slice
 //             of the pixel tiles, accumulates in registers and writes ONE partial; a second kernel sums the
 //             partials (deterministic two-stage reduction, no atomics).
-//   dbias:    per-channel sum of dz (conv_bias_grad_kernel).
+//   dbias:    row sums of the dz tiles the wgrad blocks already hold in LDS, reduced with the weight partials.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -77,40 +77,53 @@ __global__ void conv_dgrad_fold_kernel(const float* __restrict__ g, float* __res
 // ------------------------------------------------------------------------------------------------
 // wgrad
 // ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void wg_dma4(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 4, voff, soff, 0, 0);
+}
+
 struct WgradKArgs {
     const float* x1;
     const float* x2;
     const float* dz;
-    float* partial;  // [nsplit][Cout][Cin][taps]
+    float* partial;  // [nsplit][Cout*Cin*taps + Cout]  (weights, then the bias partial sums)
     int B, H, W, H1, W1, C1, C2, Cin, Cout, up1, pad_mode;
     int tiles_x, tiles_y, ntiles;  // pixel tiles per image / total (B * tiles_x * tiles_y)
     int nsplit;
+    int want_bias;
 };
 
-// Block = WM x WN waves. Wave (wm, wn) owns MR out-channel tiles (16 each) x one 16-input-channel group x TAPS.
+// Block = WM x WN waves. Wave (wm, wn) owns MR out-channel tiles (16 each) x NC 16-input-channel groups x TAPS.
 // Pixel tile = TH x TW (TW % 4 == 0): the MFMA K index walks 4 consecutive pixels of a row.
-template <int TH, int TW, int MR, int WM, int WN, int TAPS>
+// Both operand tiles are gathered by LDS-DMA (position-linear rows), double buffered across pixel tiles.
+template <int TH, int TW, int MR, int NC, int WM, int WN, int TAPS>
 struct WgradTile {
     static constexpr int NT = WM * WN * 64;
     static constexpr int HALO = TAPS == 9 ? 1 : 0;
     static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
     static constexpr int NPIX = TH * TW;
-    static constexpr int COT = WM * MR * 16;   // out channels per block
-    static constexpr int CIT = WN * 16;        // in channels per block
-    // strides == 2 (mod 32): lanes (i = l&15, k = l>>4) of a 32-lane group hit banks 2i + k, all distinct
-    static constexpr int SA = ((NPIX - 2 + 31) / 32) * 32 + 2;
-    static constexpr int SB = ((PH * PW - 2 + 31) / 32) * 32 + 2;
-    static constexpr int LDS_FLOATS = COT * SA + CIT * SB;
+    static constexpr int NPATCH = PH * PW;
+    static constexpr int COT = WM * MR * 16;        // out channels per block
+    static constexpr int CIT = WN * NC * 16;        // in channels per block
+    // row strides: >= the DMA span (whole 64-lane pieces) and == 2 (mod 32) so that lanes (i = l&15, k = l>>4) of a
+    // 32-lane ds_read_b32 group hit banks 2i + k, all distinct
+    static constexpr int SPAN_A = ((NPIX + 63) / 64) * 64;
+    static constexpr int SPAN_B = ((NPATCH + 63) / 64) * 64;
+    static constexpr int SA = ((SPAN_A - 2 + 31) / 32) * 32 + 2;
+    static constexpr int SB = ((SPAN_B - 2 + 31) / 32) * 32 + 2;
+    static constexpr int BUF = COT * SA + CIT * SB;
+    static constexpr int LDS_FLOATS = 2 * BUF;
+    static constexpr int PA = SPAN_A / 64, PB = SPAN_B / 64;   // 64-lane DMA pieces per row
     static_assert(TW % 4 == 0, "pixel quads must not straddle rows");
 };
 
-template <int TH, int TW, int MR, int WM, int WN, int TAPS>
+template <int TH, int TW, int MR, int NC, int WM, int WN, int TAPS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const WgradKArgs a) {
-    using T = WgradTile<TH, TW, MR, WM, WN, TAPS>;
-    constexpr int NT = T::NT, HALO = T::HALO, PW = T::PW, SA = T::SA, SB = T::SB, NPIX = T::NPIX;
-    __shared__ float lds[T::LDS_FLOATS];
-    float* ldsA = lds;                 // dz tile   [COT][SA]
-    float* ldsB = lds + T::COT * SA;   // x patch   [CIT][SB]
+    using T = WgradTile<TH, TW, MR, NC, WM, WN, TAPS>;
+    constexpr int HALO = T::HALO, PW = T::PW, SA = T::SA, SB = T::SB, NPIX = T::NPIX;
+    constexpr int NWAVES = WM * WN;
+    constexpr unsigned kOOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,60 +132,89 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const WgradKArg
     const int split = blockIdx.z;
     const int H = a.H, W = a.W;
     const size_t plane = (size_t)H * W, plane1 = (size_t)a.H1 * a.W1;
+    const unsigned pbz = (unsigned)(plane * 4), pb1 = (unsigned)(plane1 * 4);
 
-    f32x4 acc[MR][TAPS];
+    f32x4 acc[MR][NC][TAPS];
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[m][n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;  // bias partial: thread c < COT sums row c of the dz tiles (ci-tile 0 blocks only)
 
-    // this split's share of the pixel tiles
     const int per = (a.ntiles + a.nsplit - 1) / a.nsplit;
     const int t_begin = split * per, t_end = min(t_begin + per, a.ntiles);
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // DMA of one pixel tile into buffer `buf`: rows of dz (out channels) and of the gathered input patch.
+    // Rows are handed round-robin to the waves; a row is PA (PB) pieces of 64 consecutive positions.
+    auto stage = [&](int tile, int buf) {
         int t = tile;
         const int tx = t % a.tiles_x;
         t /= a.tiles_x;
         const int ty = t % a.tiles_y;
         const int b = t / a.tiles_y;
         const int y0 = ty * TH, x0 = tx * TW;
-
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage dz tile: rows = out channels, NPIX pixels (zero outside the image / channel range)
-        for (int e = tid; e < T::COT * NPIX; e += NT) {
-            const int c = e / NPIX, p = e % NPIX;
+        float* bufA = lds + buf * T::BUF;
+        float* bufB = bufA + T::COT * SA;
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.dz + (size_t)b * a.Cout * plane), 0, (int)(a.Cout * plane * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x1 + (size_t)b * a.C1 * plane1), 0, (int)(a.C1 * plane1 * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x2 ? a.x2 + (size_t)b * a.C2 * plane : a.x1), 0, (int)(a.C2 * plane * 4), 0x00020000);
+        // per-lane byte offsets inside a channel plane for the PA / PB pieces of a row (same for every row)
+        unsigned oz[T::PA], o1[T::PB], o2[T::PB];
+#pragma unroll
+        for (int i = 0; i < T::PA; ++i) {
+            const int p = i * 64 + lane;
             const int oy = y0 + p / TW, ox = x0 + p % TW;
-            const int co = co0 + c;
-            float v = 0.f;
-            if (co < a.Cout && oy < H && ox < W) v = a.dz[((size_t)b * a.Cout + co) * plane + (size_t)oy * W + ox];
-            ldsA[c * SA + p] = v;
+            oz[i] = (p < NPIX && oy < H && ox < W) ? (unsigned)(oy * W + ox) * 4u : kOOB;
         }
-        // ---- stage the input patch of CIT channels through the pad/upsample/concat gather
-        for (int e = tid; e < T::CIT * T::PH * PW; e += NT) {
-            const int c = e / (T::PH * PW), p = e % (T::PH * PW);
+#pragma unroll
+        for (int i = 0; i < T::PB; ++i) {
+            const int p = i * 64 + lane;
             int gy = y0 + p / PW - HALO, gx = x0 + p % PW - HALO;
-            const int ci = ci0 + c;
-            bool ok = ci < a.Cin;
+            bool ok = p < T::NPATCH;
             if (HALO) {
                 ok = pad_coord(gy, H, a.pad_mode) && ok;
                 ok = pad_coord(gx, W, a.pad_mode) && ok;
             }
             ok = ok && gy >= 0 && gx >= 0 && gy < H && gx < W;
-            float v = 0.f;
-            if (ok) {
-                if (ci < a.C1)
-                    v = a.x1[((size_t)b * a.C1 + ci) * plane1 + (size_t)(gy / a.up1) * a.W1 + gx / a.up1];
-                else
-                    v = a.x2[((size_t)b * a.C2 + (ci - a.C1)) * plane + (size_t)gy * W + gx];
-            }
-            ldsB[c * SB + p] = v;
+            gy = min(max(gy, 0), H - 1);
+            gx = min(max(gx, 0), W - 1);
+            o2[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
+            o1[i] = ok ? (unsigned)((gy / a.up1) * a.W1 + gx / a.up1) * 4u : kOOB;
         }
-        __syncthreads();
+        for (int c = wave; c < T::COT; c += NWAVES) {       // wave-uniform rows
+            const int co = co0 + c;
+            const unsigned so = (unsigned)min(co, a.Cout - 1) * pbz;
+#pragma unroll
+            for (int i = 0; i < T::PA; ++i) wg_dma4(rz, (lds_ptr_t)(bufA + c * SA + i * 64), co < a.Cout ? oz[i] : kOOB, so);
+        }
+        for (int c = wave; c < T::CIT; c += NWAVES) {
+            const int ci = ci0 + c;
+            const bool from1 = ci < a.C1;
+            const unsigned so = from1 ? (unsigned)ci * pb1 : (unsigned)min(max(ci - a.C1, 0), max(a.C2 - 1, 0)) * pbz;
+#pragma unroll
+            for (int i = 0; i < T::PB; ++i) {
+                const unsigned vo = ci < a.Cin ? (from1 ? o1[i] : o2[i]) : kOOB;
+                if (from1) wg_dma4(r1, (lds_ptr_t)(bufB + c * SB + i * 64), vo, so);
+                else wg_dma4(r2, (lds_ptr_t)(bufB + c * SB + i * 64), vo, so);
+            }
+        }
+    };
 
-        // ---- MFMA over the tile's pixels: K-step = 4 consecutive pixels of one row
+    if (t_begin < t_end) stage(t_begin, 0);
+    __syncthreads();
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int buf = (tile - t_begin) & 1;
+        if (tile + 1 < t_end) stage(tile + 1, buf ^ 1);
+        const float* ldsA = lds + buf * T::BUF;
+        const float* ldsB = ldsA + T::COT * SA;
         const float* pa = ldsA + (wm * MR * 16 + (lane & 15)) * SA + (lane >> 4);
-        const float* pb = ldsB + (wn * 16 + (lane & 15)) * SB + (lane >> 4);
+        const float* pb = ldsB + (wn * NC * 16 + (lane & 15)) * SB + (lane >> 4);
 #pragma unroll 2
         for (int q = 0; q < NPIX; q += 4) {
             const int py = q / TW, px = q % TW;
@@ -180,77 +222,92 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const WgradKArg
 #pragma unroll
             for (int m = 0; m < MR; ++m) af[m] = pa[m * 16 * SA + q];
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
-                const float bf = pb[(py + ky) * PW + px + kx];
+            for (int n = 0; n < NC; ++n)
 #pragma unroll
-                for (int m = 0; m < MR; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf, acc[m][t], 0, 0, 0);
-            }
+                for (int t = 0; t < TAPS; ++t) {
+                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                    const float bf = pb[n * 16 * SB + (py + ky) * PW + px + kx];
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+                        acc[m][n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf, acc[m][n][t], 0, 0, 0);
+                }
         }
+        if (a.want_bias && blockIdx.x == 0 && tid < T::COT) {
+            const float* row = ldsA + tid * SA;
+            float s = 0.f;
+            for (int p = 0; p < NPIX; ++p) s += row[p];
+            bsum += s;
+        }
+        __syncthreads();
     }
 
     // ---- write this block's partial: D row = out channel (lane>>4)*4+r, D col = input channel lane&15
-    float* out = a.partial + (size_t)split * a.Cout * a.Cin * TAPS;
-    const int ci = ci0 + wn * 16 + (lane & 15);
+    const size_t nw = (size_t)a.Cout * a.Cin * TAPS;
+    float* out = a.partial + (size_t)split * (nw + a.Cout);
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+    for (int n = 0; n < NC; ++n) {
+        const int ci = ci0 + (wn * NC + n) * 16 + (lane & 15);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + (wm * MR + m) * 16 + (lane >> 4) * 4 + r;
-            if (co < a.Cout && ci < a.Cin) {
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) out[((size_t)co * a.Cin + ci) * TAPS + t] = acc[m][t][r];
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wm * MR + m) * 16 + (lane >> 4) * 4 + r;
+                if (co < a.Cout && ci < a.Cin) {
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) out[((size_t)co * a.Cin + ci) * TAPS + t] = acc[m][n][t][r];
+                }
             }
-        }
+    }
+    if (a.want_bias && blockIdx.x == 0 && tid < T::COT && co0 + tid < a.Cout) out[nw + co0 + tid] = bsum;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t n, int nsplit) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int s = 0; s < nsplit; ++s) v += partial[(size_t)s * n + i];
-        dw[i] = v;
-    }
-}
-
-// one block per output channel: db[co] = sum_{b,y,x} dz[b,co,y,x]
-__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ db,
-                                                              int B, int Cout, size_t plane) {
-    const int co = blockIdx.x;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* p = dz + ((size_t)b * Cout + co) * plane;
-        for (size_t i = threadIdx.x; i < plane; i += 256) s += p[i];
-    }
-    __shared__ float red[256];
-    red[threadIdx.x] = s;
+// dw[i] (and db) = sum over the split partials.  Block = 64 outputs x 16 split groups; the groups are combined
+// through LDS, so even a 1024-element weight with hundreds of partials is a handful of dependent loads per thread.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                            float* __restrict__ db, size_t nw, int Cout, int nsplit) {
+    __shared__ float red[16][64];
+    const int w = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t n = nw + Cout;
+    const size_t i = (size_t)blockIdx.x * 64 + w;
+    float v = 0.f;
+    if (i < n)
+        for (int s = g; s < nsplit; s += 16) v += partial[(size_t)s * n + i];
+    red[g][w] = v;
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-        __syncthreads();
+    if (g == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][w];
+        if (i < nw) dw[i] = t;
+        else if (db) db[i - nw] = t;
     }
-    if (threadIdx.x == 0) db[co] = red[0];
 }
 
 struct WgradCfg {
-    int TH, TW, MR, WM, WN, TAPS;
+    int TH, TW, MR, NC, WM, WN, TAPS;
     void (*launch)(const WgradKArgs&, dim3, hipStream_t);
     const char* name;
 };
 
-template <int TH, int TW, int MR, int WM, int WN, int TAPS>
+template <int TH, int TW, int MR, int NC, int WM, int WN, int TAPS>
 static void launch_wgrad(const WgradKArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TH, TW, MR, WM, WN, TAPS>), grid, dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<TH, TW, MR, NC, WM, WN, TAPS>), grid, dim3(WM * WN * 64), 0, s, a);
 }
-#define WMD_WCFG(TH, TW, MR, WM, WN, TAPS) \
-    WgradCfg { TH, TW, MR, WM, WN, TAPS, &launch_wgrad<TH, TW, MR, WM, WN, TAPS>, "conv_wgrad_kernel<" #TH "," #TW "," #MR "," #WM "," #WN "," #TAPS ">" }
+#define WMD_WCFG(TH, TW, MR, NC, WM, WN, TAPS)                                       \
+    WgradCfg {                                                                       \
+        TH, TW, MR, NC, WM, WN, TAPS, &launch_wgrad<TH, TW, MR, NC, WM, WN, TAPS>,   \
+            "conv_wgrad_kernel<" #TH "," #TW "," #MR "," #NC "," #WM "," #WN "," #TAPS ">" \
+    }
 
 static const WgradCfg kWCfgs[] = {
-    WMD_WCFG(4, 32, 1, 4, 1, 9),  // co64 x ci16
-    WMD_WCFG(4, 32, 1, 2, 2, 9),  // co32 x ci32
-    WMD_WCFG(4, 20, 1, 4, 1, 9),  // 20-wide rows (coarsest 640-wide level, NYUv2 15x20)
-    WMD_WCFG(4, 20, 1, 2, 2, 9),
-    WMD_WCFG(1, 256, 1, 4, 1, 1),  // 1x1: co64 x ci16 over 256 flattened pixels
-    WMD_WCFG(1, 256, 1, 2, 2, 1),  // 1x1: co32 x ci32
+    WMD_WCFG(2, 32, 1, 1, 4, 1, 9),   // co64 x ci16, 64-pixel tiles
+    WMD_WCFG(2, 32, 1, 1, 2, 2, 9),   // co32 x ci32
+    WMD_WCFG(2, 40, 1, 1, 4, 1, 9),   // 40-wide rows
+    WMD_WCFG(2, 40, 1, 1, 2, 2, 9),
+    WMD_WCFG(2, 20, 1, 1, 4, 1, 9),   // 20-wide rows (coarsest 640-wide level, NYUv2 15x20)
+    WMD_WCFG(2, 20, 1, 1, 2, 2, 9),
+    WMD_WCFG(1, 64, 1, 4, 4, 1, 1),   // 1x1: co64 x ci64 over 64 flattened pixels
+    WMD_WCFG(1, 64, 1, 2, 2, 2, 1),   // 1x1: co32 x ci64
 };
 constexpr int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
 
@@ -271,12 +328,15 @@ static bool plan_wgrad(const wmd_conv_wgrad_args* g, WgradPlan* p) {
         if (c.TAPS != taps) continue;
         const int TH = c.TH, TW = c.TW;
         const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
-        const int cot = c.WM * c.MR * 16, cit = c.WN * 16;
+        const int cot = c.WM * c.MR * 16, cit = c.WN * c.NC * 16;
         const int gx = (Cin + cit - 1) / cit, gy = (g->Cout + cot - 1) / cot;
         const long ntiles = (long)g->B * tx * ty;
         // padded MACs: every block sweeps all pixel tiles of its split
         const double waste = ((double)gx * cit / Cin) * ((double)gy * cot / g->Cout) * ((double)tx * TW * ty * TH / ((double)H * W));
-        int nsplit = (int)std::min<long>(ntiles, std::max<long>(1, (3L * kNumCU + (long)gx * gy - 1) / ((long)gx * gy)));
+        // ~2 blocks per CU in flight, at least 4 pixel tiles per block (prologue amortisation), at most 256 partials
+        long nsplit = std::max<long>(1, (2L * kNumCU + (long)gx * gy - 1) / ((long)gx * gy));
+        nsplit = std::min<long>(nsplit, std::max<long>(1, ntiles / 4));
+        nsplit = std::min<long>(nsplit, 256);
         const double rounds = std::ceil((double)gx * gy * nsplit / (2.0 * kNumCU));
         const double cost = waste * rounds * 2.0 * kNumCU / ((double)gx * gy * nsplit);
         if (cost < best) {
@@ -288,7 +348,7 @@ static bool plan_wgrad(const wmd_conv_wgrad_args* g, WgradPlan* p) {
             p->tiles_x = tx;
             p->tiles_y = ty;
             p->ntiles = (int)ntiles;
-            p->nsplit = nsplit;
+            p->nsplit = (int)nsplit;
             p->grid = dim3((unsigned)gx, (unsigned)gy, (unsigned)nsplit);
         }
     }
@@ -332,6 +392,8 @@ static void dgrad_conv_args(const wmd_conv_dgrad_args* g, wmd_conv_args* c, floa
     c->y = gbuf;
     c->workspace = ws;
     c->workspace_floats = ws_floats;
+    c->tune_cfg = g->tune_cfg;
+    c->tune_ksplit = g->tune_ksplit;
 }
 
 static bool dgrad_direct(const wmd_conv_dgrad_args* g) {
@@ -380,7 +442,7 @@ extern "C" size_t wmd_conv_wgrad_workspace_floats(const wmd_conv_wgrad_args* g) 
     WgradPlan p;
     if (!plan_wgrad(g, &p)) return 0;
     const int taps = g->ksize == 3 ? 9 : 1;
-    return (size_t)p.nsplit * g->Cout * (g->C1 + g->C2) * taps;
+    return (size_t)p.nsplit * ((size_t)g->Cout * (g->C1 + g->C2) * taps + g->Cout);
 }
 
 extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
@@ -395,8 +457,8 @@ extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
     const int taps = g->ksize == 3 ? 9 : 1;
     const int Cin = g->C1 + g->C2;
     const size_t nw = (size_t)g->Cout * Cin * taps;
-    if (!g->workspace || g->workspace_floats < nw * p.nsplit)
-        return fail(WMD_ERR_WORKSPACE, "wmd_conv_wgrad: workspace %zu < %zu floats", g->workspace_floats, nw * p.nsplit);
+    if (!g->workspace || g->workspace_floats < (nw + g->Cout) * p.nsplit)
+        return fail(WMD_ERR_WORKSPACE, "wmd_conv_wgrad: workspace %zu < %zu floats", g->workspace_floats, (nw + g->Cout) * p.nsplit);
     WgradKArgs a;
     a.x1 = g->x1;
     a.x2 = g->x2;
@@ -417,6 +479,7 @@ extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
     a.tiles_y = p.tiles_y;
     a.ntiles = p.ntiles;
     a.nsplit = p.nsplit;
+    a.want_bias = g->dbias != nullptr;
     hipStream_t s = (hipStream_t)stream;
     const double pix = (double)g->B * g->H * g->W;
     {
@@ -427,16 +490,10 @@ extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
     if (st) return st;
     {
         ProfScope prof("wgrad_reduce_kernel", (double)nw * p.nsplit, 4.0 * nw * (p.nsplit + 1), s);
-        const int blocks = (int)std::min<size_t>((nw + 255) / 256, (size_t)kNumCU * 8);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, g->workspace, g->dw, nw, p.nsplit);
+        const int blocks = (int)((nw + g->Cout + 63) / 64);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(1024), 0, s, g->workspace, g->dw, g->dbias, nw, g->Cout,
+                           p.nsplit);
     }
     st = check_launch("wgrad_reduce_kernel");
-    if (st) return st;
-    if (g->dbias) {
-        ProfScope prof("conv_bias_grad_kernel", pix * g->Cout, 4.0 * pix * g->Cout, s);
-        hipLaunchKernelGGL(conv_bias_grad_kernel, dim3(g->Cout), dim3(256), 0, s, g->dz, g->dbias, g->B, g->Cout,
-                           (size_t)g->H * g->W);
-        st = check_launch("conv_bias_grad_kernel");
-    }
     return st;
 }

@@ -91,7 +91,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1):
         n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
         if n:
             ws = torch.empty(n, device=x1.device, dtype=torch.float32)
-            keep.append(ws)
+            keep[:] = [ws]   # same-stream reuse: the caching allocator may hand the block to the next candidate
             a.workspace, a.workspace_floats = ptr(ws), n
         elif ks > 1:
             return -3
@@ -106,7 +106,6 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1):
                 choice = (0, 0)  # cannot time inside a capture: the library's cost model decides
             else:
                 choice = tuner.tune(key, 9 if ksize == 3 else 1, launch)
-                keep.clear()
     check(launch(*choice), "wmd_conv_fwd")
     return y
 
@@ -146,11 +145,8 @@ class _ConvFn(torch.autograd.Function):
             dx2 = torch.empty_like(x2) if need_x2 else None
             a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
                                    dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=ptr(dx2), workspace=None,
-                                   workspace_floats=0)
-            n = l.wmd_conv_dgrad_workspace_floats(C.byref(a))
-            ws = torch.empty(max(n, 1), device=dy.device, dtype=torch.float32)
-            a.workspace, a.workspace_floats = ptr(ws), n
-            check(l.wmd_conv_dgrad(C.byref(a), s), "wmd_conv_dgrad")
+                                   workspace_floats=0, tune_cfg=0, tune_ksplit=0)
+            _dgrad_launch(a, dy.device, 9 if ksize == 3 else 1)
         if need_w or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw = torch.empty_like(weight)
             db = torch.empty(cout, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
@@ -233,6 +229,32 @@ class _HeadFn(torch.autograd.Function):
         return tuple(outs)
 
 
+def _dgrad_launch(a, device, taps):
+    """wmd_conv_dgrad with the (tile, split-K) choice autotuned per problem signature, like the forward."""
+    l = _lib.lib()
+    stream = current_stream()
+    keep = []
+
+    def launch(cfg, ks):
+        a.tune_cfg, a.tune_ksplit = cfg, ks
+        n = l.wmd_conv_dgrad_workspace_floats(C.byref(a))
+        ws = torch.empty(max(n, 1), device=device, dtype=torch.float32)
+        keep[:] = [ws]
+        a.workspace, a.workspace_floats = ptr(ws), n
+        return l.wmd_conv_dgrad(C.byref(a), stream)
+
+    choice = (0, 0)
+    if tuner.enabled:
+        key = "dgrad|%d|%d|%d|%d|%d|%d|%d|%d|%d" % (a.B, a.H, a.W, a.C1, a.up1, a.C2, a.Cout, a.ksize, int(bool(a.dx1)) + 2 * int(bool(a.dx2)))
+        choice = tuner.lookup(key)
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                choice = (0, 0)
+            else:
+                choice = tuner.tune(key, taps, launch)
+    check(launch(*choice), "wmd_conv_dgrad")
+
+
 def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, need_w):
     """dgrad + wgrad through the C ABI for an already-differentiated pre-activation gradient dz."""
     l = _lib.lib()
@@ -246,11 +268,9 @@ def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, ne
         wpd = pack_weights(weight, dgrad=True)
         dx1 = torch.empty_like(x1)
         a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
-                               dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=None, workspace=None, workspace_floats=0)
-        n = l.wmd_conv_dgrad_workspace_floats(C.byref(a))
-        ws = torch.empty(max(n, 1), device=dz.device, dtype=torch.float32)
-        a.workspace, a.workspace_floats = ptr(ws), n
-        check(l.wmd_conv_dgrad(C.byref(a), s), "wmd_conv_dgrad")
+                               dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=None, workspace=None, workspace_floats=0,
+                               tune_cfg=0, tune_ksplit=0)
+        _dgrad_launch(a, dz.device, 9 if ksize == 3 else 1)
     if need_w:
         dw = torch.empty_like(weight)
         db = torch.empty(cout, device=dz.device, dtype=torch.float32) if has_bias else None
