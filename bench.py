@@ -169,8 +169,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from wavelet_monodepth_amd import _lib
+    from wavelet_monodepth_amd import _lib, tuner
     _lib.lib()  # fail loudly if the HIP library is missing
+    # tile/split-K choices measured for this workload in an earlier run (any missing key is tuned in the warm-up)
+    tuner.preload(os.path.join(ROOT, "profiles", "r01_tune_cache_config2.json"))
 
     if args.workload == "train":
         train_main(args, rank, local_rank, world, dev)
@@ -216,8 +218,15 @@ def main():
         conv_ms = sum(r["ms"] for r in convs)
         conv_fl = sum(r["flops"] for r in convs)
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same kernel only
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(dom["kernel"], {}).get("traffic_bytes_per_launch")
+        except OSError:
+            pass
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": None,
+                "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],
                 "kernel": dom["kernel"], "launches_per_step": dom["calls"] // args.steps,
                 "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
                 "flop_per_launch": dom["flops"] / dom["calls"],

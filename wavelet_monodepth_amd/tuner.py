@@ -35,15 +35,40 @@ def _save():
             json.dump({k: list(v) for k, v in _cache.items()}, f, indent=0)
 
 
+def preload(path):
+    """Merge a committed cache file (read-only: nothing is written back to it)."""
+    if os.path.exists(path):
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                _cache.setdefault(k, tuple(v))
+
+
 def config_names():
     from . import _lib
     l = _lib.lib()
     return [l.wmd_conv_config_name(i).decode() for i in range(l.wmd_conv_num_configs())]
 
 
+_names = None
+
+
+def _index_of(name):
+    global _names
+    if _names is None:
+        _names = config_names()
+    return _names.index(name) + 1 if name in _names else None
+
+
 def lookup(key):
+    """-> (cfg1, ksplit) or None.  The cache stores configuration NAMES, so it survives edits of the table."""
     _load()
-    return _cache.get(key)
+    hit = _cache.get(key)
+    if hit is None:
+        return None
+    if hit[0] == "":
+        return (0, hit[1])
+    idx = _index_of(hit[0])
+    return None if idx is None else (idx, hit[1])
 
 
 def _time(launch, cfg, ks, reps, e0, e1):
@@ -76,12 +101,12 @@ def tune(key, taps, launch):
             if ks == 1 and t > 4.0 * best_t:
                 break  # hopeless tile shape for this problem: do not sweep its splits
     if not results:
-        _cache[key] = (0, 0)
+        _cache[key] = ("", 0)
         return (0, 0)
     results.sort()
     final = sorted((_time(launch, cfg, ks, 6, e0, e1), cfg, ks) for _, cfg, ks in results[:5])
     t, cfg, ks = final[0]
-    _cache[key] = (cfg, ks)
+    _cache[key] = (names[cfg - 1], ks)
     _save()
     if os.environ.get("WMD_TUNE_VERBOSE"):
         print("[wmd tuner] %s -> %s ksplit %d (%.1f us)" % (key, names[cfg - 1], ks, t * 1e3))
