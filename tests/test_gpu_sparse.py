@@ -112,6 +112,22 @@ def test_sparse_decoder_free_running_masks(dev, name, hw, seed, thr):
     assert float(np.abs(out[("disp", 0)].cpu().numpy() - gold["disp|0"]).mean()) < 1e-4
 
 
+def test_sparse_decoder_graph_replay_matches_eager(dev):
+    sp = _decoder(dev, seed=3)
+    feats = [f.to(dev) for f in kitti_feats(1, 96, 160, seed=2)]
+    ref = sp(feats, 0.15)
+    sp.enable_graph(True)
+    for _ in range(2):
+        out = sp(feats, 0.15)
+    assert out["total_ops"] == ref["total_ops"]
+    for k, v in ref.items():
+        if torch.is_tensor(v):
+            if v.dtype == torch.bool:
+                assert torch.equal(out[k], v), key_str(k)
+            else:
+                assert_close(out[k], v, 2e-6, key_str(k))
+
+
 def test_sparse_equals_dense_at_negative_threshold(dev):
     """Reference invariant: thresh_ratio <= 0 reproduces the dense decoder with the same weights."""
     from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder

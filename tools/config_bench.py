@@ -1,0 +1,91 @@
+"""Secondary workloads of BASELINE.json (configs[2..4]) — parity-tested elsewhere, timed here for the record:
+  sparse   KITTI R18 640x192 sparse decoder, batch 1, threshold sweep, free-running and controlled-density masks
+  nyu      NYUv2 DenseNet161-shaped DecoderWave 640x480, batch 4: forward and forward+backward
+  r50      KITTI R50 1024x320 dense decoder, batch 8: forward
+usage: python tools/config_bench.py [sparse] [nyu] [r50]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from wavelet_monodepth_amd import synth
+
+dev = torch.device("cuda:0")
+which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["sparse", "nyu", "r50"]
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+if "sparse" in which:
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder, SparseDepthWaveProgressiveDecoder
+    chans = [64, 64, 128, 256, 512]
+    sp = synth.fill_state_dict(SparseDepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
+    dn = DepthWaveProgressiveDecoder(np.array(chans)).to(dev)
+    dn.load_state_dict(sp.state_dict())
+    feats = [torch.from_numpy(f).to(dev) for f in synth.encoder_features(1, 192, 640, chans, seed=1)]
+    with torch.no_grad():
+        t_dense = timeit(lambda: dn(feats))
+    print("sparse: dense decoder batch 1: %.3f ms (%.0f frames/s)" % (t_dense * 1e3, 1 / t_dense))
+    dn.enable_graph(True)
+    with torch.no_grad():
+        t_dense_g = timeit(lambda: dn(feats))
+    print("sparse: dense decoder batch 1, hipGraph replay: %.3f ms (%.0f frames/s)" % (t_dense_g * 1e3, 1 / t_dense_g))
+    sp.enable_graph("--no-graph" not in sys.argv)
+    for thr in (-1.0, 0.01, 0.02, 0.05, 0.1, 0.15, 0.2):
+        out = sp(feats, thr)
+        dens = [float(out[("wavelet_mask", s)].float().mean()) for s in (2, 1, 0)]
+        t = timeit(lambda: sp(feats, thr), n=10)
+        print("sparse: thresh %5.2f  density(scale2,1,0) = %.2f %.2f %.2f  total_ops %.3f G  %.3f ms  %.0f frames/s" % (
+            thr, dens[0], dens[1], dens[2], out["total_ops"] / 1e9, t * 1e3, 1 / t))
+    # controlled density: random seed pixels dilated into blobs covering ~p of each level's coarse grid
+    for p in (0.05, 0.10, 0.20, 0.50):
+        force = {}
+        for i, (h, w) in zip((3, 2, 1), ((12, 40), (24, 80), (48, 160))):
+            m = (torch.from_numpy(synth.uniform((h, w), "dens%d" % i, 3, 0.0, 1.0)) < p).to(torch.uint8)
+            force[i] = m
+        out = sp(feats, 0.05, _force_masks=force)
+        dens = [float(out[("wavelet_mask", s)].float().mean()) for s in (2, 1, 0)]
+        t = timeit(lambda: sp(feats, 0.05, _force_masks=force), n=10)
+        print("sparse: injected density %.2f -> masks %.2f %.2f %.2f  total_ops %.3f G  %.3f ms  %.0f frames/s" % (
+            p, dens[0], dens[1], dens[2], out["total_ops"] / 1e9, t * 1e3, 1 / t))
+
+if "nyu" in which:
+    from wavelet_monodepth_amd.nyu import DecoderWave
+    enc = [96, 96, 192, 384, 2208]
+    B = 4
+    dec = synth.fill_state_dict(DecoderWave(enc_features=enc), seed=9).to(dev)
+    feats = [torch.from_numpy(synth.normal((B, c, 480 >> (k + 1), 640 >> (k + 1)), "nyu%d" % k, 9)).to(dev) for k, c in enumerate(enc)]
+    with torch.no_grad():
+        t = timeit(lambda: dec(feats), n=10)
+    gmac = 33.325
+    print("nyu: DecoderWave 640x480 batch %d forward: %.3f ms  %.1f frames/s  %.1f TFLOP/s" % (B, t * 1e3, B / t, 2 * gmac * B / t / 1e3))
+    fg = [f.clone().requires_grad_(True) for f in feats]
+
+    def step():
+        out = dec(fg)
+        sum(out[("disp", s)].mean() for s in range(4)).backward()
+    t = timeit(step, n=5, warm=2)
+    print("nyu: DecoderWave 640x480 batch %d forward+backward: %.3f ms  %.1f frames/s" % (B, t * 1e3, B / t))
+
+if "r50" in which:
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    chans = [64, 256, 512, 1024, 2048]
+    B = 8
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
+    feats = [torch.from_numpy(f).to(dev) for f in synth.encoder_features(B, 320, 1024, chans, seed=1)]
+    with torch.no_grad():
+        t = timeit(lambda: dec(feats), n=10)
+    print("r50: dense decoder 1024x320 batch %d forward: %.3f ms  %.1f frames/s  %.1f TFLOP/s" % (B, t * 1e3, B / t, 2 * 17.19 * B / t / 1e3))

@@ -122,13 +122,17 @@ struct SparseKArgs {
     size_t plane, plane1;
 };
 
-template <int MR, int TAPS, bool DUAL>
-__global__ __launch_bounds__(64) void sparse_conv_kernel(const SparseKArgs a) {
+// WK wavefronts share one (16-pixel tile, MR out-channel tiles) task and split the input-channel loop between
+// them (the chain is latency-bound: a single wave would walk all Cin*9 gathers serially); partial accumulators
+// are combined through LDS by wave 0.
+template <int MR, int TAPS, bool DUAL, int WK>
+__global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs a) {
     const wmd_sparse_conv_args& g = a.g;
     const int nnz = min(*g.out_nnz, g.max_out);
     const int tile = blockIdx.x;
     if (tile * 16 >= nnz) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kq = lane >> 4;
     const int pidx = tile * 16 + j;
     const bool px_ok = pidx < nnz;
@@ -171,7 +175,8 @@ __global__ __launch_bounds__(64) void sparse_conv_kernel(const SparseKArgs a) {
     }
 
     const int nci4 = (Cin + 3) / 4;
-    for (int ci4 = 0; ci4 < nci4; ++ci4) {
+#pragma unroll 2
+    for (int ci4 = wk; ci4 < nci4; ci4 += WK) {
         const int ci = ci4 * 4 + kq;
         const bool from1 = ci < g.C1;
         const bool ch_ok = ci < Cin;
@@ -204,6 +209,25 @@ __global__ __launch_bounds__(64) void sparse_conv_kernel(const SparseKArgs a) {
         }
     }
 
+    if (WK > 1) {
+        __shared__ f32x4 red[WK > 1 ? WK - 1 : 1][DUAL ? 2 * MR : MR][64];
+        if (wk > 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                red[wk - 1][m][lane] = acc[m];
+                if (DUAL) red[wk - 1][MR + m][lane] = acc2[m];
+            }
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w = 0; w < WK - 1; ++w)
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                acc[m] += red[w][m][lane];
+                if (DUAL) acc2[m] += red[w][MR + m][lane];
+            }
+    }
     if (!px_ok) return;
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -304,21 +328,22 @@ extern "C" int wmd_sparse_conv(const wmd_sparse_conv_args* g, void* stream) {
     const int tiles = (g->max_out + 15) / 16;
     const int taps = g->ksize == 3 ? 9 : 1;
     ProfScope prof("sparse_conv_kernel", 0.0, 0.0, s);
+    constexpr int WK = 8;  // waves per task for 3x3 (Cin*9 gathers per pixel); 1x1 chains are 9x shorter
     if (g->wp2) {
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<1, 9, true>), dim3(tiles, 1), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<1, 1, true>), dim3(tiles, 1), dim3(64), 0, s, a);
+        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<1, 9, true, WK>), dim3(tiles, 1), dim3(64 * WK), 0, s, a);
+        else hipLaunchKernelGGL((sparse_conv_kernel<1, 1, true, 2>), dim3(tiles, 1), dim3(128), 0, s, a);
     } else if (a.ncot >= 4) {
         const dim3 grid(tiles, (a.ncot + 3) / 4);
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<4, 9, false>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<4, 1, false>), grid, dim3(64), 0, s, a);
+        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<4, 9, false, WK>), grid, dim3(64 * WK), 0, s, a);
+        else hipLaunchKernelGGL((sparse_conv_kernel<4, 1, false, 2>), grid, dim3(128), 0, s, a);
     } else if (a.ncot >= 2) {
         const dim3 grid(tiles, (a.ncot + 1) / 2);
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<2, 9, false>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<2, 1, false>), grid, dim3(64), 0, s, a);
+        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<2, 9, false, WK>), grid, dim3(64 * WK), 0, s, a);
+        else hipLaunchKernelGGL((sparse_conv_kernel<2, 1, false, 2>), grid, dim3(128), 0, s, a);
     } else {
         const dim3 grid(tiles, 1);
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<1, 9, false>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<1, 1, false>), grid, dim3(64), 0, s, a);
+        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<1, 9, false, WK>), grid, dim3(64 * WK), 0, s, a);
+        else hipLaunchKernelGGL((sparse_conv_kernel<1, 1, false, 2>), grid, dim3(128), 0, s, a);
     }
     return check_launch("sparse_conv_kernel");
 }

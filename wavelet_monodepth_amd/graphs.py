@@ -14,8 +14,9 @@ class GraphCache:
     def clear(self):
         self._entries.clear()
 
-    def run(self, fn, inputs, params):
-        key = tuple((t.data_ptr(), tuple(t.shape)) for t in inputs) + tuple((p.data_ptr(), p._version) for p in params)
+    def run(self, fn, inputs, params, extra_key=()):
+        key = tuple((t.data_ptr(), tuple(t.shape)) for t in inputs) + tuple((p.data_ptr(), p._version) for p in params) \
+            + tuple(extra_key)
         ent = self._entries.get(key)
         if ent is None:
             if len(self._entries) >= self._max:
@@ -33,4 +34,4 @@ class GraphCache:
             ent = (g, out, list(inputs))  # keep the inputs alive: the graph reads their storage
             self._entries[key] = ent
         ent[0].replay()
-        return dict(ent[1])
+        return dict(ent[1]) if isinstance(ent[1], dict) else ent[1]

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from .. import ops, sparse_ops as S
 from ..wavelets import IDWT
+from ..graphs import GraphCache
 from .depth_decoder import _build_wave_convs
 
 
@@ -46,6 +47,8 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         self.convs = _build_wave_convs(self.num_ch_enc, self.num_ch_dec, use_skips)
         self.decoder = nn.ModuleList(list(self.convs.values()))
         self.sigmoid = nn.Sigmoid()
+        self._graph_mode = False
+        self._graphs = GraphCache()
 
     # ------------------------------------------------------------------------------------------
     def _dense_coefficients(self, x, i, with_ll):
@@ -67,11 +70,29 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                                 pad="reflect", mode=2, scale=2.0 ** (i - 1))
         return yl, yh.unsqueeze(1)
 
+    def enable_graph(self, on=True):
+        """Capture the whole device-side chain (≈45 launches, all pixel counts stay on the device) into one hipGraph
+        per (inputs, threshold, scales) and replay it; only the python-int op model is computed on the host after."""
+        self._graph_mode = bool(on)
+        self._graphs.clear()
+        return self
+
     @torch.no_grad()
     def forward(self, input_features, thresh_ratio=0.05, sparse_scales=[0, 1, 2, 3], _force_masks=None):
-        self.outputs = out = {}
+        assert input_features[-1].shape[0] == 1, "works with single input only"
+        if self._graph_mode and _force_masks is None:
+            thr, scales = float(thresh_ratio), tuple(sparse_scales)
+            res = self._graphs.run(lambda f: self._device_chain(f, thr, scales, None), list(input_features),
+                                   self.parameters(), extra_key=(thr, scales))
+            out, counters, static_ops = dict(res[0]), res[1], res[2]
+        else:
+            out, counters, static_ops = self._device_chain(input_features, thresh_ratio, sparse_scales, _force_masks)
+        self.outputs = out
+        return self._host_op_model(out, counters, static_ops)
+
+    def _device_chain(self, input_features, thresh_ratio, sparse_scales, _force_masks):
+        out = {}
         x = input_features[-1]
-        assert x.shape[0] == 1, "works with single input only"
         dev = x.device
         sparse_scales = list(sparse_scales)
         counters = []          # (level, nnz tensor [3]) resolved into python ints once, at the end
@@ -159,7 +180,10 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             static_ops[i] = scale_ops
             if i == 1:
                 break
+        return out, counters, static_ops
 
+    @staticmethod
+    def _host_op_model(out, counters, static_ops):
         # ---- the reference's op model needs the pixel counts as python ints: one sync for the whole forward
         total_ops = 0
         resolved = {lvl: [int(v) for v in nnz.tolist()] for (lvl, nnz, *_rest) in counters}
