@@ -200,6 +200,42 @@ typedef struct {
 int wmd_head3x3_fwd(const wmd_head_args* args, void* stream);
 size_t wmd_head3x3_workspace_floats(const wmd_head_args* args);
 
+/* Fused inference form of a level's two high-frequency heads (depth_decoder.py:108-136):
+ *   mid_s = LeakyReLU(W1_s x + b1_s)            s in {+,-}, both C -> C     (MFMA GEMM, result stays in LDS)
+ *   t[s*27 + co*9 + tap] = sum_c W3_s[co,c,tap] * mid_s[c]                  (second MFMA GEMM of the same block)
+ * i.e. the 3x3 convolution regrouped as 27 tap-partial 1x1 outputs; wmd_head_shiftsum_fwd then gathers the
+ * nine shifted taps, adds the bias, applies sigmoid / 2^(s-1)(sig+ - sig-) and (optionally) the Haar IDWT.
+ * wp1: wmd_conv_pack_weights image of the stacked [2C, C, 1, 1] filter (+ rows first); bias1 [2C];
+ * wp2: two wmd_conv_pack_weights images of [27, C, 1, 1] (W3.permute(0,2,3,1).reshape(27, C)), + then -.
+ * C in {32, 64, 128}; other widths return WMD_ERR_UNSUPPORTED (callers use the unfused operators).            */
+typedef struct {
+    int B, H, W, C;
+    float slope;
+    const float* x;      /* [B,C,H,W]      */
+    const float* wp1;
+    const float* bias1;
+    const float* wp2;
+    float* t;            /* [B,54,H,W]     */
+} wmd_head_fused_args;
+int wmd_head_fused_fwd(const wmd_head_fused_args* args, void* stream);
+
+typedef struct {
+    int B, H, W;
+    int pad_mode;        /* padding of the 3x3 it completes (reflect for the KITTI heads)                    */
+    float scale;         /* 2^(s-1)                                                                          */
+    const float* t;      /* [B,54,H,W] from wmd_head_fused_fwd                                               */
+    const float* bias_p; /* [3] */
+    const float* bias_n; /* [3] */
+    float* yh;           /* [B,3,H,W] = scale*sigmoid(.) - scale*sigmoid(.)                                  */
+    /* optional fused IDWT (wmd_idwt_haar_fwd semantics): yl [B,H,W] -> out [B,2H,2W], disp                  */
+    const float* yl;
+    float* out;
+    float* disp;
+    float disp_scale;
+    int clamp01;
+} wmd_head_shiftsum_args;
+int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* args, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Sparse (threshold-gated) decoder path, batch 1
  *

@@ -271,6 +271,28 @@ def test_kitti_dense_decoder_graph_replay_and_grad_mode_paths_agree(dev):
             assert_close(a[k], b[k], 2e-6, "graph vs eager " + key_str(k))
 
 
+@pytest.mark.parametrize("C,H,W", [(32, 12, 40), (64, 9, 28), (128, 6, 20), (32, 5, 7)])
+def test_fused_head_level_vs_oracle(dev, C, H, W):
+    """wmd_head_fused_fwd + wmd_head_shiftsum_fwd == Conv1x1 -> LeakyReLU -> Conv3x3(refl) -> sigmoid combine -> IDWT."""
+    from wavelet_monodepth_amd import ops
+    B, s = 2, 2
+    x = t(synth.normal((B, C, H, W), "fx", 6))
+    yl = t(synth.normal((B, 1, H, W), "fyl", 6)) * 2 + 4
+    hp = [t(a) for a in synth.conv_params("f1p", C, C, 1, 6)] + [t(a) for a in synth.conv_params("f3p", 3, C, 3, 6)]
+    hn = [t(a) for a in synth.conv_params("f1n", C, C, 1, 6)] + [t(a) for a in synth.conv_params("f3n", 3, C, 3, 6)]
+    lk = lambda v: torch.nn.functional.leaky_relu(v, 0.1)
+    sp = torch.sigmoid(R.conv3x3(lk(R.conv1x1(x, hp[0], hp[1])), hp[2], hp[3], "reflect"))
+    sn = torch.sigmoid(R.conv3x3(lk(R.conv1x1(x, hn[0], hn[1])), hn[2], hn[3], "reflect"))
+    yh_ref = (2 ** (s - 1) * sp - 2 ** (s - 1) * sn).unsqueeze(1)
+    out_ref = R.haar_idwt(yl, yh_ref)
+    g = lambda v: v.to(dev)
+    yh, out, disp = ops.head_fused_level_nograd(g(x), [g(v) for v in hp], [g(v) for v in hn], scale=2.0 ** (s - 1), yl=g(yl),
+                                                disp_scale=1.0 / 2 ** (s - 1), clamp01=True)
+    assert float((yh.cpu() - yh_ref).abs().max()) < 4e-6          # differences of sigmoids: absolute tolerance
+    assert_close(out, out_ref, 2e-6, "idwt")
+    assert_close(disp, torch.clamp(out_ref / 2 ** (s - 1), 0, 1), 2e-6, "disp")
+
+
 def test_kitti_baseline_decoder_vs_reference_golden(dev):
     from wavelet_monodepth_amd.kitti import DepthDecoder
     gold = load_golden("kitti_baseline_r18_64x64.npz")

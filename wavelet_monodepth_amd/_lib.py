@@ -48,6 +48,18 @@ class HeadArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
 
 
+class HeadFusedArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("slope", C.c_float),
+                ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p), ("t", C.c_void_p)]
+
+
+class HeadShiftsumArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pad_mode", C.c_int), ("scale", C.c_float),
+                ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
+                ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
+                ("clamp01", C.c_int)]
+
+
 class DilateSpec(C.Structure):
     _fields_ = [("up", C.c_int), ("radius", C.c_int), ("out", C.c_void_p)]
 
@@ -91,6 +103,8 @@ SIGNATURES = {
     "wmd_conv_wgrad": (C.c_int, [C.POINTER(ConvWgradArgs), C.c_void_p]),
     "wmd_head3x3_fwd": (C.c_int, [C.POINTER(HeadArgs), C.c_void_p]),
     "wmd_head3x3_workspace_floats": (C.c_size_t, [C.POINTER(HeadArgs)]),
+    "wmd_head_fused_fwd": (C.c_int, [C.POINTER(HeadFusedArgs), C.c_void_p]),
+    "wmd_head_shiftsum_fwd": (C.c_int, [C.POINTER(HeadShiftsumArgs), C.c_void_p]),
     "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),

@@ -21,6 +21,7 @@
 // matrix pipe as the only saturated unit; the kernel is MFMA-bound by construction.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "wmd_internal.h"
 
 namespace wmd {
@@ -44,9 +45,13 @@ struct ConvKArgs {
     int ncot;        // number of 16-out-channel tiles in wp
     int nchunks;     // ceil(Cin / CK)
     int ksplit, chunks_per_split;
+    // fused wavelet head (FUSE kernels only): second GEMM over the LeakyReLU'd block result
+    const float* wp2;   // per side: packed [27 -> 32 rows, CO_T] image
+    float* t;           // [B, sides*27, H*W]
+    int t_ctot;
 };
 
-template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
+template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, int NBUF = 2>
 struct ConvTile {
     static constexpr int NT = WM * WN * 64;
     static constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -64,7 +69,7 @@ struct ConvTile {
     static constexpr int A_FLOATS = WM * MR * A_RUN;
     static constexpr int B_FLOATS = CK * PS;
     static constexpr int NAV = (A_FLOATS / 4 + NT - 1) / NT;  // 16-byte weight pieces per thread and chunk
-    static constexpr int LDS_FLOATS = 2 * B_FLOATS + 2 * A_FLOATS;
+    static constexpr int LDS_FLOATS = NBUF * (B_FLOATS + A_FLOATS);  // NBUF = 1: the whole reduction is one chunk
     static_assert(WN * NR * 16 >= NPIX, "tile has more pixels than MFMA columns");
     static_assert(CK % 8 == 0, "CK must be a multiple of 8 (an even number of 4-channel K-steps)");
     static_assert((A_FLOATS / 4) % 64 == 0, "the weight tile must be a whole number of 64-lane 16-byte pieces");
@@ -82,14 +87,15 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_ptr_t ds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
 }
 
-template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
+template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, bool FUSE = false, int NBUF = 2>
 __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a) {
-    using T = ConvTile<TH, TW, MR, NR, WM, WN, CK, TAPS>;
+    using T = ConvTile<TH, TW, MR, NR, WM, WN, CK, TAPS, NBUF>;
     constexpr int NT = T::NT, HALO = T::HALO, PW = T::PW, PS = T::PS, NPOS = T::NPOS;
     constexpr int KSTEPS = CK / 4;
 
-    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
-    float* ldsA = lds + 2 * T::B_FLOATS;
+    constexpr int MID_FLOATS = FUSE ? WM * MR * 16 * T::PS : 0;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS > MID_FLOATS ? T::LDS_FLOATS : MID_FLOATS];
+    float* ldsA = lds + NBUF * T::B_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        if (c + 1 < c_end) stage(c + 1, buf ^ 1);  // wave-uniform branch; the other buffer was released by the last barrier
+        if (NBUF == 2 && c + 1 < c_end) stage(c + 1, buf ^ 1);  // wave-uniform branch; the other buffer was released by the last barrier
         const float* bsrc = lds + buf * T::B_FLOATS;
         const float* asrc = ldsA + buf * T::A_FLOATS + a_lane;
 #pragma unroll
@@ -235,6 +241,73 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
             }
         }
         __syncthreads();
+    }
+
+    if constexpr (FUSE) {
+        // ---- fused wavelet head: mid = LeakyReLU(acc + b1) stays on chip; t = W3' * mid --------------------
+        // The block holds ALL CO_T mid channels of one side (blockIdx.y) for its pixels.  W3' is the 3x3 filter
+        // regrouped as 27 "tap-partial" 1x1 outputs (row co*9+tap); the spatial shift-sum over the 9 taps
+        // (+ bias, sigmoid, combine, IDWT) is done by head_shiftsum_kernel on the 54-plane result.
+        static_assert(!FUSE || TAPS == 1, "the fused head is a 1x1 chain");
+        constexpr int CO_T = WM * MR * 16, PS2 = T::PS, R2W = 2 / WM;
+        static_assert(!FUSE || WM <= 2, "two 16-row tiles of tap-partials are split over at most two wave rows");
+        float* mid = lds;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int chl = (wm * MR + m) * 16 + (lane & 15);
+            const float bv = a.bias ? a.bias[blockIdx.y * CO_T + chl] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int q = (wn * NR + n) * 16 + (lane >> 4) * 4;
+                float4 v;
+                v.x = act_apply(acc[m][n][0] + bv, a.act, a.slope);
+                v.y = act_apply(acc[m][n][1] + bv, a.act, a.slope);
+                v.z = act_apply(acc[m][n][2] + bv, a.act, a.slope);
+                v.w = act_apply(acc[m][n][3] + bv, a.act, a.slope);
+                *reinterpret_cast<float4*>(mid + chl * PS2 + q) = v;
+            }
+        }
+        __syncthreads();
+        f32x4 acc2[R2W][NR];
+#pragma unroll
+        for (int j = 0; j < R2W; ++j)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) acc2[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NCI4_2 = CO_T / 4;   // CO_T is a multiple of 16
+        const float* w2 = a.wp2 + (size_t)blockIdx.y * (2 * NCI4_2 * 64) + lane;
+        const float* msrc = mid + (lane >> 4) * PS2 + (lane & 15);
+#pragma unroll 4
+        for (int k4 = 0; k4 < NCI4_2; ++k4) {
+            float pf[NR], wf[R2W];
+#pragma unroll
+            for (int j = 0; j < R2W; ++j) wf[j] = w2[((WM == 1 ? j : wm) * NCI4_2 + k4) * 64];
+#pragma unroll
+            for (int n = 0; n < NR; ++n) pf[n] = msrc[k4 * 4 * PS2 + (wn * NR + n) * 16];
+#pragma unroll
+            for (int j = 0; j < R2W; ++j)
+#pragma unroll
+                for (int n = 0; n < NR; ++n) acc2[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[n], wf[j], acc2[j][n], 0, 0, 0);
+        }
+        const bool vec = (W & 3) == 0;
+#pragma unroll
+        for (int j = 0; j < R2W; ++j) {
+            const int r2 = (WM == 1 ? j : wm) * 16 + (lane & 15);
+            if (r2 >= 27) continue;
+            float* tb = a.t + ((size_t)b * a.t_ctot + blockIdx.y * 27 + r2) * plane2;
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int ox = x0 + (wn * NR + n) * 16 + (lane >> 4) * 4;
+                if (ox >= W) continue;
+                if (vec && ox + 3 < W) {
+                    *reinterpret_cast<float4*>(tb + ox) = make_float4(acc2[j][n][0], acc2[j][n][1], acc2[j][n][2], acc2[j][n][3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ox + r < W) tb[ox + r] = acc2[j][n][r];
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: lane = (channel lane&15, pixel quad lane>>4) ----------------------------------------
@@ -433,6 +506,54 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
 }  // namespace wmd
 
 using namespace wmd;
+
+extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
+    if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: null args");
+    if (!g->x || !g->wp1 || !g->wp2 || !g->t) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: null tensor pointer");
+    if (g->B <= 0 || g->H <= 0 || g->W <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_head_fused_fwd: B=%d H=%d W=%d", g->B, g->H, g->W);
+    if (g->C != 32 && g->C != 64 && g->C != 128)
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: C=%d (32, 64 or 128; wider heads run unfused)", g->C);
+    ConvKArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x1 = g->x;
+    a.wp = g->wp1;
+    a.bias = g->bias1;
+    a.B = g->B;
+    a.H = 1;
+    a.W = g->H * g->W;   // 1x1: the image is a flat pixel vector
+    a.H1 = 1;
+    a.W1 = a.W;
+    a.C1 = g->C;
+    a.Cin = g->C;
+    a.Cout = 2 * g->C;
+    a.up1 = 1;
+    a.act = WMD_ACT_LEAKY;
+    a.slope = g->slope;
+    a.nci4 = ((g->C + 15) / 16) * 4;
+    a.ncot = 2 * g->C / 16;
+    a.nchunks = g->C == 128 ? 4 : 1;   // C = 32 / 64: the whole reduction is one LDS-resident chunk
+    a.ksplit = 1;
+    a.chunks_per_split = a.nchunks;
+    a.tiles_y = 1;
+    a.wp2 = g->wp2;
+    a.t = g->t;
+    a.t_ctot = 54;
+    hipStream_t s = (hipStream_t)stream;
+    const double pix = (double)g->B * g->H * g->W;
+    ProfScope prof("conv_fwd_kernel<fused head>", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C),
+                   4.0 * pix * (g->C + 54), s);
+    if (g->C == 32) {
+        a.tiles_x = (a.W + 255) / 256;
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 256, 2, 4, 1, 4, 32, 1, true, 1>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
+    } else if (g->C == 64) {
+        a.tiles_x = (a.W + 127) / 128;
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 128, 2, 4, 2, 2, 64, 1, true, 1>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
+    } else {
+        a.tiles_x = (a.W + 127) / 128;
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 128, 4, 4, 2, 2, 32, 1, true>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
+    }
+    return check_launch("conv_fwd_kernel<fused head>");
+}
 
 extern "C" int wmd_conv_num_configs(void) { return kNumCfgs; }
 extern "C" const char* wmd_conv_config_name(int i) { return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : nullptr; }

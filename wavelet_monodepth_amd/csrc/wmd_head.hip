@@ -285,6 +285,59 @@ __global__ void head_finalize_kernel(const wmd_head_args a, const float* __restr
     }
 }
 
+// Completes the fused head: y[co][p] = scale*sig(b+[co] + sum_tap t+[co*9+tap][pad(p+d_tap)]) - scale*sig(same for -),
+// and optionally the Haar synthesis of (yl, y) -> out / disp.  One thread per coefficient pixel; HBM-bound
+// (54 planes read about once through the caches, 3 + 4 (+4) values written).
+__global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
+    const int H = a.H, W = a.W;
+    const size_t plane = (size_t)H * W;
+    const size_t total = (size_t)a.B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = i % W;
+        const int y = (i / W) % H;
+        const size_t b = i / plane;
+        int off[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int gy = y + t / 3 - 1, gx = x + t % 3 - 1;
+            const bool ok = pad_coord(gy, H, a.pad_mode) & pad_coord(gx, W, a.pad_mode);
+            off[t] = ok ? gy * W + gx : -1;
+        }
+        const float* tb = a.t + b * 54 * plane;
+        float yh[3];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            float sp = a.bias_p ? a.bias_p[co] : 0.f, sn = a.bias_n ? a.bias_n[co] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (off[t] >= 0) {
+                    sp += tb[(size_t)(co * 9 + t) * plane + off[t]];
+                    sn += tb[(size_t)(27 + co * 9 + t) * plane + off[t]];
+                }
+            const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
+            yh[co] = a.scale * a1 - a.scale * a2;
+            a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
+        }
+        if (a.yl && a.out) {
+            const float l = a.yl[i];
+            float v[4] = {(l + yh[0] + yh[1] + yh[2]) * 0.5f, (l + yh[0] - yh[1] - yh[2]) * 0.5f,
+                          (l - yh[0] + yh[1] - yh[2]) * 0.5f, (l - yh[0] - yh[1] + yh[2]) * 0.5f};
+            const size_t dst = b * 4 * plane + (size_t)(2 * y) * (2 * W) + 2 * x;
+            *reinterpret_cast<float2*>(a.out + dst) = make_float2(v[0], v[1]);
+            *reinterpret_cast<float2*>(a.out + dst + 2 * W) = make_float2(v[2], v[3]);
+            if (a.disp) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] *= a.disp_scale;
+                    if (a.clamp01) v[k] = fminf(fmaxf(v[k], 0.f), 1.f);
+                }
+                *reinterpret_cast<float2*>(a.disp + dst) = make_float2(v[0], v[1]);
+                *reinterpret_cast<float2*>(a.disp + dst + 2 * W) = make_float2(v[2], v[3]);
+            }
+        }
+    }
+}
+
 static void head_plan(const wmd_head_args* g, int* tiles_x, int* tiles_y, int* csplit, int* cper) {
     *tiles_x = (g->W + HT_W - 1) / HT_W;
     *tiles_y = (g->H + HT_H - 1) / HT_H;
@@ -351,4 +404,19 @@ extern "C" int wmd_head3x3_fwd(const wmd_head_args* g, void* stream) {
     hipLaunchKernelGGL(head_finalize_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, *g,
                        g->workspace, csplit);
     return check_launch("head_finalize_kernel");
+}
+
+extern "C" int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* g, void* stream) {
+    if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: null args");
+    if (!g->t || !g->yh) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: null tensor pointer");
+    if (g->B <= 0 || g->H <= 0 || g->W <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_head_shiftsum_fwd: B=%d H=%d W=%d", g->B, g->H, g->W);
+    if (g->pad_mode < 0 || g->pad_mode > 2) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: pad_mode=%d", g->pad_mode);
+    if (g->pad_mode == WMD_PAD_REFLECT && (g->H < 2 || g->W < 2))
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_head_shiftsum_fwd: reflect padding needs H,W >= 2");
+    if ((g->out != nullptr) != (g->yl != nullptr)) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: yl and out go together");
+    const size_t n = (size_t)g->B * g->H * g->W;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("head_shiftsum_kernel", 60.0 * n, 4.0 * n * (54 + 3 + (g->out ? (g->disp ? 9 : 5) : 0)), s);
+    hipLaunchKernelGGL(head_shiftsum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 16)), dim3(256), 0, s, *g);
+    return check_launch("head_shiftsum_kernel");
 }

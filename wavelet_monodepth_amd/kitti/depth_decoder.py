@@ -58,6 +58,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self.tanh = nn.Tanh()
         self._graph_mode = False
         self._graphs = GraphCache()
+        self.fuse_heads = True   # inference: fused 1x1 -> 3x3 -> IDWT head kernels where the width allows (32/64/128)
 
     # -- pieces ------------------------------------------------------------------------------
     def _head_mid(self, x, key):
@@ -124,15 +125,29 @@ class DepthWaveProgressiveDecoder(nn.Module):
             x = self.convs[("upconv", i, 0)](x)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip=skip, up=2)  # fused upsample + concat
-            if i == 4:
-                yl, yh = self.get_coefficients(x, scale=i, return_ll=True)
+            fused = (not torch.is_grad_enabled()) and i < 4 and int(self.num_ch_dec[i]) in ops.FUSED_HEAD_WIDTHS \
+                and self.fuse_heads
+            if fused:
+                # two launches per level: 1x1 -> LeakyReLU -> tap-partials (mid stays on chip), then the 9-tap gather +
+                # sigmoid + combine + Haar synthesis
+                hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
+                yl_in = yl
+                yh, yl, disp = ops.head_fused_level_nograd(
+                    x, (hp[0].conv.weight, hp[0].conv.bias, hp[2].conv.weight, hp[2].conv.bias),
+                    (hn[0].conv.weight, hn[0].conv.bias, hn[2].conv.weight, hn[2].conv.bias),
+                    scale=2.0 ** (i - 1), yl=yl, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
+                self.outputs[("wavelets", i - 1, "LL")] = yl_in
             else:
-                _, yh = self.get_coefficients(x, scale=i, return_ll=False)
-            self.outputs[("wavelets", i - 1, "LL")] = yl
+                if i == 4:
+                    yl, yh = self.get_coefficients(x, scale=i, return_ll=True)
+                else:
+                    _, yh = self.get_coefficients(x, scale=i, return_ll=False)
+                self.outputs[("wavelets", i - 1, "LL")] = yl
             self.outputs[("wavelets", i - 1, "LH")] = yh[:, :, 0]
             self.outputs[("wavelets", i - 1, "HL")] = yh[:, :, 1]
             self.outputs[("wavelets", i - 1, "HH")] = yh[:, :, 2]
-            yl, disp = ops.idwt_haar(yl, yh, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
+            if not fused:
+                yl, disp = ops.idwt_haar(yl, yh, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
             self.outputs[("disp", i - 1)] = disp
         return self.outputs
 

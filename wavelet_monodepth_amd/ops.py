@@ -348,6 +348,58 @@ def head3x3_nograd(x_full, cin, off_p, weight_p, bias_p, off_n=None, weight_n=No
     return y
 
 
+def _tap_partial_pack(w3p, w3n):
+    """[3,C,3,3] x 2 -> two packed [27,C,1,1] images (row co*9+tap), memoised on w3p."""
+    tag = (w3p._version, w3p.data_ptr(), w3n._version, w3n.data_ptr())
+    hit = getattr(w3p, "_wmd_pack_t27", None) if _PACK_CACHE else None
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    l = _lib.lib()
+    cin = w3p.shape[1]
+    n = l.wmd_conv_packed_weight_floats(27, cin, 1)
+    wp = torch.empty(2 * n, device=w3p.device, dtype=torch.float32)
+    for k, w in enumerate((w3p, w3n)):
+        w27 = w.detach().permute(0, 2, 3, 1).reshape(27, cin, 1, 1).contiguous()
+        check(l.wmd_conv_pack_weights(ptr(w27), wp.data_ptr() + 4 * k * n, 27, cin, 1, current_stream()), "wmd_conv_pack_weights")
+    if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
+        try:
+            w3p._wmd_pack_t27 = (tag, wp)
+        except AttributeError:
+            pass
+    return wp
+
+
+FUSED_HEAD_WIDTHS = (32, 64, 128)
+
+
+def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False):
+    """Inference form of one level's high-frequency heads + (optionally) the Haar IDWT in two launches:
+    wmd_head_fused_fwd (1x1 -> LeakyReLU -> 27 tap-partials per side, intermediate stays on chip) and
+    wmd_head_shiftsum_fwd (9-tap gather, bias, sigmoid, combine, IDWT).  head_* = (w1, b1, w3, b3).
+    Returns (yh [B,1,3,H,W], out or None, disp or None)."""
+    l = _lib.lib()
+    x = _c(x)
+    B, Cc, H, W = x.shape
+    (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
+    wp1, bias1 = stacked_pack([w1p, w1n], [b1p, b1n])
+    wp2 = _tap_partial_pack(w3p, w3n)
+    t = torch.empty((B, 54, H, W), device=x.device, dtype=torch.float32)
+    s = current_stream()
+    a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t))
+    check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
+    yh = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
+    out = disp = None
+    if yl is not None:
+        yl = _c(yl)
+        out = torch.empty((B, 1, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        disp = torch.empty_like(out) if disp_scale is not None else None
+    g = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scale), t=ptr(t), bias_p=ptr(b3p),
+                              bias_n=ptr(b3n), yh=ptr(yh), yl=ptr(yl), out=ptr(out), disp=ptr(disp),
+                              disp_scale=float(disp_scale or 1.0), clamp01=int(clamp01))
+    check(l.wmd_head_shiftsum_fwd(C.byref(g), s), "wmd_head_shiftsum_fwd")
+    return yh.unsqueeze(1), out, disp
+
+
 # ---------------------------------------------------------------------------------------------
 # Haar transforms
 # ---------------------------------------------------------------------------------------------
