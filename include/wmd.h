@@ -303,6 +303,19 @@ typedef struct {
 int wmd_sparse_conv(const wmd_sparse_conv_args* args, void* stream);
 
 /* ------------------------------------------------------------------ *
+ * Multi-scale loss front-end
+ * ------------------------------------------------------------------ */
+/* F.interpolate(x, [H,W], mode="bilinear", align_corners) (KITTI/trainer.py:337-338 with align_corners=False;
+ * NYUv2/train.py:304-305 with align_corners=True, H = h*2^s) and, when depth != NULL, disp_to_depth
+ * (KITTI/layers.py:16-25): depth = 1 / (1/max_depth + (1/min_depth - 1/max_depth) * y).
+ * x [N,h,w] -> y [N,H,W] (may be NULL), depth [N,H,W] (may be NULL).                                        */
+int wmd_upsample_bilinear_fwd(const float* x, float* y, float* depth, int N, int h, int w, int H, int W,
+                              int align_corners, float min_depth, float max_depth, void* stream);
+/* Adjoint: dx [N,h,w] = B^T (dy + ddepth * d depth/d y); `depth` is the forward output (needed with ddepth). */
+int wmd_upsample_bilinear_bwd(const float* dy, const float* ddepth, const float* depth, float* dx, int N, int h,
+                              int w, int H, int W, int align_corners, float min_depth, float max_depth, void* stream);
+
+/* ------------------------------------------------------------------ *
  * Data-parallel gradient exchange (new: the reference is single-GPU, trainer.py:45)
  * ------------------------------------------------------------------ */
 typedef struct wmd_comm wmd_comm;

@@ -352,3 +352,25 @@ def test_nyu_dense_decoder_densenet161_shapes_vs_oracle(dev):
         out = dec([f.to(dev) for f in feats])
     for k in ref:
         assert_close(out[k], ref[k], NET_TOL, key_str(k))
+
+
+@pytest.mark.parametrize("shape,size,ac", [((2, 1, 6, 20), (192, 640), False), ((2, 1, 96, 320), (192, 640), False),
+                                           ((1, 1, 30, 40), (240, 320), True), ((2, 3, 5, 7), (11, 9), False),
+                                           ((1, 1, 12, 40), (12, 40), True)])
+def test_upsample_bilinear_and_disp_to_depth(dev, shape, size, ac):
+    """Loss front-end against F.interpolate + disp_to_depth on the CPU, forward and backward."""
+    from wavelet_monodepth_amd import ops
+    x = t(synth.uniform(shape, "ux", 7, 0.05, 0.95)).requires_grad_(True)
+    gy = t(synth.normal((shape[0], shape[1]) + size, "ugy", 7))
+    gd = t(synth.normal((shape[0], shape[1]) + size, "ugd", 7))
+    ref = torch.nn.functional.interpolate(x, size, mode="bilinear", align_corners=ac)
+    _, dref = R.disp_to_depth(ref, 0.1, 100.0)
+    ((ref * gy).sum() + (dref * gd).sum() * 1e-3).backward()
+    xg = x.detach().to(dev).requires_grad_(True)
+    y, d = ops.upsample_bilinear(xg, size, align_corners=ac, depth_range=(0.1, 100.0))
+    ((y * gy.to(dev)).sum() + (d * gd.to(dev)).sum() * 1e-3).backward()
+    assert_close(y, ref, 2e-6, "bilinear")
+    assert_close(d, dref, 1e-5, "depth")
+    assert_close(xg.grad, x.grad, 2e-5, "dx")
+    y2 = ops.upsample_bilinear(xg.detach(), size, align_corners=ac)
+    assert torch.equal(y2, y.detach())

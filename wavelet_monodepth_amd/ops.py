@@ -461,3 +461,46 @@ def dwt_haar(x, J=1):
         yh.append(nh)
         ll = nl
     return ll, yh
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-scale loss front-end
+# ---------------------------------------------------------------------------------------------
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W, align_corners, depth_range):
+        l = _lib.lib()
+        x = _c(x)
+        B, Cc, h, w = x.shape
+        y = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+        depth = torch.empty_like(y) if depth_range is not None else None
+        lo, hi = depth_range if depth_range is not None else (1.0, 2.0)
+        check(l.wmd_upsample_bilinear_fwd(ptr(x), ptr(y), ptr(depth), B * Cc, h, w, H, W, int(align_corners), float(lo),
+                                          float(hi), current_stream()), "wmd_upsample_bilinear_fwd")
+        ctx.save_for_backward(depth)
+        ctx.cfg = (tuple(x.shape), H, W, align_corners, depth_range)
+        if depth is None:
+            return y, y.new_empty(0)
+        return y, depth
+
+    @staticmethod
+    def backward(ctx, dy, ddepth):
+        l = _lib.lib()
+        (depth,) = ctx.saved_tensors
+        shp, H, W, align_corners, depth_range = ctx.cfg
+        dx = torch.empty(shp, device=dy.device, dtype=torch.float32)
+        lo, hi = depth_range if depth_range is not None else (1.0, 2.0)
+        use_dd = depth_range is not None and ddepth is not None
+        check(l.wmd_upsample_bilinear_bwd(ptr(_c(dy)), ptr(_c(ddepth)) if use_dd else None, ptr(depth) if use_dd else None,
+                                          ptr(dx), shp[0] * shp[1], shp[2], shp[3], H, W, int(align_corners), float(lo),
+                                          float(hi), current_stream()), "wmd_upsample_bilinear_bwd")
+        return dx, None, None, None, None
+
+
+def upsample_bilinear(x, size, align_corners=False, depth_range=None):
+    """F.interpolate(x, size, mode="bilinear", align_corners) -> y; with depth_range=(min_depth, max_depth) also
+    returns disp_to_depth(y)[1] (KITTI/trainer.py:337-342).  Differentiable."""
+    _require_gpu(x)
+    y, depth = _UpsampleFn.apply(x, int(size[0]), int(size[1]), bool(align_corners), depth_range)
+    return (y, depth) if depth_range is not None else y
