@@ -207,7 +207,7 @@ size_t wmd_head3x3_workspace_floats(const wmd_head_args* args);
  * nine shifted taps, adds the bias, applies sigmoid / 2^(s-1)(sig+ - sig-) and (optionally) the Haar IDWT.
  * wp1: wmd_conv_pack_weights image of the stacked [2C, C, 1, 1] filter (+ rows first); bias1 [2C];
  * wp2: two wmd_conv_pack_weights images of [27, C, 1, 1] (W3.permute(0,2,3,1).reshape(27, C)), + then -.
- * C in {32, 64, 128}; other widths return WMD_ERR_UNSUPPORTED (callers use the unfused operators).            */
+ * C in {32, 64, 128, 256}; other widths return WMD_ERR_UNSUPPORTED (callers use the unfused operators).       */
 typedef struct {
     int B, H, W, C;
     float slope;

@@ -271,7 +271,7 @@ def test_kitti_dense_decoder_graph_replay_and_grad_mode_paths_agree(dev):
             assert_close(a[k], b[k], 2e-6, "graph vs eager " + key_str(k))
 
 
-@pytest.mark.parametrize("C,H,W", [(32, 12, 40), (64, 9, 28), (128, 6, 20), (32, 5, 7)])
+@pytest.mark.parametrize("C,H,W", [(32, 12, 40), (64, 9, 28), (128, 6, 20), (256, 12, 40), (32, 5, 7)])
 def test_fused_head_level_vs_oracle(dev, C, H, W):
     """wmd_head_fused_fwd + wmd_head_shiftsum_fwd == Conv1x1 -> LeakyReLU -> Conv3x3(refl) -> sigmoid combine -> IDWT."""
     from wavelet_monodepth_amd import ops

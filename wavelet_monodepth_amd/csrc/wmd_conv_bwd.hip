@@ -452,6 +452,8 @@ extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
     int st = validate_bwd(g->B, g->H, g->W, g->C1, g->up1, g->C2, g->Cout, g->ksize, g->pad_mode, "wmd_conv_wgrad");
     if (st) return st;
     if (g->ksize == 1 && g->up1 == 2) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: 1x1 with upsampled input");
+    if ((double)std::max(g->C1, std::max(g->C2, g->Cout)) * g->H * g->W * 4 > 2147483647.0)
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: a per-image tensor slice exceeds 2 GiB");
     WgradPlan p;
     if (!plan_wgrad(g, &p)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: no kernel configuration");
     const int taps = g->ksize == 3 ? 9 : 1;

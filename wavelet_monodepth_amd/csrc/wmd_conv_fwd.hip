@@ -249,8 +249,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         // regrouped as 27 "tap-partial" 1x1 outputs (row co*9+tap); the spatial shift-sum over the 9 taps
         // (+ bias, sigmoid, combine, IDWT) is done by head_shiftsum_kernel on the 54-plane result.
         static_assert(!FUSE || TAPS == 1, "the fused head is a 1x1 chain");
-        constexpr int CO_T = WM * MR * 16, PS2 = T::PS, R2W = 2 / WM;
-        static_assert(!FUSE || WM <= 2, "two 16-row tiles of tap-partials are split over at most two wave rows");
+        constexpr int CO_T = WM * MR * 16, PS2 = T::PS, R2W = WM >= 2 ? 1 : 2;
+        // the two 16-row tiles of tap-partials go to wave rows 0 and 1 (both to row 0 when WM == 1)
         float* mid = lds;
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
             }
         }
         __syncthreads();
+        if (WM > 2 && wm >= 2) return;
         f32x4 acc2[R2W][NR];
 #pragma unroll
         for (int j = 0; j < R2W; ++j)
@@ -414,7 +415,12 @@ static const ConvCfg kCfgs[] = {
     WMD_CFG(4, 32, 4, 2, 1, 4, 8, 9),   // co64  x 128px
     WMD_CFG(2, 32, 4, 2, 2, 2, 8, 9),   // co128 x 64px
     WMD_CFG(5, 32, 4, 5, 2, 2, 8, 9),   // co128 x 160px  (H % 5: 10x32 coarsest level of 1024x320)
+    WMD_CFG(8, 32, 4, 4, 2, 4, 8, 9),   // co128 x 256px, 8 waves
+    WMD_CFG(8, 32, 2, 4, 2, 4, 8, 9),   // co64  x 256px, 8 waves
+    WMD_CFG(4, 32, 2, 4, 2, 2, 8, 9),   // co64  x 128px, 2x2 waves
     // 3x3, 40-wide rows (W = 40/80/160/320)
+    WMD_CFG(8, 40, 4, 5, 1, 4, 8, 9),   // co64  x 320px
+    WMD_CFG(4, 40, 2, 5, 2, 2, 8, 9),   // co64  x 160px, 2x2 waves
     WMD_CFG(4, 40, 4, 5, 2, 2, 8, 9),   // co128 x 160px
     WMD_CFG(4, 40, 4, 5, 1, 2, 8, 9),   // co64  x 160px
     WMD_CFG(2, 40, 4, 5, 1, 1, 8, 9),   // co64  x 80px, single wave
@@ -511,8 +517,8 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: null args");
     if (!g->x || !g->wp1 || !g->wp2 || !g->t) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: null tensor pointer");
     if (g->B <= 0 || g->H <= 0 || g->W <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_head_fused_fwd: B=%d H=%d W=%d", g->B, g->H, g->W);
-    if (g->C != 32 && g->C != 64 && g->C != 128)
-        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: C=%d (32, 64 or 128; wider heads run unfused)", g->C);
+    if (g->C != 32 && g->C != 64 && g->C != 128 && g->C != 256)
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: C=%d (32, 64, 128 or 256; other widths run unfused)", g->C);
     ConvKArgs a;
     memset(&a, 0, sizeof(a));
     a.x1 = g->x;
@@ -531,7 +537,7 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     a.slope = g->slope;
     a.nci4 = ((g->C + 15) / 16) * 4;
     a.ncot = 2 * g->C / 16;
-    a.nchunks = g->C == 128 ? 4 : 1;   // C = 32 / 64: the whole reduction is one LDS-resident chunk
+    a.nchunks = g->C >= 128 ? g->C / 32 : 1;   // C = 32 / 64: the whole reduction is one LDS-resident chunk
     a.ksplit = 1;
     a.chunks_per_split = a.nchunks;
     a.tiles_y = 1;
@@ -548,9 +554,12 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     } else if (g->C == 64) {
         a.tiles_x = (a.W + 127) / 128;
         hipLaunchKernelGGL((conv_fwd_kernel<1, 128, 2, 4, 2, 2, 64, 1, true, 1>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
-    } else {
+    } else if (g->C == 128) {
         a.tiles_x = (a.W + 127) / 128;
         hipLaunchKernelGGL((conv_fwd_kernel<1, 128, 4, 4, 2, 2, 32, 1, true>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
+    } else {
+        a.tiles_x = (a.W + 63) / 64;
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 64, 4, 4, 4, 1, 32, 1, true>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
     }
     return check_launch("conv_fwd_kernel<fused head>");
 }
@@ -627,6 +636,12 @@ extern "C" int wmd_conv_fwd(const wmd_conv_args* g, void* stream) {
 // transposed/flipped weights, shift1 = 1 and an (H+2) x (W+2) logical extent).
 int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stream) {
     int st = WMD_OK;
+    // buffer descriptors address one image of a source tensor with 32-bit byte offsets below 2^31
+    const double lim = 2147483647.0;
+    if ((double)g->C1 * H1 * W1 * 4 > lim || (double)g->C2 * g->H * g->W * 4 > lim ||
+        (double)wmd_conv_packed_weight_floats(g->Cout, g->C1 + g->C2, g->ksize) * 4 > lim ||
+        (double)g->Cout * g->H * g->W * 4 > lim)
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: a per-image tensor slice or the weight image exceeds 2 GiB");
     ConvPlan plan;
     if (!plan_conv(g, &plan, g->workspace != nullptr, g->workspace_floats)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_fwd: no kernel configuration");
     const ConvCfg& c = *plan.cfg;

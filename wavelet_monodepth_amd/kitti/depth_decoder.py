@@ -125,12 +125,15 @@ class DepthWaveProgressiveDecoder(nn.Module):
             x = self.convs[("upconv", i, 0)](x)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip=skip, up=2)  # fused upsample + concat
-            fused = (not torch.is_grad_enabled()) and i < 4 and int(self.num_ch_dec[i]) in ops.FUSED_HEAD_WIDTHS \
-                and self.fuse_heads
+            fused = (not torch.is_grad_enabled()) and int(self.num_ch_dec[i]) in ops.FUSED_HEAD_WIDTHS and self.fuse_heads
             if fused:
                 # two launches per level: 1x1 -> LeakyReLU -> tap-partials (mid stays on chip), then the 9-tap gather +
                 # sigmoid + combine + Haar synthesis
                 hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
+                if i == 4:   # the LL head (C -> C/4 -> 1) exists only at the coarsest level; it runs unfused
+                    h0 = self.convs[("waveconv", i, 0)]
+                    mid0 = h0[0](x, act="leaky", slope=0.1)
+                    yl = ops.head3x3(mid0, h0[2].conv.weight, h0[2].conv.bias, pad="reflect", mode=1, scale=2.0 ** i)
                 yl_in = yl
                 yh, yl, disp = ops.head_fused_level_nograd(
                     x, (hp[0].conv.weight, hp[0].conv.bias, hp[2].conv.weight, hp[2].conv.bias),

@@ -369,7 +369,7 @@ def _tap_partial_pack(w3p, w3n):
     return wp
 
 
-FUSED_HEAD_WIDTHS = (32, 64, 128)
+FUSED_HEAD_WIDTHS = (32, 64, 128, 256)
 
 
 def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False):
