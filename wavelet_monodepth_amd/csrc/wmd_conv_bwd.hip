@@ -12,6 +12,7 @@
 //   dbias:    row sums of the dz tiles the wgrad blocks already hold in LDS, reduced with the weight partials.
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include "wmd_internal.h"
 
@@ -24,54 +25,74 @@ int run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stream);
 // ------------------------------------------------------------------------------------------------
 // dgrad stage 2: adjoint of pad + concat + upsample
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fold_rows(int y, int n, int pad_mode, int halo, int (&rows)[3]) {
-    // padded-domain indices (0 .. n+1) whose forward source is logical index y
-    int cnt = 0;
-    rows[cnt++] = y + halo;
-    if (!halo) return cnt;
-    if (pad_mode == WMD_PAD_REFLECT) {
-        if (y == 1) rows[cnt++] = 0;
-        if (y == n - 2) rows[cnt++] = n + 1;
-    } else if (pad_mode == WMD_PAD_REPLICATE) {
-        if (y == 0) rows[cnt++] = 0;
-        if (y == n - 1) rows[cnt++] = n + 1;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global load
+
+// One (image, channel) plane: out[y, x] = sum of the u x u padded-domain gradients that the forward gather read from
+// source pixel (y, x), plus -- on the (rare, divergent) border lines -- the halo rows / columns that reflect or
+// replicate padding mirrored onto it.  VEC: a thread owns 4 consecutive padded-domain columns (4/U outputs).
+template <int U, bool VEC>
+__device__ __forceinline__ void fold_plane(const float* __restrict__ gp, float* __restrict__ op, int H, int W, int pad_mode,
+                                           int halo) {
+    constexpr int NX = VEC ? 4 : U;       // padded-domain columns per thread
+    constexpr int VX = NX / U;            // outputs per thread
+    const int Wp = W + 2 * halo;
+    const int h_ = H / U, w_ = W / U, wq = w_ / VX;
+    const int lo_src = pad_mode == WMD_PAD_REFLECT ? 1 : 0, hi_src = W - (pad_mode == WMD_PAD_REFLECT ? 2 : 1);
+    const int lo_row = lo_src, hi_row = H - (pad_mode == WMD_PAD_REFLECT ? 2 : 1);
+    const bool folds = halo && pad_mode != WMD_PAD_ZERO;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < h_ * wq; i += gridDim.x * blockDim.x) {
+        const int y = i / wq, xq = i - y * wq;
+        const int X0 = xq * NX;
+        float o[VX];
+#pragma unroll
+        for (int e = 0; e < VX; ++e) o[e] = 0.f;
+        auto add_row = [&](int r) {
+            const float* p = gp + (size_t)r * Wp;
+            float v[NX];
+            if constexpr (VEC) {
+                const f32x4u q = *reinterpret_cast<const f32x4u*>(p + X0 + halo);
+                v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < NX; ++e) v[e] = p[X0 + halo + e];
+            }
+#pragma unroll
+            for (int e = 0; e < NX; ++e) {
+                float s = v[e];
+                if (folds && X0 + e == lo_src) s += p[0];
+                if (folds && X0 + e == hi_src) s += p[W + 1];
+                o[e / U] += s;
+            }
+        };
+#pragma unroll
+        for (int dy = 0; dy < U; ++dy) {
+            const int Y = y * U + dy;
+            add_row(Y + halo);
+            if (folds && Y == lo_row) add_row(0);
+            if (folds && Y == hi_row) add_row(H + 1);
+        }
+        float* dst = op + (size_t)y * w_ + xq * VX;
+        if constexpr (VX == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else if constexpr (VX == 2) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+        else dst[0] = o[0];
     }
-    return cnt;
 }
 
-__global__ void conv_dgrad_fold_kernel(const float* __restrict__ g, float* __restrict__ dx1, float* __restrict__ dx2,
-                                       int B, int C1, int C2, int H, int W, int up1, int pad_mode, int halo) {
-    const int Hp = H + 2 * halo, Wp = W + 2 * halo;
-    const int H1 = H / up1, W1 = W / up1;
-    const size_t n1 = dx1 ? (size_t)B * C1 * H1 * W1 : 0;
-    const size_t n2 = dx2 ? (size_t)B * C2 * H * W : 0;
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv_dgrad_fold_kernel(const float* __restrict__ g, float* __restrict__ dx1,
+                                                              float* __restrict__ dx2, int B, int C1, int C2, int H, int W,
+                                                              int up1, int pad_mode, int halo) {
+    // blockIdx.y = (image, channel) plane of the padded-domain gradient
     const int Cin = C1 + C2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
-        const bool first = i < n1;
-        size_t r = first ? i : i - n1;
-        const int w_ = first ? W1 : W, h_ = first ? H1 : H, c_ = first ? C1 : C2;
-        const int x = r % w_;
-        r /= w_;
-        const int y = r % h_;
-        r /= h_;
-        const int c = r % c_;
-        const int b = r / c_;
-        const int ch = first ? c : C1 + c;
-        const int u = first ? up1 : 1;
-        const float* gp = g + ((size_t)b * Cin + ch) * Hp * Wp;
-        float acc = 0.f;
-        for (int dy = 0; dy < u; ++dy) {
-            int rows[3];
-            const int nr = fold_rows(y * u + dy, H, pad_mode, halo, rows);
-            for (int dx = 0; dx < u; ++dx) {
-                int cols[3];
-                const int nc = fold_rows(x * u + dx, W, pad_mode, halo, cols);
-                for (int a = 0; a < nr; ++a)
-                    for (int q = 0; q < nc; ++q) acc += gp[(size_t)rows[a] * Wp + cols[q]];
-            }
-        }
-        (first ? dx1 : dx2)[first ? i : i - n1] = acc;
-    }
+    const int b = blockIdx.y / Cin, ch = blockIdx.y % Cin;
+    const bool first = ch < C1;
+    float* out = first ? dx1 : dx2;
+    if (!out) return;
+    const int u = first ? up1 : 1;
+    const float* gp = g + (size_t)blockIdx.y * (H + 2 * halo) * (W + 2 * halo);
+    float* op = out + ((size_t)b * (first ? C1 : C2) + (first ? ch : ch - C1)) * (H / u) * (W / u);
+    if (u == 2) fold_plane<2, VEC>(gp, op, H, W, pad_mode, halo);
+    else fold_plane<1, VEC>(gp, op, H, W, pad_mode, halo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,6 +304,92 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
+// Weight gradient of the wavelet heads' last convolution (Cout <= 4: an MFMA tile would be > 75 % padding):
+//   dW[co,ci,t] = sum_{b,y,x} dz[b,co,y,x] * pad(x)[b,ci,y+ky,x+kx]
+// One block per (input channel, image, row slab).  A thread owns one column of one of `nseg` row segments of the
+// slab and walks down it with the 3x3 window in registers (3 new loads of x + COUT of dz per pixel), 9*COUT
+// accumulators; then a wavefront shuffle + LDS reduction.  Channel-0 blocks also produce the bias partial sums.
+// Partials use the same [split][Cout*Cin*9 + Cout] layout as the MFMA path, so wgrad_reduce_kernel finishes both.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_wgrad_smallco_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                 float* __restrict__ partial, int C, int H, int W,
+                                                                 int pad_mode, int spi, int nseg, int want_bias) {
+    const int ci = blockIdx.x, split = blockIdx.y;
+    const int b = split / spi, sl = split - b * spi;
+    const int rps = (H + spi - 1) / spi;
+    const int r0 = sl * rps, r1 = min(H, r0 + rps);
+    const int rseg = (max(r1 - r0, 0) + nseg - 1) / nseg;
+    const size_t plane = (size_t)H * W;
+    const float* xp = x + ((size_t)b * C + ci) * plane;
+    const float* gp = dz + (size_t)b * COUT * plane;
+    float acc[COUT][9], bs[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        bs[co] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[co][t] = 0.f;
+    }
+    for (int item = threadIdx.x; item < W * nseg; item += 256) {
+        const int seg = item / W, xx = item - seg * W;
+        const int y0 = r0 + seg * rseg, y1 = min(r1, y0 + rseg);
+        if (y0 >= y1) continue;
+        int cx[3];
+        bool okx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            cx[d] = xx + d - 1;
+            okx[d] = pad_coord(cx[d], W, pad_mode);
+            cx[d] = min(max(cx[d], 0), W - 1);
+        }
+        auto load_row = [&](int yy, float* out) {
+            const bool oky = pad_coord(yy, H, pad_mode);
+            const float* rp = xp + (size_t)min(max(yy, 0), H - 1) * W;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = rp[cx[d]];
+                out[d] = (oky && okx[d]) ? v : 0.f;
+            }
+        };
+        float win[9];
+        load_row(y0 - 1, win);
+        load_row(y0, win + 3);
+#pragma unroll 4
+        for (int y = y0; y < y1; ++y) {   // unrolled: the next rows' loads are issued ahead of this row's FMAs
+            load_row(y + 1, win + 6);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float g = gp[co * plane + (size_t)y * W + xx];
+                bs[co] += g;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[co][t] = fmaf(g, win[t], acc[co][t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) win[t] = win[t + 3];
+        }
+    }
+    __shared__ float red[4][COUT * 10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            float s = t < 9 ? acc[co][t] : bs[co];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) red[wave][co * 10 + t] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < COUT * 10) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const int co = threadIdx.x / 10, t = threadIdx.x % 10;
+        const size_t nw = (size_t)COUT * C * 9;
+        float* out = partial + (size_t)split * (nw + COUT);
+        if (t < 9) out[((size_t)co * C + ci) * 9 + t] = s;
+        else if (want_bias && ci == 0) out[nw + co] = s;
+    }
+}
+
 struct WgradCfg {
     int TH, TW, MR, NC, WM, WN, TAPS;
     void (*launch)(const WgradKArgs&, dim3, hipStream_t);
@@ -302,8 +409,8 @@ static void launch_wgrad(const WgradKArgs& a, dim3 grid, hipStream_t s) {
 static const WgradCfg kWCfgs[] = {
     WMD_WCFG(2, 32, 1, 1, 4, 1, 9),   // co64 x ci16, 64-pixel tiles
     WMD_WCFG(2, 32, 1, 1, 2, 2, 9),   // co32 x ci32
-    WMD_WCFG(2, 40, 1, 1, 4, 1, 9),   // 40-wide rows
-    WMD_WCFG(2, 40, 1, 1, 2, 2, 9),
+    WMD_WCFG(1, 40, 1, 1, 4, 1, 9),   // 40-wide rows: one row per tile keeps the double buffer at 50 KB (3 blocks / CU;
+    WMD_WCFG(1, 40, 1, 1, 2, 2, 9),   //   the 2 x 40 tile needs 91 KB = 1 block / CU and ran at 50 instead of 76 TFLOP/s)
     WMD_WCFG(2, 20, 1, 1, 4, 1, 9),   // 20-wide rows (coarsest 640-wide level, NYUv2 15x20)
     WMD_WCFG(2, 20, 1, 1, 2, 2, 9),
     WMD_WCFG(1, 64, 1, 4, 4, 1, 1),   // 1x1: co64 x ci64 over 64 flattened pixels
@@ -430,15 +537,52 @@ extern "C" int wmd_conv_dgrad(const wmd_conv_dgrad_args* g, void* stream) {
     if (st || dgrad_direct(g)) return st;
     const size_t n = (g->dx1 ? (size_t)g->B * g->C1 * (g->H / g->up1) * (g->W / g->up1) : 0) +
                      (g->dx2 ? (size_t)g->B * g->C2 * g->H * g->W : 0);
-    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 16);
+    // a thread folds 4 padded-domain columns when rows split into whole quads (dx pointers come 16-byte aligned
+    // from the caller's allocator; the scalar kernel covers everything else)
+    const bool vec = g->W % 4 == 0 && ((uintptr_t)g->dx1 % 16 == 0) && ((uintptr_t)g->dx2 % 16 == 0);
+    const int work = g->H * g->W / (vec ? 4 : 1);
+    const dim3 grid(std::max(1, std::min((work + 255) / 256, 64)), g->B * (g->C1 + g->C2));
     ProfScope prof("conv_dgrad_fold_kernel", (double)n, 4.0 * (gsz + n), (hipStream_t)stream);
-    hipLaunchKernelGGL(conv_dgrad_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gbuf, g->dx1, g->dx2, g->B,
-                       g->C1, g->C2, g->H, g->W, g->up1, g->pad_mode, halo);
+    if (vec)
+        hipLaunchKernelGGL(conv_dgrad_fold_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, gbuf, g->dx1, g->dx2, g->B, g->C1,
+                           g->C2, g->H, g->W, g->up1, g->pad_mode, halo);
+    else
+        hipLaunchKernelGGL(conv_dgrad_fold_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, gbuf, g->dx1, g->dx2, g->B, g->C1,
+                           g->C2, g->H, g->W, g->up1, g->pad_mode, halo);
     return check_launch("conv_dgrad_fold_kernel");
+}
+
+static bool smallco_wgrad(const wmd_conv_wgrad_args* g) {
+    return g->Cout <= 4 && g->ksize == 3 && g->up1 == 1 && g->C2 == 0;
+}
+struct SmallcoPlan {
+    int spi;    // row slabs per image
+    int nseg;   // row segments per slab walked concurrently by one block
+    int nsplit; // B * spi partial-sum slices
+};
+static SmallcoPlan smallco_plan(const wmd_conv_wgrad_args* g) {
+    SmallcoPlan p;
+    // ~4 blocks per CU over (channels x images x slabs) -- the column walk is latency bound, it wants waves --
+    // slabs of at least 8 rows
+    long spi = (4L * kNumCU + (long)g->C1 * g->B - 1) / ((long)g->C1 * g->B);
+    spi = std::max<long>(1, std::min<long>(spi, std::max(1, g->H / 8)));
+    p.spi = (int)spi;
+    const int rps = (g->H + p.spi - 1) / p.spi;
+    // segments: fill the 256 threads with whole columns, but keep the 2-row window prologue amortised
+    double best = -1.0;
+    p.nseg = 1;
+    for (int n = 1; n <= std::min(8, rps); ++n) {
+        const int items = g->W * n, passes = (items + 255) / 256, rseg = (rps + n - 1) / n;
+        const double score = (double)items / (passes * 256.0) * rseg / (rseg + 2.0);
+        if (score > best) { best = score; p.nseg = n; }
+    }
+    p.nsplit = g->B * p.spi;
+    return p;
 }
 
 extern "C" size_t wmd_conv_wgrad_workspace_floats(const wmd_conv_wgrad_args* g) {
     if (!g || g->B <= 0 || g->Cout <= 0) return 0;
+    if (smallco_wgrad(g)) return (size_t)smallco_plan(g).nsplit * ((size_t)g->Cout * g->C1 * 9 + g->Cout);
     WgradPlan p;
     if (!plan_wgrad(g, &p)) return 0;
     const int taps = g->ksize == 3 ? 9 : 1;
@@ -454,6 +598,31 @@ extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
     if (g->ksize == 1 && g->up1 == 2) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: 1x1 with upsampled input");
     if ((double)std::max(g->C1, std::max(g->C2, g->Cout)) * g->H * g->W * 4 > 2147483647.0)
         return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: a per-image tensor slice exceeds 2 GiB");
+    if (smallco_wgrad(g)) {
+        const size_t nw = (size_t)g->Cout * g->C1 * 9;
+        const SmallcoPlan sp = smallco_plan(g);
+        const int nsplit = sp.nsplit;
+        if (!g->workspace || g->workspace_floats < (nw + g->Cout) * nsplit)
+            return fail(WMD_ERR_WORKSPACE, "wmd_conv_wgrad: workspace %zu < %zu floats", g->workspace_floats, (nw + g->Cout) * nsplit);
+        hipStream_t s = (hipStream_t)stream;
+        const double pix = (double)g->B * g->H * g->W;
+        {
+            ProfScope prof("conv_wgrad_smallco_kernel", 18.0 * g->C1 * g->Cout * pix, 4.0 * pix * (g->C1 + g->Cout), s);
+            const dim3 grid(g->C1, nsplit);
+            switch (g->Cout) {
+                case 1: hipLaunchKernelGGL(conv_wgrad_smallco_kernel<1>, grid, dim3(256), 0, s, g->x1, g->dz, g->workspace, g->C1, g->H, g->W, g->pad_mode, sp.spi, sp.nseg, g->dbias != nullptr); break;
+                case 2: hipLaunchKernelGGL(conv_wgrad_smallco_kernel<2>, grid, dim3(256), 0, s, g->x1, g->dz, g->workspace, g->C1, g->H, g->W, g->pad_mode, sp.spi, sp.nseg, g->dbias != nullptr); break;
+                case 3: hipLaunchKernelGGL(conv_wgrad_smallco_kernel<3>, grid, dim3(256), 0, s, g->x1, g->dz, g->workspace, g->C1, g->H, g->W, g->pad_mode, sp.spi, sp.nseg, g->dbias != nullptr); break;
+                default: hipLaunchKernelGGL(conv_wgrad_smallco_kernel<4>, grid, dim3(256), 0, s, g->x1, g->dz, g->workspace, g->C1, g->H, g->W, g->pad_mode, sp.spi, sp.nseg, g->dbias != nullptr); break;
+            }
+        }
+        st = check_launch("conv_wgrad_smallco_kernel");
+        if (st) return st;
+        ProfScope prof("wgrad_reduce_kernel", (double)nw * nsplit, 4.0 * nw * (nsplit + 1), s);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + g->Cout + 63) / 64)), dim3(1024), 0, s, g->workspace, g->dw,
+                           g->dbias, nw, g->Cout, nsplit);
+        return check_launch("wgrad_reduce_kernel");
+    }
     WgradPlan p;
     if (!plan_wgrad(g, &p)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_wgrad: no kernel configuration");
     const int taps = g->ksize == 3 ? 9 : 1;

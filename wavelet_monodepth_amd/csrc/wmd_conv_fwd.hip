@@ -71,8 +71,8 @@ struct ConvTile {
     static constexpr int NAV = (A_FLOATS / 4 + NT - 1) / NT;  // 16-byte weight pieces per thread and chunk
     static constexpr int LDS_FLOATS = NBUF * (B_FLOATS + A_FLOATS);  // NBUF = 1: the whole reduction is one chunk
     static_assert(WN * NR * 16 >= NPIX, "tile has more pixels than MFMA columns");
-    static_assert(CK % 8 == 0, "CK must be a multiple of 8 (an even number of 4-channel K-steps)");
-    static_assert((A_FLOATS / 4) % 64 == 0, "the weight tile must be a whole number of 64-lane 16-byte pieces");
+    static_assert(CK % 4 == 0, "CK must be a whole number of 4-channel K-steps");
+    static_assert(A_FLOATS % 4 == 0, "the weight tile is moved in 16-byte pieces (a partial last wave is exec-masked)");
     static_assert(TW % 4 == 0, "four consecutive pixels of an accumulator row must not straddle image rows");
 };
 
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         float* dstA = ldsA + buf * T::A_FLOATS + wave * 256;
 #pragma unroll
         for (int v = 0; v < T::NAV; ++v) {
-            if (T::NAV * NT * 4 == T::A_FLOATS || (tid + v * NT) * 4 < T::A_FLOATS)  // whole waves by construction
+            if (T::NAV * NT * 4 == T::A_FLOATS || (tid + v * NT) * 4 < T::A_FLOATS)  // partial last wave: exec-masked
                 lds_dma16(rw, (lds_ptr_t)(dstA + v * NT * 4), aoff[v], soffA);
         }
     };
@@ -415,6 +415,15 @@ static const ConvCfg kCfgs[] = {
     WMD_CFG(4, 32, 4, 2, 1, 4, 8, 9),   // co64  x 128px
     WMD_CFG(2, 32, 4, 2, 2, 2, 8, 9),   // co128 x 64px
     WMD_CFG(5, 32, 4, 5, 2, 2, 8, 9),   // co128 x 160px  (H % 5: 10x32 coarsest level of 1024x320)
+    WMD_CFG(4, 32, 2, 2, 1, 4, 8, 9),   // co32  x 128px (32 KB of LDS: 5 blocks per CU)
+    WMD_CFG(8, 32, 2, 4, 1, 4, 4, 9),   // co32  x 256px, 4-channel chunks (21 KB)
+    WMD_CFG(4, 32, 4, 2, 1, 4, 4, 9),   // co64  x 128px, 4-channel chunks (25 KB)
+    WMD_CFG(2, 40, 1, 5, 2, 1, 8, 9),   // co32  x 80px, 2 waves: enough blocks on 12x40 / 24x80 without split-K
+    WMD_CFG(2, 40, 2, 5, 2, 1, 8, 9),   // co64  x 80px, 2 waves
+    WMD_CFG(4, 40, 1, 5, 2, 2, 8, 9),   // co32  x 160px, 4 waves
+    WMD_CFG(4, 40, 2, 5, 2, 2, 4, 9),   // co64  x 160px, 4-channel chunks
+    WMD_CFG(4, 40, 4, 5, 2, 2, 4, 9),   // co128 x 160px, 4-channel chunks
+    WMD_CFG(4, 32, 2, 4, 1, 2, 8, 9),   // co32  x 128px, 2 waves
     WMD_CFG(8, 32, 4, 4, 2, 4, 8, 9),   // co128 x 256px, 8 waves
     WMD_CFG(8, 32, 2, 4, 2, 4, 8, 9),   // co64  x 256px, 8 waves
     WMD_CFG(4, 32, 2, 4, 2, 2, 8, 9),   // co64  x 128px, 2x2 waves
