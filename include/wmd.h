@@ -236,6 +236,32 @@ typedef struct {
 } wmd_head_shiftsum_args;
 int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* args, void* stream);
 
+/* Single-launch inference form of a level's two high-frequency heads AND the Haar synthesis that consumes them
+ * (depth_decoder.py:108-136,164-166): 1x1 -> LeakyReLU -> 3x3 (as tap-partials) -> sigmoid -> 2^(s-1)(sig+ - sig-)
+ * -> IDWT -> clamp, with every intermediate in LDS (wmd_head_level.hip).  Same operands as wmd_head_fused_fwd +
+ * wmd_head_shiftsum_fwd, which remain the route for the widths this kernel does not cover.
+ * wmd_head_level_supported(C) != 0 for C in {32, 64}.                                                            */
+typedef struct {
+    int B, H, W, C;
+    int pad_mode;        /* padding of the 3x3 (reflect for the KITTI heads)                                  */
+    float slope;         /* LeakyReLU slope of the 1x1 (0.1)                                                  */
+    float scale;         /* 2^(s-1)                                                                           */
+    const float* x;      /* [B,C,H,W]                                                                         */
+    const float* wp1;    /* packed stacked [2C,C,1,1] filter, + rows first (wmd_conv_pack_weights)            */
+    const float* bias1;  /* [2C] or NULL                                                                      */
+    const float* wp2;    /* two packed [27,C,1,1] images (row co*9+tap), + then -                             */
+    const float* bias_p; /* [3] or NULL                                                                       */
+    const float* bias_n; /* [3] or NULL                                                                       */
+    float* yh;           /* [B,3,H,W]                                                                         */
+    const float* yl;     /* optional [B,H,W]: fused wmd_idwt_haar_fwd                                         */
+    float* out;          /* [B,2H,2W] (with yl)                                                               */
+    float* disp;         /* optional [B,2H,2W] = clamp(out * disp_scale)                                      */
+    float disp_scale;
+    int clamp01;
+} wmd_head_level_args;
+int wmd_head_level_supported(int C);
+int wmd_head_level_fwd(const wmd_head_level_args* args, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Sparse (threshold-gated) decoder path, batch 1
  *

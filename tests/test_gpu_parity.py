@@ -271,9 +271,11 @@ def test_kitti_dense_decoder_graph_replay_and_grad_mode_paths_agree(dev):
             assert_close(a[k], b[k], 2e-6, "graph vs eager " + key_str(k))
 
 
-@pytest.mark.parametrize("C,H,W", [(32, 12, 40), (64, 9, 28), (128, 6, 20), (256, 12, 40), (32, 5, 7)])
+@pytest.mark.parametrize("C,H,W", [(32, 12, 40), (64, 9, 28), (128, 6, 20), (256, 12, 40), (32, 5, 7), (32, 10, 84),
+                                   (64, 48, 160), (32, 2, 2)])
 def test_fused_head_level_vs_oracle(dev, C, H, W):
-    """wmd_head_fused_fwd + wmd_head_shiftsum_fwd == Conv1x1 -> LeakyReLU -> Conv3x3(refl) -> sigmoid combine -> IDWT."""
+    """wmd_head_level_fwd (C = 32, 64: one launch) and wmd_head_fused_fwd + wmd_head_shiftsum_fwd (other widths)
+    == Conv1x1 -> LeakyReLU -> Conv3x3(refl) -> sigmoid combine -> IDWT; tiles with overhang in both directions."""
     from wavelet_monodepth_amd import ops
     B, s = 2, 2
     x = t(synth.normal((B, C, H, W), "fx", 6))

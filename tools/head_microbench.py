@@ -25,3 +25,19 @@ for C, H, W in [(256, 12, 40), (128, 24, 80), (64, 48, 160), (32, 96, 320)]:
     us = recs[0]["ms"] / recs[0]["calls"] * 1e3
     fl = 2 * 2 * 27 * C * B * H * W
     print("head3x3 C=%3d %3dx%-3d: %7.1f us  %5.1f TFLOP/s" % (C, H, W, us, fl / us / 1e6))
+
+# full level (both heads + IDWT), one-launch vs two-launch form (WMD_TWO_LAUNCH_HEAD=1)
+for C, H, W in [(256, 12, 40), (128, 24, 80), (64, 48, 160), (32, 96, 320)]:
+    x = torch.randn(B, C, H, W, device=dev)
+    yl = torch.randn(B, 1, H, W, device=dev)
+    mk = lambda: (torch.randn(C, C, 1, 1, device=dev) * 0.1, torch.randn(C, device=dev), torch.randn(3, C, 3, 3, device=dev) * 0.05,
+                  torch.randn(3, device=dev))
+    hp, hn = mk(), mk()
+    for _ in range(3):
+        ops.head_fused_level_nograd(x, hp, hn, 2.0, yl, 0.5, True)
+    torch.cuda.synchronize()
+    _lib.profile_begin()
+    for _ in range(20):
+        ops.head_fused_level_nograd(x, hp, hn, 2.0, yl, 0.5, True)
+    recs = _lib.profile_end()
+    print("level C=%3d %3dx%-3d: %s" % (C, H, W, ", ".join("%s %.1f us" % (r["kernel"], r["ms"] / r["calls"] * 1e3) for r in recs)))

@@ -53,6 +53,15 @@ class HeadFusedArgs(C.Structure):
                 ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p), ("t", C.c_void_p)]
 
 
+class HeadLevelArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("pad_mode", C.c_int),
+                ("slope", C.c_float), ("scale", C.c_float),
+                ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p),
+                ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
+                ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
+                ("clamp01", C.c_int)]
+
+
 class HeadShiftsumArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pad_mode", C.c_int), ("scale", C.c_float),
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
@@ -105,6 +114,8 @@ SIGNATURES = {
     "wmd_head3x3_workspace_floats": (C.c_size_t, [C.POINTER(HeadArgs)]),
     "wmd_head_fused_fwd": (C.c_int, [C.POINTER(HeadFusedArgs), C.c_void_p]),
     "wmd_head_shiftsum_fwd": (C.c_int, [C.POINTER(HeadShiftsumArgs), C.c_void_p]),
+    "wmd_head_level_supported": (C.c_int, [C.c_int]),
+    "wmd_head_level_fwd": (C.c_int, [C.POINTER(HeadLevelArgs), C.c_void_p]),
     "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "wmd_internal.h"
 
 namespace wmd {
@@ -164,32 +165,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         aoff[v] = (unsigned)(((size_t)cot * a.nci4 * TAPS * 64 + rem) * 4);
     }
 
-    // issue the DMA of one chunk (patch + weights) into LDS buffer `buf`; completion = vmcnt(0) + barrier
-    auto stage = [&](int chunk, int buf) {
-        const int c0 = chunk * CK;
-        float* dstB = lds + buf * T::B_FLOATS + wave * 64;  // + lane*4 bytes is added by the hardware
-#pragma unroll
-        for (int j = 0; j < CK; ++j) {
-            const int ci = c0 + j;  // wave-uniform
+    // DMA of one chunk (patch + weights) into LDS buffer `buf`, as NPIECES wave-instructions per wave; completion =
+    // vmcnt(0) + barrier.  `q` is a compile-time constant wherever this is called (fully unrolled loops).
+    constexpr int NPB = CK * NPOS, NPIECES = NPB + T::NAV;
+    auto stage_piece = [&](int chunk, int buf, int q) {
+        if (q < NPB) {
+            const int j = q / NPOS, i = q % NPOS;
+            const int ci = chunk * CK + j;  // wave-uniform
             const bool from_x1 = ci < a.C1;
             const bool chan_ok = ci < a.Cin;
             const unsigned soff = from_x1 ? (unsigned)ci * pb1 : (unsigned)max(ci - a.C1, 0) * pb2;
-#pragma unroll
-            for (int i = 0; i < NPOS; ++i) {
-                if (NPOS * NT == T::NPOSITIONS || tid + i * NT < T::NPOSITIONS) {  // partial last wave: exec-masked
-                    const unsigned vo = chan_ok ? (from_x1 ? ob1[i] : ob2[i]) : kOOB;
-                    lds_ptr_t d = (lds_ptr_t)(dstB + j * PS + i * NT);
-                    if (from_x1) lds_dma4(r1, d, vo, soff);
-                    else lds_dma4(r2, d, vo, soff);
-                }
+            if (NPOS * NT == T::NPOSITIONS || tid + i * NT < T::NPOSITIONS) {  // partial last wave: exec-masked
+                const unsigned vo = chan_ok ? (from_x1 ? ob1[i] : ob2[i]) : kOOB;
+                lds_ptr_t d = (lds_ptr_t)(lds + buf * T::B_FLOATS + wave * 64 + j * PS + i * NT);  // + lane*4 bytes by the hardware
+                if (from_x1) lds_dma4(r1, d, vo, soff);
+                else lds_dma4(r2, d, vo, soff);
             }
-        }
-        const unsigned soffA = (unsigned)chunk * (unsigned)(T::A_RUN * 4);  // K-steps of a chunk are contiguous
-        float* dstA = ldsA + buf * T::A_FLOATS + wave * 256;
-#pragma unroll
-        for (int v = 0; v < T::NAV; ++v) {
+        } else {
+            const int v = q - NPB;
+            const unsigned soffA = (unsigned)chunk * (unsigned)(T::A_RUN * 4);  // K-steps of a chunk are contiguous
             if (T::NAV * NT * 4 == T::A_FLOATS || (tid + v * NT) * 4 < T::A_FLOATS)  // partial last wave: exec-masked
-                lds_dma16(rw, (lds_ptr_t)(dstA + v * NT * 4), aoff[v], soffA);
+                lds_dma16(rw, (lds_ptr_t)(ldsA + buf * T::A_FLOATS + wave * 256 + v * NT * 4), aoff[v], soffA);
         }
     };
 
@@ -215,32 +211,59 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const int c_begin = ks * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
 
-    if (c_begin < c_end) stage(c_begin, 0);
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
+    }
     __syncthreads();  // (hipcc drains the DMA with vmcnt(0) ahead of the barrier)
 
-    for (int c = c_begin; c < c_end; ++c) {
+    // One chunk of the reduction.  Software pipeline over its S = KSTEPS*TAPS (K-step, tap) groups: the fragments of
+    // group s+D are requested before the MFMAs of group s are issued, so a ds_read has D groups (>= 160 MFMA cycles
+    // each for NR = 5) to land; with PREFETCH the next chunk's DMA pieces are dealt out one or two per group over
+    // the first two thirds of the chunk, in the shadow of the MFMAs, instead of as one burst that stalls the wave
+    // (an LDS-DMA piece costs 60-180 issue cycles, MI355X_MICROARCH.md).  sched_barrier pins that order (left
+    // alone, the scheduler sinks the reads next to their uses and hoists the DMA into one block).
+    auto chunk_body = [&](int c, auto prefetch) {
+        constexpr bool PREFETCH = decltype(prefetch)::value;
+        constexpr int S = KSTEPS * TAPS, D = S >= 3 ? 2 : 1, RS = D + 1;
+        constexpr int SP = (S * 2) / 3 > 0 ? (S * 2) / 3 : 1;
         const int buf = (c - c_begin) & 1;
-        if (NBUF == 2 && c + 1 < c_end) stage(c + 1, buf ^ 1);  // wave-uniform branch; the other buffer was released by the last barrier
         const float* bsrc = lds + buf * T::B_FLOATS;
         const float* asrc = ldsA + buf * T::A_FLOATS + a_lane;
+        float pf[RS][NR], wf[RS][MR];
+        auto fetch = [&](int s) {
+            const int kk = s / TAPS, tp = s % TAPS, slot = s % RS;
+            const int ky = (TAPS == 9) ? tp / 3 : 0, kx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
+            for (int m = 0; m < MR; ++m) wf[slot][m] = asrc[m * T::A_RUN + (kk * TAPS + tp) * 64];
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) {
-                const int ky = (TAPS == 9) ? tp / 3 : 0, kx = (TAPS == 9) ? tp % 3 : 0;
-                float pf[NR], wf[MR];
+            for (int n = 0; n < NR; ++n) pf[slot][n] = bsrc[boff[n] + kk * 4 * PS + ky * PW + kx];
+        };
 #pragma unroll
-                for (int m = 0; m < MR; ++m) wf[m] = asrc[m * T::A_RUN + (kk * TAPS + tp) * 64];
+        for (int s = 0; s < D && s < S; ++s) fetch(s);
 #pragma unroll
-                for (int n = 0; n < NR; ++n) pf[n] = bsrc[boff[n] + kk * 4 * PS + ky * PW + kx];
+        for (int s = 0; s < S; ++s) {
+            if constexpr (PREFETCH) {
 #pragma unroll
-                for (int m = 0; m < MR; ++m)
-#pragma unroll
-                    for (int n = 0; n < NR; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[n], wf[m], acc[m][n], 0, 0, 0);
+                for (int q = 0; q < NPIECES; ++q)
+                    if (q * SP / NPIECES == s) stage_piece(c + 1, buf ^ 1, q);
             }
+            if (s + D < S) fetch(s + D);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[s % RS][n], wf[s % RS][m], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        __syncthreads();  // next buffer landed (vmcnt(0) precedes the barrier), this one is released
+    };
+    if constexpr (NBUF == 2) {
+        for (int c = c_begin; c + 1 < c_end; ++c) chunk_body(c, std::true_type{});
+        if (c_begin < c_end) chunk_body(c_end - 1, std::false_type{});
+    } else {
+        for (int c = c_begin; c < c_end; ++c) chunk_body(c, std::false_type{});
     }
 
     if constexpr (FUSE) {

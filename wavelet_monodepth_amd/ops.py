@@ -370,6 +370,7 @@ def _tap_partial_pack(w3p, w3n):
 
 
 FUSED_HEAD_WIDTHS = (32, 64, 128, 256)
+_TWO_LAUNCH_HEAD = os.environ.get("WMD_TWO_LAUNCH_HEAD", "0") == "1"   # development switch: A/B the two forms
 
 
 def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False):
@@ -383,16 +384,24 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
     (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
     wp1, bias1 = stacked_pack([w1p, w1n], [b1p, b1n])
     wp2 = _tap_partial_pack(w3p, w3n)
-    t = torch.empty((B, 54, H, W), device=x.device, dtype=torch.float32)
     s = current_stream()
-    a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t))
-    check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
     yh = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
     out = disp = None
     if yl is not None:
         yl = _c(yl)
         out = torch.empty((B, 1, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
         disp = torch.empty_like(out) if disp_scale is not None else None
+    if l.wmd_head_level_supported(Cc) and not _TWO_LAUNCH_HEAD:
+        # one launch: every intermediate of the level stays in LDS
+        a = _lib.HeadLevelArgs(B=B, H=H, W=W, C=Cc, pad_mode=PAD["reflect"], slope=0.1, scale=float(scale), x=ptr(x),
+                               wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), bias_p=ptr(b3p), bias_n=ptr(b3n), yh=ptr(yh),
+                               yl=ptr(yl), out=ptr(out), disp=ptr(disp), disp_scale=float(disp_scale or 1.0),
+                               clamp01=int(clamp01))
+        check(l.wmd_head_level_fwd(C.byref(a), s), "wmd_head_level_fwd")
+        return yh.unsqueeze(1), out, disp
+    t = torch.empty((B, 54, H, W), device=x.device, dtype=torch.float32)
+    a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t))
+    check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
     g = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scale), t=ptr(t), bias_p=ptr(b3p),
                               bias_n=ptr(b3n), yh=ptr(yh), yl=ptr(yl), out=ptr(out), disp=ptr(disp),
                               disp_scale=float(disp_scale or 1.0), clamp01=int(clamp01))
