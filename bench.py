@@ -172,7 +172,9 @@ def main():
     from wavelet_monodepth_amd import _lib, tuner
     _lib.lib()  # fail loudly if the HIP library is missing
     # tile/split-K choices measured for this workload in an earlier run (any missing key is tuned in the warm-up)
-    tuner.preload(os.path.join(ROOT, "profiles", "r01_tune_cache_config2.json"))
+    # (WMD_BENCH_RETUNE=1 ignores the committed choices: used to regenerate that file after kernel changes)
+    if os.environ.get("WMD_BENCH_RETUNE", "0") != "1":
+        tuner.preload(os.path.join(ROOT, "profiles", "r01_tune_cache_config2.json"))
 
     if args.workload == "train":
         train_main(args, rank, local_rank, world, dev)

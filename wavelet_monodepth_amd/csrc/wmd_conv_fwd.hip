@@ -459,6 +459,8 @@ static const ConvCfg kCfgs[] = {
     WMD_CFG(3, 40, 4, 4, 1, 2, 8, 9),   // co64  x 120px (H = 15/30/60 ...)
     // 3x3, 20-wide rows (coarsest 640-wide level, NYUv2 15x20)
     WMD_CFG(6, 20, 4, 4, 2, 2, 8, 9),   // co128 x 120px
+    WMD_CFG(6, 20, 2, 4, 2, 2, 8, 9),   // co64  x 120px (48 KB: 3 blocks per CU)
+    WMD_CFG(6, 20, 2, 4, 1, 2, 8, 9),   // co32  x 120px, 2 waves
     WMD_CFG(3, 20, 4, 4, 1, 1, 8, 9),   // co64  x 60px, single wave
     WMD_CFG(5, 20, 4, 7, 1, 1, 8, 9),   // co64  x 100px, single wave
     // generic small tile (any W)
