@@ -258,7 +258,7 @@ def main():
                                    "(BASELINE.json configs[1]); encoder features resident in HBM",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d (independent shards)" % world},
             "roofline": roof,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(dec, feats),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dec, feats),   # rank 0, N=1 only
         }
         print(json.dumps(res))
     if world > 1:

@@ -9,16 +9,18 @@
 // NYUv2/networks/layers.py:11-32,57-67).
 //
 // GEMM view: M = Cout, N = pixels of a TH x TW tile of one image, K = Cin*k*k.
-//   A (weights)  : read straight from a fragment-ordered global image (wmd_conv_pack_weights) -
-//                  one fully coalesced 256-byte wave load per 16co x 4ci x tap fragment, register
-//                  double-buffered one K-step ahead.
-//   B (pixels)   : a CK-channel halo patch staged global -> registers -> LDS (double-buffered,
-//                  one barrier per CK channels); every lane reads its B element with ds_read_b32
-//                  at a compile-time offset (tap and channel are immediates).
-//   D            : MR x NR accumulator fragments (16x16) per wave; lane (l&15) = pixel,
-//                  (l>>4)*4+r = out-channel inside the fragment.
-// fp32 MFMA issues once per 32 cycles per SIMD, so one A load + one B ds_read per 16 MFMAs keeps the
-// matrix pipe as the only saturated unit; the kernel is MFMA-bound by construction.
+//   B (pixels)   : a CK-channel halo patch gathered by LDS-DMA (buffer_load_dword ... lds) into a position-linear
+//                  LDS image, double-buffered, one barrier per CK channels; every lane reads its B element with
+//                  ds_read_b32 at a compile-time offset (tap and channel are immediates).
+//   A (weights)  : the block's slice of the fragment-ordered global image (wmd_conv_pack_weights), copied into LDS
+//                  by 16-byte LDS-DMA with the same chunk; one ds_read_b32 per 16co x 4ci x tap fragment.
+//   D            : MR x NR accumulator fragments (16x16) per wave; lane (l&15) = out-channel, (l>>4)*4+r = pixel
+//                  (MFMA roles swapped, see below) -> 16-byte stores.
+// fp32 MFMA issues once per 32 cycles per SIMD; one A read + NR B reads feed MR*NR MFMAs, so the matrix pipe is the
+// only unit that can saturate: the kernel is MFMA-bound by construction (measured 0.62-0.73 MFMA-busy).
+// Split-K (coarse levels) keeps a second, HBM-bound reduce launch: finishing the tile in the last-arriving block
+// needs agent-scope release/acquire fences, which write back / invalidate the XCD's whole L2 on gfx950 -- measured
+// 2-6x SLOWER than the two-launch form (every other block loses its weight and halo lines), so it was dropped.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
