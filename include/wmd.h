@@ -352,6 +352,41 @@ int wmd_comm_init(wmd_comm** comm, const void* unique_id_128, int world, int ran
 int wmd_comm_allreduce(wmd_comm* comm, float* buf, size_t n, float scale, void* stream);
 int wmd_comm_destroy(wmd_comm* comm);
 
+/* ------------------------------------------------------------------ *
+ * Evaluation arithmetic behind the reference's accuracy claims; batches stay in HBM.
+ * ------------------------------------------------------------------ */
+
+/* Per-image chain of KITTI/evaluate_depth.py:268-307 for B images of one size:
+ *   pred_disp [B,h,w] --cv2.resize (bilinear, half-pixel centres, edge clamp)--> [B,H,W] --> depth = pred_scale / disp
+ *   mask_mode 1: Eigen split: min_depth < gt < max_depth inside the Garg crop (:284-290); 0: gt > 0 (:293)
+ *   median_scaling != 0: depth *= median(gt[mask]) / median(depth[mask])  (:298-301; np.median = mean of the two middle values)
+ *   depth = clamp(depth, min_depth, max_depth) (:304-305); compute_errors (:50-68)
+ * out [B,9] = abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, log10, n_valid  (a row of NaN + 0 when the mask is empty);
+ * the applied ratio of image b is left in workspace (see wmd_eval_workspace_floats) for the caller to read.        */
+typedef struct {
+    int B, h, w, H, W;
+    float min_depth, max_depth;   /* 1e-3, 80 (evaluate_depth.py:85-86)                    */
+    int mask_mode;
+    float pred_scale;             /* pred_depth_scale_factor (5.4 for stereo, :35)         */
+    int median_scaling;
+    const float* pred_disp;
+    const float* gt_depth;
+    float* out;
+    float* workspace;             /* wmd_eval_workspace_floats(B, H, W)                    */
+    size_t workspace_floats;
+} wmd_eval_kitti_args;
+size_t wmd_eval_workspace_floats(int B, int H, int W);
+int wmd_eval_kitti(const wmd_eval_kitti_args* args, void* stream);
+
+/* compute_errors (KITTI/evaluate_depth.py:50-68) and compute_errors_nyu (NYUv2/utils.py:85-98) on B prepared
+ * arrays of n_per_image positive values each: out9 [B,9] as above (NYUv2 reads abs_rel, rmse, log10, a1..a3).
+ * Entries with gt < 0 are skipped (masked).                                                                      */
+int wmd_eval_errors(const float* pred, const float* gt, int B, size_t n_per_image, float* out9, void* stream);
+
+/* batch_post_process_disparity (KITTI/evaluate_depth.py:71-79) with the [:, :, ::-1] flip of the second operand
+ * (:204) fused: r_disp is the raw prediction for the mirrored image.  l_disp, r_disp, out: [B,h,w].              */
+int wmd_flip_postprocess(const float* l_disp, const float* r_disp, float* out, int B, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

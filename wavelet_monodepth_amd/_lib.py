@@ -62,6 +62,13 @@ class HeadLevelArgs(C.Structure):
                 ("clamp01", C.c_int)]
 
 
+class EvalKittiArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("h", C.c_int), ("w", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("mask_mode", C.c_int), ("pred_scale", C.c_float),
+                ("median_scaling", C.c_int), ("pred_disp", C.c_void_p), ("gt_depth", C.c_void_p), ("out", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+
+
 class HeadShiftsumArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pad_mode", C.c_int), ("scale", C.c_float),
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
@@ -123,6 +130,10 @@ SIGNATURES = {
     "wmd_sparse_conv": (C.c_int, [C.POINTER(SparseConvArgs), C.c_void_p]),
     "wmd_upsample_bilinear_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
     "wmd_upsample_bilinear_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
+    "wmd_eval_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "wmd_eval_kitti": (C.c_int, [C.POINTER(EvalKittiArgs), C.c_void_p]),
+    "wmd_eval_errors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "wmd_flip_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wmd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wmd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "wmd_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),

@@ -1,0 +1,373 @@
+// Evaluation arithmetic that follows the decoder -- the numbers the reference's "abs_rel within
+// 0.001" claims are quoted on:
+//   KITTI/evaluate_depth.py:50-68    compute_errors           abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+//   KITTI/evaluate_depth.py:71-79    batch_post_process_disparity (Monodepth-v1 flip post-processing)
+//   KITTI/evaluate_depth.py:268-307  per-image chain: cv2.resize(pred_disp) -> 1/disp -> Eigen mask (depth range and
+//                                    Garg crop) -> scale factor -> median scaling -> clamp -> compute_errors
+//   NYUv2/utils.py:85-98             compute_errors_nyu        abs_rel, rmse, log10, a1, a2, a3
+// The reference does this per image in numpy on the host; here a batch of images stays in HBM:
+//   eval_prepare_kernel   one pass over the ground-truth grid: bilinear resample of the low-resolution disparity
+//                         (half-pixel centres, edge clamp = cv2.INTER_LINEAR = F.interpolate(align_corners=False)),
+//                         reciprocal, mask; masked-out pixels are stored as -1 in both planes; per-image counts.
+//   eval_hist/scan/next   np.median of the valid pixels of a plane = mean of the two middle order statistics: radix
+//                         select on the float bit patterns (positive floats order like their uint32 patterns; the -1
+//                         sentinels order above every valid value): three multi-block histogram levels (11+11+10
+//                         bits) + one count/min pass for the upper middle value.
+//   eval_metrics_kernel   ratio scaling + clamp + the seven (KITTI) / six (NYUv2) error sums, fp64 accumulation, up to 64
+//                         blocks per image + a deterministic finish.
+// All three are HBM-bound streaming kernels: 8 + 4 B read and 8 B written per ground-truth pixel in prepare, 4 B per
+// pixel and pass in the selection, 8 B per pixel in the metrics.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include "wmd_internal.h"
+
+namespace wmd {
+
+__global__ void eval_prepare_kernel(const float* __restrict__ disp, const float* __restrict__ gt, float* __restrict__ pd,
+                                    float* __restrict__ gm, int* __restrict__ count, int h, int w, int H, int W,
+                                    float min_depth, float max_depth, int mask_mode, float pred_scale) {
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const float* d = disp + (size_t)b * h * w;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    // Garg / Eigen crop, evaluate_depth.py:286-287 (truncation of the products, like astype(np.int32))
+    const int cy0 = (int)(0.40810811 * H), cy1 = (int)(0.99189189 * H), cx0 = (int)(0.03594771 * W), cx1 = (int)(0.96405229 * W);
+    int local = 0;
+    const int total = H * W;   // < 2^31 (checked by the host)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const float g = gt[(size_t)b * plane + i];
+        bool valid;
+        if (mask_mode == 1) valid = g > min_depth && g < max_depth && y >= cy0 && y < cy1 && x >= cx0 && x < cx1;
+        else valid = g > 0.f;
+        float fy = (y + 0.5f) * sy - 0.5f, fx = (x + 0.5f) * sx - 0.5f;
+        int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        fy -= y0;
+        fx -= x0;
+        if (y0 < 0) { y0 = 0; fy = 0.f; }
+        if (x0 < 0) { x0 = 0; fx = 0.f; }
+        if (y0 >= h - 1) { y0 = h - 1; fy = 0.f; }
+        if (x0 >= w - 1) { x0 = w - 1; fx = 0.f; }
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float top = d[y0 * w + x0] * (1.f - fx) + d[y0 * w + x1] * fx;
+        const float bot = d[y1 * w + x0] * (1.f - fx) + d[y1 * w + x1] * fx;
+        const float dv = top * (1.f - fy) + bot * fy;
+        const float depth = (1.f / dv) * pred_scale;
+        pd[(size_t)b * plane + i] = valid ? depth : -1.f;
+        gm[(size_t)b * plane + i] = valid ? g : -1.f;
+        local += valid ? 1 : 0;
+    }
+    // block count -> one atomic
+    __shared__ int red[4];
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = red[0] + red[1] + red[2] + red[3];
+        if (tot) atomicAdd(&count[b], tot);
+    }
+}
+
+// np.median of the n = count[b] valid values of a plane = 0.5 * (v[k0] + v[k1]), k0 = (n-1)/2, k1 = n/2 (0-based order
+// statistics).  v[k0] by a three-level radix select over the float bit patterns (11 + 11 + 10 bits), every level a
+// multi-block histogram pass (LDS sub-histograms flushed with global atomics) followed by a one-block scan that picks
+// the bin holding the rank; v[k1] from one more pass: it is v[k0] again when enough values are <= v[k0], else the
+// smallest value above it.  Four streaming passes over the plane instead of sorting it.
+constexpr int EV_BINS = 2048;
+struct EvSel {            // per (image, plane) selection state, lives in the workspace
+    unsigned prefix;      // key bits decided so far (right-aligned)
+    unsigned rank;        // rank still to be resolved inside the current prefix
+    unsigned count_le;    // final pass: #keys <= key(v[k0])
+    unsigned min_gt;      // final pass: smallest key > key(v[k0])
+};
+
+__device__ __forceinline__ const unsigned* ev_plane(const float* pd, const float* gm, int which, int b, size_t plane) {
+    return reinterpret_cast<const unsigned*>((which == 0 ? pd : gm) + (size_t)b * plane);
+}
+
+// level 0: bits 31..21, level 1: bits 20..10, level 2: bits 9..0
+__global__ __launch_bounds__(256) void eval_hist_kernel(const float* __restrict__ pd, const float* __restrict__ gm,
+                                                        const EvSel* __restrict__ sel, unsigned* __restrict__ hist,
+                                                        size_t plane, int level) {
+    const int which = blockIdx.y, b = blockIdx.z;
+    const unsigned* v = ev_plane(pd, gm, which, b, plane);
+    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+    const unsigned mask = level == 2 ? 1023u : 2047u;
+    const int hi_shift = level == 0 ? 32 : (level == 1 ? 21 : 10);
+    const unsigned prefix = sel[b * 2 + which].prefix;
+    __shared__ unsigned lh[EV_BINS];
+    for (int i = threadIdx.x; i < EV_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned k = v[i];
+        if ((unsigned)((unsigned long long)k >> hi_shift) == prefix) atomicAdd(&lh[(k >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    unsigned* gh = hist + (size_t)(b * 2 + which) * EV_BINS;
+    for (int i = threadIdx.x; i < EV_BINS; i += blockDim.x)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// one block per (plane, image): find the bin that holds the rank, descend, clear the histogram for the next level
+__global__ __launch_bounds__(256) void eval_scan_kernel(EvSel* __restrict__ sel, unsigned* __restrict__ hist,
+                                                        const int* __restrict__ count, int level) {
+    const int which = blockIdx.x, b = blockIdx.y;
+    EvSel* st = sel + b * 2 + which;
+    unsigned* gh = hist + (size_t)(b * 2 + which) * EV_BINS;
+    __shared__ unsigned part[256];
+    __shared__ unsigned s_bin, s_rank;
+    const int n = count[b];
+    const unsigned rank = level == 0 ? (n > 0 ? (unsigned)(n - 1) / 2u : 0u) : st->rank;
+    // 8 bins per thread
+    unsigned loc[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        loc[j] = gh[threadIdx.x * 8 + j];
+        sum += loc[j];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned cum = 0;
+        int t = 0;
+        for (; t < 255; ++t) {
+            if (cum + part[t] > rank) break;
+            cum += part[t];
+        }
+        s_bin = (unsigned)t;      // the thread whose 8 bins hold the rank
+        s_rank = rank - cum;
+    }
+    __syncthreads();
+    if (threadIdx.x == s_bin) {
+        unsigned cum = 0, r = s_rank;
+        int j = 0;
+        for (; j < 7; ++j) {
+            if (cum + loc[j] > r) break;
+            cum += loc[j];
+        }
+        const int bits = level == 2 ? 10 : 11;
+        st->prefix = ((level == 0 ? 0u : st->prefix) << bits) | (unsigned)(threadIdx.x * 8 + j);
+        st->rank = r - cum;
+        st->count_le = 0;
+        st->min_gt = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gh[threadIdx.x * 8 + j] = 0;
+}
+
+__global__ __launch_bounds__(256) void eval_next_kernel(const float* __restrict__ pd, const float* __restrict__ gm,
+                                                        EvSel* __restrict__ sel, size_t plane) {
+    const int which = blockIdx.y, b = blockIdx.z;
+    const unsigned* v = ev_plane(pd, gm, which, b, plane);
+    EvSel* st = sel + b * 2 + which;
+    const unsigned key = st->prefix;
+    unsigned le = 0, mn = 0xFFFFFFFFu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned k = v[i];
+        le += k <= key ? 1u : 0u;
+        mn = (k > key && k < mn) ? k : mn;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        le += __shfl_xor(le, o);
+        const unsigned other = __shfl_xor(mn, o);
+        mn = other < mn ? other : mn;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (le) atomicAdd(&st->count_le, le);
+        atomicMin(&st->min_gt, mn);
+    }
+}
+
+__global__ void eval_median_finish_kernel(const EvSel* __restrict__ sel, const int* __restrict__ count, float* __restrict__ med, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (image, plane)
+    if (i >= B * 2) return;
+    const int n = count[i >> 1];
+    if (n <= 0) {
+        med[i] = 0.f;
+        return;
+    }
+    const EvSel st = sel[i];
+    const unsigned k1 = (unsigned)n / 2u;
+    const float v0 = __uint_as_float(st.prefix);
+    const float v1 = st.count_le > k1 ? v0 : __uint_as_float(st.min_gt);
+    med[i] = 0.5f * (v0 + v1);
+}
+
+// out[b][0..8] = abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, log10, n_valid.  Entries < 0 in gm are skipped.
+// gridDim.x blocks share an image: each reduces its slice to nine fp64 sums; a lone block finishes in place, otherwise
+// the sums go to partial[b][block][9] and eval_metrics_finish_kernel adds them in block order (deterministic).
+__device__ __forceinline__ void ev_finish(const double* s9, float* out9) {
+    const double n = s9[8];
+    for (int k = 0; k < 9; ++k) {
+        double r;
+        if (k == 8) r = n;
+        else if (n == 0.0) r = nan("");
+        else if (k == 2 || k == 3) r = sqrt(s9[k] / n);
+        else r = s9[k] / n;
+        out9[k] = (float)r;
+    }
+}
+
+__global__ __launch_bounds__(1024) void eval_metrics_kernel(const float* __restrict__ pd, const float* __restrict__ gm,
+                                                           const float* __restrict__ med, float* __restrict__ out,
+                                                           double* __restrict__ partial, size_t plane, int median_scaling,
+                                                           float clamp_lo, float clamp_hi, int do_clamp) {
+    const int b = blockIdx.y;
+    const float* p = pd + (size_t)b * plane;
+    const float* g = gm + (size_t)b * plane;
+    const float ratio = (median_scaling && med) ? med[b * 2 + 1] / med[b * 2 + 0] : 1.f;
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+        const float gt = g[i];
+        if (gt < 0.f) continue;
+        float pr = p[i];
+        if (median_scaling) pr *= ratio;
+        if (do_clamp) {
+            pr = pr < clamp_lo ? clamp_lo : pr;
+            pr = pr > clamp_hi ? clamp_hi : pr;
+        }
+        const float th = fmaxf(gt / pr, pr / gt);
+        const float diff = gt - pr;
+        const float dl = logf(gt) - logf(pr);
+        acc[0] += (double)(fabsf(diff) / gt);
+        acc[1] += (double)((diff * diff) / gt);
+        acc[2] += (double)(diff * diff);
+        acc[3] += (double)(dl * dl);
+        acc[4] += th < 1.25f ? 1.0 : 0.0;
+        acc[5] += th < 1.5625f ? 1.0 : 0.0;      // 1.25 ** 2
+        acc[6] += th < 1.953125f ? 1.0 : 0.0;    // 1.25 ** 3
+        acc[7] += (double)fabsf(log10f(gt) - log10f(pr));
+        acc[8] += 1.0;
+    }
+    __shared__ double red[16][9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double s = acc[k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s9[9];
+        for (int k = 0; k < 9; ++k) {
+            double s = 0.0;
+            for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += red[wv][k];
+            s9[k] = s;
+        }
+        if (gridDim.x == 1) {
+            ev_finish(s9, out + b * 9);
+        } else {
+            for (int k = 0; k < 9; ++k) partial[((size_t)b * gridDim.x + blockIdx.x) * 9 + k] = s9[k];
+        }
+    }
+}
+
+__global__ void eval_metrics_finish_kernel(const double* __restrict__ partial, float* __restrict__ out, int B, int nblk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s9[9];
+    for (int k = 0; k < 9; ++k) s9[k] = 0.0;
+    for (int j = 0; j < nblk; ++j)
+        for (int k = 0; k < 9; ++k) s9[k] += partial[((size_t)b * nblk + j) * 9 + k];
+    ev_finish(s9, out + b * 9);
+}
+
+// Monodepth-v1 flip post-processing; r_disp is the prediction for the flipped image, NOT flipped back
+// (evaluate_depth.py:204 flips it with [:, :, ::-1] before the call; that flip is fused here).
+__global__ void flip_postprocess_kernel(const float* __restrict__ l, const float* __restrict__ r, float* __restrict__ out,
+                                        size_t n, int w) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const size_t row = i - x;
+        const float lv = l[i], rv = r[row + (w - 1 - x)];
+        // np.linspace(0, 1, w)[x] in float64, like the reference's meshgrid
+        const double lin = w > 1 ? (double)x / (double)(w - 1) : 0.0, linr = w > 1 ? (double)(w - 1 - x) / (double)(w - 1) : 0.0;
+        const double lm = 1.0 - fmin(fmax(20.0 * (lin - 0.05), 0.0), 1.0);
+        const double rm = 1.0 - fmin(fmax(20.0 * (linr - 0.05), 0.0), 1.0);
+        const float m = 0.5f * (lv + rv);
+        out[i] = (float)(rm * (double)lv + lm * (double)rv + (1.0 - lm - rm) * (double)m);
+    }
+}
+
+}  // namespace wmd
+
+using namespace wmd;
+
+extern "C" size_t wmd_eval_workspace_floats(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    // two masked planes, [B] counts (int), [B,2] medians, [B,2] selection states, [B,2,2048] histograms
+    // + [B,64,9] fp64 partial error sums (and one float of slack to align them to 8 bytes)
+    return (size_t)B * H * W * 2 + (size_t)B * 3 + (size_t)B * 2 * 4 + (size_t)B * 2 * 2048 + (size_t)B * 64 * 9 * 2 + 2;
+}
+
+extern "C" int wmd_eval_kitti(const wmd_eval_kitti_args* g, void* stream) {
+    if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_eval_kitti: null args");
+    if (!g->pred_disp || !g->gt_depth || !g->out || !g->workspace) return fail(WMD_ERR_BAD_ARG, "wmd_eval_kitti: null pointer");
+    if (g->B <= 0 || g->h <= 0 || g->w <= 0 || g->H <= 0 || g->W <= 0)
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_eval_kitti: B=%d h=%d w=%d H=%d W=%d", g->B, g->h, g->w, g->H, g->W);
+    if (g->mask_mode < 0 || g->mask_mode > 1) return fail(WMD_ERR_BAD_ARG, "wmd_eval_kitti: mask_mode=%d", g->mask_mode);
+    if ((double)g->H * g->W > 2147483647.0) return fail(WMD_ERR_UNSUPPORTED, "wmd_eval_kitti: more than 2^31 pixels per image");
+    const size_t need = wmd_eval_workspace_floats(g->B, g->H, g->W);
+    if (g->workspace_floats < need) return fail(WMD_ERR_WORKSPACE, "wmd_eval_kitti: workspace %zu < %zu floats", g->workspace_floats, need);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t plane = (size_t)g->H * g->W;
+    float* pd = g->workspace;
+    float* gm = pd + (size_t)g->B * plane;
+    int* count = reinterpret_cast<int*>(gm + (size_t)g->B * plane);
+    float* med = reinterpret_cast<float*>(count + g->B);
+    if (hipMemsetAsync(count, 0, sizeof(int) * g->B, s) != hipSuccess) return fail(WMD_ERR_HIP, "wmd_eval_kitti: hipMemsetAsync failed");
+    {
+        ProfScope prof("eval_prepare_kernel", 12.0 * g->B * plane, 4.0 * g->B * (3.0 * plane + (double)g->h * g->w), s);
+        const int bx = (int)std::max<size_t>(1, std::min<size_t>((plane + 1023) / 1024, 128));   // one count atomic per block
+        hipLaunchKernelGGL(eval_prepare_kernel, dim3(bx, g->B), dim3(256), 0, s, g->pred_disp, g->gt_depth, pd, gm, count, g->h, g->w,
+                           g->H, g->W, g->min_depth, g->max_depth, g->mask_mode, g->pred_scale);
+    }
+    int st = check_launch("eval_prepare_kernel");
+    if (st) return st;
+    if (g->median_scaling) {
+        EvSel* sel = reinterpret_cast<EvSel*>(med + 2 * g->B);
+        unsigned* hist = reinterpret_cast<unsigned*>(sel + 2 * g->B);
+        if (hipMemsetAsync(sel, 0, sizeof(EvSel) * 2 * g->B + sizeof(unsigned) * 2 * EV_BINS * g->B, s) != hipSuccess)
+            return fail(WMD_ERR_HIP, "wmd_eval_kitti: hipMemsetAsync failed");
+        const int nblk = (int)std::max<size_t>(1, std::min<size_t>((plane + 4095) / 4096, 64));
+        ProfScope prof("eval_median (4 passes)", 0.0, 4.0 * 4 * 2 * g->B * plane, s);
+        for (int level = 0; level < 3; ++level) {
+            hipLaunchKernelGGL(eval_hist_kernel, dim3(nblk, 2, g->B), dim3(256), 0, s, pd, gm, sel, hist, plane, level);
+            hipLaunchKernelGGL(eval_scan_kernel, dim3(2, g->B), dim3(256), 0, s, sel, hist, count, level);
+        }
+        hipLaunchKernelGGL(eval_next_kernel, dim3(nblk, 2, g->B), dim3(256), 0, s, pd, gm, sel, plane);
+        hipLaunchKernelGGL(eval_median_finish_kernel, dim3((2 * g->B + 63) / 64), dim3(64), 0, s, sel, count, med, g->B);
+        st = check_launch("eval_median");
+        if (st) return st;
+    }
+    const int mblk = (int)std::max<size_t>(1, std::min<size_t>((plane + 8191) / 8192, 64));
+    float* after = reinterpret_cast<float*>(reinterpret_cast<unsigned*>(med + 2 * g->B) + (size_t)g->B * 2 * 4 + (size_t)g->B * 2 * EV_BINS);
+    double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(after) + 7) & ~(uintptr_t)7);
+    ProfScope prof("eval_metrics_kernel", 30.0 * g->B * plane, 8.0 * g->B * plane, s);
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3(mblk, g->B), dim3(1024), 0, s, pd, gm, med, g->out, partial, plane, g->median_scaling,
+                       g->min_depth, g->max_depth, 1);
+    if (mblk > 1) hipLaunchKernelGGL(eval_metrics_finish_kernel, dim3((g->B + 63) / 64), dim3(64), 0, s, partial, g->out, g->B, mblk);
+    return check_launch("eval_metrics_kernel");
+}
+
+extern "C" int wmd_eval_errors(const float* pred, const float* gt, int B, size_t n_per_image, float* out9, void* stream) {
+    if (!pred || !gt || !out9) return fail(WMD_ERR_BAD_ARG, "wmd_eval_errors: null pointer");
+    if (B <= 0 || n_per_image == 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_eval_errors: B=%d n=%zu", B, n_per_image);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("eval_metrics_kernel", 30.0 * B * n_per_image, 8.0 * B * n_per_image, s);
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3(1, B), dim3(1024), 0, s, pred, gt, (const float*)nullptr, out9, (double*)nullptr, n_per_image, 0, 0.f, 0.f, 0);
+    return check_launch("eval_metrics_kernel");
+}
+
+extern "C" int wmd_flip_postprocess(const float* l_disp, const float* r_disp, float* out, int B, int h, int w, void* stream) {
+    if (!l_disp || !r_disp || !out) return fail(WMD_ERR_BAD_ARG, "wmd_flip_postprocess: null pointer");
+    if (B <= 0 || h <= 0 || w <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_flip_postprocess: B=%d h=%d w=%d", B, h, w);
+    const size_t n = (size_t)B * h * w;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("flip_postprocess_kernel", 8.0 * n, 12.0 * n, s);
+    hipLaunchKernelGGL(flip_postprocess_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, l_disp, r_disp, out, n, w);
+    return check_launch("flip_postprocess_kernel");
+}
