@@ -451,10 +451,75 @@ def nyu_wave_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0
     }
 
 
-def nyu_up_block(x, skip, sd, key):
-    """UpSampleBlock (NYUv2/networks/layers.py:57-67): up2 -> cat -> Conv3x3(reflection) -> LeakyReLU(0.2)."""
+def nyu_baseline_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0.5, variant224=False):
+    """Decoder / Decoder224 parameters (densedepth_decoder.py:16-34, 50-74)."""
+    f = int(enc_features[-1] * decoder_width)
+    e = list(enc_features)
+    sh = {"conv2.conv.weight": (f, e[-1], 3, 3), "conv2.conv.bias": (f,)}
+    cin = f
+    for k in (1, 2, 3, 4):
+        cout = f // (2 ** k)
+        sh["up%d.convA.conv.weight" % k] = (cout, cin + e[-1 - k], 3, 3)
+        sh["up%d.convA.conv.bias" % k] = (cout,)
+        cin = cout
+    if variant224:
+        sh["conv5.0.conv.weight"] = (f // 32, f // 16, 3, 3)
+        sh["conv5.0.conv.bias"] = (f // 32,)
+        cin = f // 32
+    sh["conv3.weight"] = (1, cin, 3, 3)
+    sh["conv3.bias"] = (1,)
+    return sh
+
+
+def nyu_wave224_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0.5):
+    """DecoderWave224 parameters (densedepth_decoder.py:152-180)."""
+    f = int(enc_features[-1] * decoder_width)
+    e = list(enc_features)
+    sh = {"conv2.conv.weight": (f, e[-1], 3, 3), "conv2.conv.bias": (f,),
+          "wave1_ll.conv.weight": (1, f // 2, 3, 3), "wave1_ll.conv.bias": (1,)}
+    cin = f
+    for k in (1, 2, 3, 4):
+        cout = f // (2 ** k)
+        sh["up%d.convA.conv.weight" % k] = (cout, cin + e[-1 - k], 3, 3)
+        sh["up%d.convA.conv.bias" % k] = (cout,)
+        sh["wave%d.conv.weight" % k] = (3, cout, 3, 3)
+        sh["wave%d.conv.bias" % k] = (3,)
+        cin = cout
+    return sh
+
+
+def nyu_up_block(x, skip, sd, key, pad="reflect"):
+    """UpSampleBlock (NYUv2/networks/layers.py:57-67): up2 -> cat -> Conv3x3(padding) -> LeakyReLU(0.2)."""
     t = torch.cat([up2(x), skip], 1)
-    return F.leaky_relu(conv3x3(t, sd[key + ".convA.conv.weight"], sd[key + ".convA.conv.bias"], "reflect"), 0.2)
+    return F.leaky_relu(conv3x3(t, sd[key + ".convA.conv.weight"], sd[key + ".convA.conv.bias"], pad), 0.2)
+
+
+def nyu_baseline_decoder(x_blocks, sd, variant224=False):
+    """Decoder.forward (densedepth_decoder.py:36-46) / Decoder224.forward (:76-89): zero padding everywhere; the output
+    layer is a bare nn.Conv2d(C, 1, 3, padding=1) (keys conv3.weight / conv3.bias)."""
+    x = conv3x3(x_blocks[4], sd["conv2.conv.weight"], sd["conv2.conv.bias"], "zero")
+    for k, skip in zip((1, 2, 3, 4), (x_blocks[3], x_blocks[2], x_blocks[1], x_blocks[0])):
+        x = nyu_up_block(x, skip, sd, "up%d" % k, "zero")
+    if variant224:
+        x = F.leaky_relu(conv3x3(up2(x), sd["conv5.0.conv.weight"], sd["conv5.0.conv.bias"], "zero"), 0.2)
+    return {("disp", 0): conv3x3(x, sd["conv3.weight"], sd["conv3.bias"], "zero")}
+
+
+def nyu_wave224_decoder(x_blocks, sd):
+    """DecoderWave224.forward (densedepth_decoder.py:182-221), incl. the floor division of ("disp", 1) at :212."""
+    out = {}
+    x = nyu_up_block(conv3x3(x_blocks[-1], sd["conv2.conv.weight"], sd["conv2.conv.bias"], "replicate"), x_blocks[-2], sd, "up1")
+    ll = 16 * conv3x3(x, sd["wave1_ll.conv.weight"], sd["wave1_ll.conv.bias"], "replicate")
+    out[("wavelets", 3, "LL")] = ll
+    for level in range(4):
+        s = 3 - level
+        h = (2 ** s) * conv3x3(x, sd["wave%d.conv.weight" % (level + 1)], sd["wave%d.conv.bias" % (level + 1)], "zero").unsqueeze(1)
+        out[("wavelets", s, "LH")], out[("wavelets", s, "HL")], out[("wavelets", s, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+        ll = haar_idwt(ll, h)
+        out[("disp", s)] = ll // 2 if s == 1 else ll / (2 ** s)
+        if level < 3:
+            x = nyu_up_block(x, x_blocks[-3 - level], sd, "up%d" % (level + 2))
+    return out
 
 
 def nyu_wave_decoder(x_blocks, sd):

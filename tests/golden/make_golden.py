@@ -165,6 +165,33 @@ def gen_kitti():
     print("kitti goldens written")
 
 
+def gen_nyu_variants():
+    """Decoder, Decoder224, DecoderWave224 (non-depthwise) — forward outputs and loss gradients."""
+    sys.path.insert(0, "/root/reference/NYUv2")
+    from networks.decoders import Decoder, Decoder224, DecoderWave224
+
+    enc = [8, 8, 16, 32, 64]
+    H, W, B = 64, 96, 2
+    blocks = [t(synth.normal((B, c, H >> (k + 1), W >> (k + 1)), "nyu_feat%d" % k, 8)) for k, c in enumerate(enc)]
+    for name, cls, seed in (("decoder", Decoder, 21), ("decoder224", Decoder224, 22), ("decoderwave224", DecoderWave224, 23)):
+        dec = synth.fill_state_dict(quiet(cls, enc_features=enc), seed=seed)
+        bg = [b_.clone().requires_grad_(True) for b_ in blocks]
+        out = dec(bg)
+        res = outputs_to_np(out)
+        # ("disp", 1) of DecoderWave224 comes out of `//` (floor_divide: no derivative in torch) -- leave it out of the loss
+        loss = sum(v.mean() for k, v in out.items() if k[0] == "disp" and not (name == "decoderwave224" and k[1] == 1))
+        loss.backward()
+        res["loss"] = loss.detach().numpy()
+        for k, f in enumerate(bg):
+            if f.grad is not None:
+                res["dfeat%d" % k] = f.grad.numpy()
+        for n, p in dec.named_parameters():
+            if p.grad is not None:
+                res["d|" + n] = sample(p.grad.numpy())
+        np.savez_compressed(os.path.join(HERE, "nyu_%s_small_64x96.npz" % name), **res)
+        print(name, sorted(k for k in res if not k.startswith("d"))[:8], float(loss))
+
+
 def gen_nyu():
     sys.path.insert(0, "/root/reference/NYUv2")
     import networks.layers as NL
@@ -223,4 +250,4 @@ def gen_nyu():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "kitti"
-    {"kitti": gen_kitti, "nyu": gen_nyu}[which]()
+    {"kitti": gen_kitti, "nyu": gen_nyu, "nyu_variants": gen_nyu_variants}[which]()

@@ -341,6 +341,35 @@ def test_nyu_dense_decoder_gradients_vs_reference_golden(dev):
         assert_close(sample(p.grad.cpu().numpy()), g["d|" + name], NET_TOL, name)
 
 
+@pytest.mark.parametrize("name", ["decoder", "decoder224", "decoderwave224"])
+def test_nyu_decoder_variants_vs_reference_golden(dev, name):
+    """Decoder / Decoder224 / DecoderWave224 forward + gradients vs the reference's own modules."""
+    from util import nyu_feats, sample
+    from wavelet_monodepth_amd import nyu
+    g = load_golden("nyu_%s_small_64x96.npz" % name)
+    cls, seed = {"decoder": (nyu.Decoder, 21), "decoder224": (nyu.Decoder224, 22), "decoderwave224": (nyu.DecoderWave224, 23)}[name]
+    dec = synth.fill_state_dict(cls(enc_features=NYU_ENC), seed=seed).to(dev)
+    feats = [f.to(dev).requires_grad_(True) for f in nyu_feats(2, 64, 96, NYU_ENC)]
+    out = dec(feats)
+    assert set(key_str(k) for k in out) == {k for k in g if k.startswith("disp") or k.startswith("wavelets")}
+    for k, v in out.items():
+        if name == "decoderwave224" and k == ("disp", 1):
+            # floor division: values within rounding noise of an integer may land on either side
+            diff = (v.detach().cpu() - t(g[key_str(k)])).abs()
+            assert float((diff > 1e-4).float().mean()) < 1e-3 and float(diff.max()) <= 1.0 + 1e-4
+        else:
+            assert_close(v, g[key_str(k)], NET_TOL, key_str(k))
+    loss = sum(v.mean() for k, v in out.items() if k[0] == "disp" and not (name == "decoderwave224" and k[1] == 1))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    for k, f in enumerate(feats):
+        assert_close(f.grad, g["dfeat%d" % k], NET_TOL, "dfeat%d" % k)
+    for n, p in dec.named_parameters():
+        assert_close(sample(p.grad.cpu().numpy()), g["d|" + n], NET_TOL, n)
+    with pytest.raises(NotImplementedError):
+        cls(enc_features=NYU_ENC, **({"dw_upconv": True} if name == "decoderwave224" else {"is_depthwise": True}))
+
+
 def test_nyu_dense_decoder_densenet161_shapes_vs_oracle(dev):
     """BASELINE config 5 shapes (DenseNet161 features of a 640x480 image), batch 1, with the ragged
     channel counts 2208/1104/552/276/138."""

@@ -213,6 +213,35 @@ def test_nyu_dense_decoder_grads():
         assert_close(sample(v.grad.numpy()), g["d|" + name], 2e-5, name)
 
 
+def _variant(name):
+    if name == "decoderwave224":
+        return R.nyu_wave224_param_shapes(NYU_ENC), R.nyu_wave224_decoder, 23
+    v224 = name == "decoder224"
+    return R.nyu_baseline_param_shapes(NYU_ENC, variant224=v224), (lambda f, sd: R.nyu_baseline_decoder(f, sd, variant224=v224)), 22 if v224 else 21
+
+
+@pytest.mark.parametrize("name", ["decoder", "decoder224", "decoderwave224"])
+def test_nyu_decoder_variants_forward_and_grads(name):
+    """Decoder / Decoder224 / DecoderWave224 restatements vs the reference's own modules."""
+    g = load_golden("nyu_%s_small_64x96.npz" % name)
+    shapes, fn, seed = _variant(name)
+    sd = R.make_state_dict(shapes, seed=seed)
+    for v in sd.values():
+        v.requires_grad_(True)
+    feats = [f.requires_grad_(True) for f in nyu_feats(2, 64, 96, NYU_ENC)]
+    out = fn(feats, sd)
+    fwd = {k: v for k, v in g.items() if k.startswith("disp") or k.startswith("wavelets")}
+    check_outputs(out, fwd)
+    assert set(key_str(k) for k in out) == set(fwd)
+    loss = sum(v.mean() for k, v in out.items() if k[0] == "disp" and not (name == "decoderwave224" and k[1] == 1))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    for k, f in enumerate(feats):
+        assert_close(f.grad, g["dfeat%d" % k], 2e-5, "dfeat%d" % k)
+    for n, v in sd.items():
+        assert_close(sample(v.grad.numpy()), g["d|" + n], 2e-5, n)
+
+
 @pytest.mark.parametrize("thr", [-1.0, 0.02, 0.1])
 def test_nyu_sparse_decoder(thr):
     sd = R.make_state_dict(R.nyu_wave_param_shapes(NYU_ENC), seed=8)

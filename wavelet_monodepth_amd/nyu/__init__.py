@@ -1,1 +1,1 @@
-from .densedepth_decoder import DecoderWave, SparseDecoderWave  # noqa: F401
+from .densedepth_decoder import Decoder, Decoder224, DecoderWave, DecoderWave224, SparseDecoderWave  # noqa: F401

@@ -1,12 +1,15 @@
 """NYUv2 DenseDepth-style wavelet decoders on MI355X, API-compatible with the reference
 (/root/reference/NYUv2/networks/decoders/densedepth_decoder.py):
 
+  Decoder            :15-46     DenseDepth baseline (no wavelets), zero padding
+  Decoder224         :49-89     224x224 variant: one more nearest x2 + Conv3x3/LeakyReLU before the output conv
   DecoderWave        :92-148    dense
+  DecoderWave224     :151-221   four wavelet levels (incl. the reference's floor division of ("disp", 1), :212)
   SparseDecoderWave  :224-409   two sparse levels (see sparse_decoder.py)
 
-Same constructors, `state_dict` names (conv2.conv.*, up{1,2,3}.convA.conv.*, wave1_ll.conv.*, wave{1,2,3}.conv.*,
-iwt.*, iwt_LL.*) and output keys.  The depthwise options (dw_waveconv / dw_upconv) and the baseline
-Decoder/Decoder224/DecoderWave224 classes are SURVEY §8(f) "next" items.
+Same constructors, `state_dict` names (conv2.conv.*, up{1..4}.convA.conv.*, conv5.0.conv.*, conv3.*, wave1_ll.conv.*,
+wave{1..4}.conv.*, iwt.*, iwt_LL.*) and output keys.  The depthwise options (is_depthwise / dw_waveconv / dw_upconv,
+off by default in the reference) raise NotImplementedError: SURVEY §8(f) rank 4, not built.
 """
 import torch
 import torch.nn as nn
@@ -15,6 +18,59 @@ from .. import ops, sparse_ops as S
 from ..layers import NyuConv3x3, UpSampleBlock
 from ..wavelets import IDWT
 from ..graphs import GraphCache
+
+
+class _OutConv3x3(nn.Conv2d):
+    """The baselines' output layer is a bare nn.Conv2d(C, 1, 3, padding=1) (densedepth_decoder.py:33,71): same
+    parameter names (conv3.weight / conv3.bias), executed by the small-Cout head kernel with zero padding."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(int(in_channels), int(out_channels), kernel_size=3, stride=1, padding=1, padding_mode="zeros")
+
+    def forward(self, x):
+        return ops.head3x3(x, self.weight, self.bias, pad="zero", mode=0, scale=1.0)
+
+
+class Decoder(nn.Module):
+    def __init__(self, enc_features=[96, 96, 192, 384, 2208], decoder_width=0.5, is_depthwise=False):
+        super().__init__()
+        features = int(enc_features[-1] * decoder_width)
+        padding = "zero"
+        self.conv2 = NyuConv3x3(enc_features[-1], features, padding="zero")
+        self.up1 = UpSampleBlock(skip_input=features // 1 + enc_features[-2], output_features=features // 2, padding=padding,
+                                 is_depthwise=is_depthwise)
+        self.up2 = UpSampleBlock(skip_input=features // 2 + enc_features[-3], output_features=features // 4, padding=padding,
+                                 is_depthwise=is_depthwise)
+        self.up3 = UpSampleBlock(skip_input=features // 4 + enc_features[-4], output_features=features // 8, padding=padding,
+                                 is_depthwise=is_depthwise)
+        self.up4 = UpSampleBlock(skip_input=features // 8 + enc_features[-5], output_features=features // 16, padding=padding,
+                                 is_depthwise=is_depthwise)
+        self.conv3 = _OutConv3x3(features // 16, 1)
+
+    def _trunk(self, features):
+        x_block0, x_block1, x_block2, x_block3, x_block4 = tuple(features)
+        x_d0 = self.conv2(x_block4)
+        x_d1 = self.up1(x_d0, x_block3)
+        x_d2 = self.up2(x_d1, x_block2)
+        x_d3 = self.up3(x_d2, x_block1)
+        return self.up4(x_d3, x_block0)
+
+    def forward(self, features):
+        return {("disp", 0): self.conv3(self._trunk(features))}
+
+
+class Decoder224(Decoder):
+    def __init__(self, enc_features=[96, 96, 192, 384, 2208], decoder_width=0.5, is_depthwise=False):
+        super().__init__(enc_features=enc_features, decoder_width=decoder_width, is_depthwise=is_depthwise)
+        features = int(enc_features[-1] * decoder_width)
+        # nn.Sequential(Conv3x3, LeakyReLU(0.2)) in the reference (:66-67): key conv5.0.conv.*; the nearest x2 in front of
+        # it (:87) and the activation are fused into the convolution
+        self.conv5 = nn.Sequential(NyuConv3x3(features // 16, features // 32), nn.LeakyReLU(0.2))
+        self.conv3 = _OutConv3x3(features // 32, 1)
+
+    def forward(self, features):
+        x_d5 = self.conv5[0](self._trunk(features), up=2, act="leaky", slope=0.2)
+        return {("disp", 0): self.conv3(x_d5)}
 
 
 class DecoderWave(nn.Module):
@@ -83,6 +139,61 @@ class DecoderWave(nn.Module):
         outputs[("wavelets", 0, "HH")] = h[:, :, 2]
         ll, _ = ops.idwt_haar(ll, h)
         outputs[("disp", 0)] = ll
+        return outputs
+
+
+class DecoderWave224(nn.Module):
+    """densedepth_decoder.py:151-221: four levels; LL head scaled by 2^4, highs by 2^3, 2^2, 2^1, 1; ("disp", s) = LL_s / 2^s
+    except ("disp", 1), which the reference computes with floor division (`ll // 2`, :212) -- reproduced as is."""
+
+    def __init__(self, enc_features=[96, 96, 192, 384, 2208], decoder_width=0.5, dw_waveconv=False, dw_upconv=False):
+        super().__init__()
+        features = int(enc_features[-1] * decoder_width)
+        wave_pad = "zero"
+        padding = "reflection"
+        self.iwt = IDWT(wave="haar", mode=wave_pad)
+        self.iwt_LL = IDWT(wave="haar", mode="zero")
+        self.conv2 = NyuConv3x3(enc_features[-1], features, padding="replicate")
+        self.up1 = UpSampleBlock(skip_input=features // 1 + enc_features[-2], output_features=features // 2,
+                                 padding=padding, is_depthwise=dw_upconv)
+        self.wave1_ll = NyuConv3x3(features // 2, 1, padding="replicate")
+        self.wave1 = NyuConv3x3(features // 2, 3, padding=wave_pad, is_depthwise=dw_waveconv)
+        self.up2 = UpSampleBlock(skip_input=features // 2 + enc_features[-3], output_features=features // 4,
+                                 padding=padding, is_depthwise=dw_upconv)
+        self.wave2 = NyuConv3x3(features // 4, 3, padding=wave_pad, is_depthwise=dw_waveconv)
+        self.up3 = UpSampleBlock(skip_input=features // 4 + enc_features[-4], output_features=features // 8,
+                                 padding=padding, is_depthwise=dw_upconv)
+        self.wave3 = NyuConv3x3(features // 8, 3, padding=wave_pad, is_depthwise=dw_waveconv)
+        self.up4 = UpSampleBlock(skip_input=features // 8 + enc_features[-5], output_features=features // 16,
+                                 padding=padding, is_depthwise=dw_upconv)
+        self.wave4 = NyuConv3x3(features // 16, 3, padding=wave_pad, is_depthwise=dw_waveconv)
+        self.sigmoid = nn.Sigmoid()
+
+    _wave = staticmethod(DecoderWave._wave)
+
+    def forward(self, x_blocks):
+        outputs = {}
+        x = self.up1(self.conv2(x_blocks[-1]), x_blocks[-2])
+        ll = self._wave(self.wave1_ll, x, 2.0 ** 4)
+        for level, (wave, up, skip) in enumerate(((self.wave1, self.up2, x_blocks[-3]), (self.wave2, self.up3, x_blocks[-4]),
+                                                  (self.wave3, self.up4, x_blocks[-5]), (self.wave4, None, None))):
+            s = 3 - level
+            h = self._wave(wave, x, 2.0 ** s).unsqueeze(1)
+            if level == 0:
+                outputs[("wavelets", 3, "LL")] = ll
+            outputs[("wavelets", s, "LH")] = h[:, :, 0]
+            outputs[("wavelets", s, "HL")] = h[:, :, 1]
+            outputs[("wavelets", s, "HH")] = h[:, :, 2]
+            if s == 1:
+                ll, _ = ops.idwt_haar(ll, h)
+                outputs[("disp", 1)] = ll // (2 ** 1)     # sic (floor_divide: not differentiable, as in the reference)
+            elif s == 0:
+                ll, _ = ops.idwt_haar(ll, h)
+                outputs[("disp", 0)] = ll
+            else:
+                ll, outputs[("disp", s)] = ops.idwt_haar(ll, h, disp_scale=1.0 / 2 ** s, clamp01=False)
+            if up is not None:
+                x = up(x, skip)
         return outputs
 
 
