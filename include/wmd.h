@@ -387,6 +387,47 @@ int wmd_eval_errors(const float* pred, const float* gt, int B, size_t n_per_imag
  * (:204) fused: r_disp is the raw prediction for the mirrored image.  l_disp, r_disp, out: [B,h,w].              */
 int wmd_flip_postprocess(const float* l_disp, const float* r_disp, float* out, int B, int h, int w, void* stream);
 
+/* ------------------------------------------------------------------ *
+ * Photometric loss stack of the KITTI trainer, forward and backward
+ * ------------------------------------------------------------------ */
+
+/* SSIM (KITTI/layers.py:281-311) and compute_reprojection_loss (KITTI/trainer.py:393-405).  x = pred, y = target, [B,C,H,W].
+ * mode 0: out [B,C,H,W] = clamp((1 - SSIM(x, y)) / 2, 0, 1)                      (the SSIM module)
+ * mode 1: out [B,1,H,W] = w_ssim * mean_c(mode 0) + w_l1 * mean_c |y - x|        (0.85 / 0.15 in the trainer)
+ * Backward: g has the shape of out; dx and/or dy [B,C,H,W] (either may be NULL); workspace = 3*B*C*H*W floats.       */
+int wmd_ssim_fwd(const float* x, const float* y, float* out, int B, int C, int H, int W, int mode, float w_ssim, float w_l1,
+                 void* stream);
+size_t wmd_ssim_bwd_workspace_floats(int B, int C, int H, int W);
+int wmd_ssim_bwd(const float* x, const float* y, const float* g, float* dx, float* dy, int B, int C, int H, int W, int mode,
+                 float w_ssim, float w_l1, float* workspace, size_t workspace_floats, void* stream);
+
+/* BackprojectDepth -> Project3D -> F.grid_sample(src, grid, padding_mode="border") (KITTI/layers.py:176-229,
+ * KITTI/trainer.py:352-372) in one kernel: out[b,c,y,x] = bilinear(src[b,c], project(K T, depth[b,y,x] * inv_K (x,y,1))).
+ * K, inv_K, T: [B,4,4] row-major.  Backward returns d(depth) [B,1,H,W] and dT [B,4,4]; the source frame and the
+ * intrinsics are constants of the loss (no gradient), as in the trainer.                                              */
+typedef struct {
+    int B, C, H, W;      /* target grid = depth map size; C colour channels                                          */
+    int Hs, Ws;          /* source frame size (equal to H, W in the trainer)                                         */
+    float eps;           /* Project3D eps, 1e-7                                                                       */
+    const float* src;    /* [B,C,Hs,Ws] */
+    const float* depth;  /* [B,1,H,W]   */
+    const float* K;
+    const float* inv_K;
+    const float* T;
+} wmd_warp_args;
+int wmd_warp_fwd(const wmd_warp_args* args, float* out, void* stream);
+size_t wmd_warp_bwd_workspace_floats(const wmd_warp_args* args);
+int wmd_warp_bwd(const wmd_warp_args* args, const float* grad_out, float* ddepth, float* dT, float* workspace,
+                 size_t workspace_floats, void* stream);
+
+/* get_smooth_loss (KITTI/layers.py:238-252): out[0] = mean |dx disp| exp(-gamma mean_c |dx img|) + the same along y.
+ * disp [B,1,H,W], img [B,C,H,W]; backward w.r.t. disp only (grad_out: 1 float on the device).                          */
+size_t wmd_smooth_workspace_floats(int B, int H, int W);
+int wmd_smooth_fwd(const float* disp, const float* img, float* out, int B, int C, int H, int W, float gamma, float* workspace,
+                   size_t workspace_floats, void* stream);
+int wmd_smooth_bwd(const float* disp, const float* img, const float* grad_out, float* ddisp, int B, int C, int H, int W,
+                   float gamma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

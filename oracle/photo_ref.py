@@ -1,0 +1,63 @@
+"""CPU oracle (torch-CPU, differentiable) of the photometric loss stack — TEST INFRASTRUCTURE ONLY (see oracle/__init__).
+
+Restates KITTI/layers.py:176-229 (BackprojectDepth, Project3D), :238-252 (get_smooth_loss), :281-311 (SSIM) and
+KITTI/trainer.py:393-405 (compute_reprojection_loss), :352-372 (the grid_sample call).  Pinned by outputs AND gradients
+of the reference's own layers module (tests/golden/photo_reference.npz, tests/golden/make_golden_photo.py);
+compute_reprojection_loss is a method of the un-importable trainer and is restated on top of the pinned SSIM.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def ssim(x, y):
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    x = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    y = F.pad(y, (1, 1, 1, 1), mode="reflect")
+    mu_x = F.avg_pool2d(x, 3, 1)
+    mu_y = F.avg_pool2d(y, 3, 1)
+    sigma_x = F.avg_pool2d(x ** 2, 3, 1) - mu_x ** 2
+    sigma_y = F.avg_pool2d(y ** 2, 3, 1) - mu_y ** 2
+    sigma_xy = F.avg_pool2d(x * y, 3, 1) - mu_x * mu_y
+    n = (2 * mu_x * mu_y + C1) * (2 * sigma_xy + C2)
+    d = (mu_x ** 2 + mu_y ** 2 + C1) * (sigma_x + sigma_y + C2)
+    return torch.clamp((1 - n / d) / 2, 0, 1)
+
+
+def compute_reprojection_loss(pred, target, use_ssim=True):
+    l1 = torch.abs(target - pred).mean(1, True)
+    if not use_ssim:
+        return l1
+    return 0.85 * ssim(pred, target).mean(1, True) + 0.15 * l1
+
+
+def backproject(depth, inv_K):
+    B, _, H, W = depth.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W)], 0).unsqueeze(0).repeat(B, 1, 1)
+    cam = torch.matmul(inv_K[:, :3, :3], pix)
+    cam = depth.view(B, 1, -1) * cam
+    return torch.cat([cam, torch.ones(B, 1, H * W)], 1)
+
+
+def project(points, K, T, H, W, eps=1e-7):
+    B = points.shape[0]
+    P = torch.matmul(K, T)[:, :3, :]
+    cam = torch.matmul(P, points)
+    pix = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + eps)
+    pix = pix.view(B, 2, H, W).permute(0, 2, 3, 1)
+    pix = torch.stack([pix[..., 0] / (W - 1), pix[..., 1] / (H - 1)], -1)
+    return (pix - 0.5) * 2
+
+
+def warp_frame(color, depth, K, inv_K, T):
+    H, W = depth.shape[-2:]
+    grid = project(backproject(depth, inv_K), K, T, H, W)
+    return F.grid_sample(color, grid, padding_mode="border", align_corners=False)
+
+
+def get_smooth_loss(disp, img, gamma=2):
+    gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
+    gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+    gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
+    giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
+    return (gdx * torch.exp(-gamma * gix)).mean() + (gdy * torch.exp(-gamma * giy)).mean()

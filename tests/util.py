@@ -52,3 +52,23 @@ def assert_close(a, b, rtol, what=""):
     assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
     err = max_rel(a, b)
     assert err <= rtol, "%s: max relative error %.3e > %.1e" % (what, err, rtol)
+
+
+def photo_case(B=2, H=24, W=40, seed=31):
+    """Two frames, a depth map, KITTI-like intrinsics and a small rigid motion — shared with the tests."""
+    tgt = synth.uniform((B, 3, H, W), "ph_tgt", seed, 0.0, 1.0).astype(np.float32)
+    src = synth.uniform((B, 3, H, W), "ph_src", seed, 0.0, 1.0).astype(np.float32)
+    # smooth the frames a little so the bilinear sampling gradient is informative
+    k = np.ones((3, 3), np.float32) / 9
+    for a in (tgt, src):
+        pad = np.pad(a, ((0, 0), (0, 0), (1, 1), (1, 1)), mode="edge")
+        a[:] = sum(pad[:, :, i:i + H, j:j + W] * k[i, j] for i in range(3) for j in range(3))
+    depth = synth.uniform((B, 1, H, W), "ph_depth", seed, 2.0, 30.0).astype(np.float32)
+    K = np.tile(np.array([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32), (B, 1, 1))
+    inv_K = np.linalg.inv(K).astype(np.float32)
+    T = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    for b in range(B):
+        ang = 0.02 * (b + 1)
+        T[b, :3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+        T[b, :3, 3] = [0.3 * (b + 1), -0.05, 0.4]
+    return tgt, src, depth, K, inv_K, T

@@ -69,6 +69,12 @@ class EvalKittiArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
 
 
+class WarpArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Hs", C.c_int), ("Ws", C.c_int),
+                ("eps", C.c_float), ("src", C.c_void_p), ("depth", C.c_void_p), ("K", C.c_void_p), ("inv_K", C.c_void_p),
+                ("T", C.c_void_p)]
+
+
 class HeadShiftsumArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pad_mode", C.c_int), ("scale", C.c_float),
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
@@ -134,6 +140,15 @@ SIGNATURES = {
     "wmd_eval_kitti": (C.c_int, [C.POINTER(EvalKittiArgs), C.c_void_p]),
     "wmd_eval_errors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_flip_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_ssim_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_void_p]),
+    "wmd_ssim_bwd_workspace_floats": (C.c_size_t, [C.c_int] * 4),
+    "wmd_ssim_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wmd_warp_fwd": (C.c_int, [C.POINTER(WarpArgs), C.c_void_p, C.c_void_p]),
+    "wmd_warp_bwd_workspace_floats": (C.c_size_t, [C.POINTER(WarpArgs)]),
+    "wmd_warp_bwd": (C.c_int, [C.POINTER(WarpArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wmd_smooth_workspace_floats": (C.c_size_t, [C.c_int] * 3),
+    "wmd_smooth_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wmd_smooth_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "wmd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wmd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "wmd_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),

@@ -265,14 +265,16 @@ __global__ __launch_bounds__(1024) void eval_metrics_kernel(const float* __restr
     }
 }
 
-__global__ void eval_metrics_finish_kernel(const double* __restrict__ partial, float* __restrict__ out, int B, int nblk) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double s9[9];
-    for (int k = 0; k < 9; ++k) s9[k] = 0.0;
-    for (int j = 0; j < nblk; ++j)
-        for (int k = 0; k < 9; ++k) s9[k] += partial[((size_t)b * nblk + j) * 9 + k];
-    ev_finish(s9, out + b * 9);
+__global__ __launch_bounds__(64) void eval_metrics_finish_kernel(const double* __restrict__ partial, float* __restrict__ out, int B, int nblk) {
+    const int b = blockIdx.x, lane = threadIdx.x;   // one wavefront per image; nblk <= 64: one partial per lane
+    __shared__ double s9[9];
+    for (int k = 0; k < 9; ++k) {
+        double s = lane < nblk ? partial[((size_t)b * nblk + lane) * 9 + k] : 0.0;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) s9[k] = s;
+    }
+    __syncthreads();
+    if (lane == 0) ev_finish(s9, out + b * 9);
 }
 
 // Monodepth-v1 flip post-processing; r_disp is the prediction for the flipped image, NOT flipped back
@@ -349,7 +351,7 @@ extern "C" int wmd_eval_kitti(const wmd_eval_kitti_args* g, void* stream) {
     ProfScope prof("eval_metrics_kernel", 30.0 * g->B * plane, 8.0 * g->B * plane, s);
     hipLaunchKernelGGL(eval_metrics_kernel, dim3(mblk, g->B), dim3(1024), 0, s, pd, gm, med, g->out, partial, plane, g->median_scaling,
                        g->min_depth, g->max_depth, 1);
-    if (mblk > 1) hipLaunchKernelGGL(eval_metrics_finish_kernel, dim3((g->B + 63) / 64), dim3(64), 0, s, partial, g->out, g->B, mblk);
+    if (mblk > 1) hipLaunchKernelGGL(eval_metrics_finish_kernel, dim3(g->B), dim3(64), 0, s, partial, g->out, g->B, mblk);
     return check_launch("eval_metrics_kernel");
 }
 
