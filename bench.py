@@ -55,6 +55,7 @@ def cpu_baseline(dec, feats, budget_s=20.0):
     cands = sorted({c for c in (avail, avail // 2, 64, 32, 16, 8) if 1 <= c <= avail}, reverse=True)
     probe = [f[:2] for f in cf]
     best, best_t = cands[-1], float("inf")
+    probe_fps = {}
     with torch.no_grad():
         for c in cands:
             torch.set_num_threads(c)
@@ -62,6 +63,7 @@ def cpu_baseline(dec, feats, budget_s=20.0):
             t0 = time.perf_counter()
             R.kitti_wave_decoder(probe, sd)
             dt = time.perf_counter() - t0
+            probe_fps[str(c)] = round(2 / dt, 1)
             if dt < best_t:
                 best, best_t = c, dt
         torch.set_num_threads(best)
@@ -74,6 +76,7 @@ def cpu_baseline(dec, feats, budget_s=20.0):
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return {"value": round(BATCH / med, 2), "unit": "frames/s", "cores": best, "kind": "port",
+            "probe_frames_per_s_by_threads": probe_fps,   # 2-frame batches; 8 threads is SURVEY.md's probe setting
             "sample": "%d timed passes of the same 12x640x192 batch (median %.3f s/pass) after 1 warm-up; torch %s CPU; "
                       "%d threads = best of %s on a 2-frame probe; host exposes %d hardware threads"
                       % (len(times), med, torch.__version__, best, cands, avail)}
@@ -192,12 +195,16 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             dec(feats)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread (extra fields only)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for k in range(args.steps):
             out = dec(feats)
+            marks[k + 1].record()
         barrier()
         elapsed = time.perf_counter() - t0
+        step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -249,6 +256,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_p10_median_p90": [round(step_ms[int(q * (len(step_ms) - 1))], 4) for q in (0.1, 0.5, 0.9)],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
