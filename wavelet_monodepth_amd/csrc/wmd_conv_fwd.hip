@@ -591,11 +591,13 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
         a.tiles_x = (a.W + 127) / 128;
         hipLaunchKernelGGL((conv_fwd_kernel<1, 128, 2, 4, 2, 2, 64, 1, true, 1>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
     } else if (g->C == 128) {
-        a.tiles_x = (a.W + 127) / 128;
-        hipLaunchKernelGGL((conv_fwd_kernel<1, 128, 4, 4, 2, 2, 32, 1, true>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
-    } else {
+        // coarse levels have few pixels: 64- / 32-pixel tiles (53 / 78 KB of LDS: 3 / 2 blocks per CU, 720 / 360 blocks) beat
+        // 128- / 64-pixel tiles by 20 % / 8 % although every weight fragment then feeds half as many MFMAs
         a.tiles_x = (a.W + 63) / 64;
-        hipLaunchKernelGGL((conv_fwd_kernel<1, 64, 4, 4, 4, 1, 32, 1, true>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 64, 4, 2, 2, 2, 32, 1, true>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
+    } else {
+        a.tiles_x = (a.W + 31) / 32;
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 32, 4, 2, 4, 1, 32, 1, true>), dim3(g->B * a.tiles_x, 2), dim3(256), 0, s, a);
     }
     return check_launch("conv_fwd_kernel<fused head>");
 }
