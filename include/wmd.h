@@ -119,6 +119,8 @@ typedef struct {
     size_t workspace_floats;
     int tune_cfg;       /* 0: built-in cost model; k>0: force tile configuration k-1     */
     int tune_ksplit;    /* 0: cost model; k>0: force k-way split of the Cin reduction    */
+    const float* wp_wino; /* optional (3x3 only): wmd_conv_pack_weights_wino image; enables the Winograd F(2x2,3x3)
+                             configurations ("conv_wino_kernel<...>": 2.25x fewer MFMAs, ~1e-6 relative rounding) */
 } wmd_conv_args;
 
 /* Fused  upsample(x1) ++ x2  ->  pad  ->  conv kxk  ->  + bias  ->  activation.
@@ -129,6 +131,12 @@ int wmd_conv_fwd(const wmd_conv_args* args, void* stream);
 
 /* Suggested workspace size (floats) for wmd_conv_fwd on this problem. */
 size_t wmd_conv_fwd_workspace_floats(const wmd_conv_args* args);
+
+/* Winograd-domain weight image of a 3x3 filter: U = G g G^T per (out, in) channel pair, in the fragment order of
+ * wmd_conv_pack_weights with 16 transformed positions in place of the 9 taps.  dgrad != 0: the transposed / flipped
+ * filter of the data-gradient pass.                                                                              */
+size_t wmd_conv_packed_weight_floats_wino(int Cout, int Cin);
+int wmd_conv_pack_weights_wino(const float* w, float* wp, int Cout, int Cin, int dgrad, void* stream);
 
 /* Tile-configuration table (for callers that autotune: wavelet_monodepth_amd/tuner.py).
  * wmd_conv_config_name returns e.g. "conv_fwd_kernel<8,32,2,4,1,4,8,9>" (the kernel's template

@@ -140,18 +140,19 @@ def test_conv_every_tile_configuration_and_split(dev):
         else:
             ref = torch.nn.functional.elu(R.conv1x1(x2, w, b))
         wp = ops.pack_weights(w.to(dev))
+        ww = ops.pack_weights_wino(w.to(dev))
         xa, xb = (x1.to(dev), x2.to(dev)) if k == 3 else (x2.to(dev), None)
         l = _lib.lib()
         tested = 0
         for i, name in enumerate(names):
-            if not name.endswith(",%d>" % (9 if k == 3 else 1)):
+            if not (name.endswith(",%d>" % (9 if k == 3 else 1)) or (k == 3 and name.startswith("conv_wino_kernel"))):
                 continue
             for ks in (1, 2, 3):
                 y = torch.full((B, Cout, H, W), float("nan"), device=dev)
                 a = _lib.ConvArgs(B=B, H=H, W=W, C1=xa.shape[1], up1=2 if k == 3 else 1, C2=0 if xb is None else C2, Cout=Cout,
                                   ksize=k, pad_mode=1, act=1, slope=0.0, x1=xa.data_ptr(), x2=None if xb is None else xb.data_ptr(),
                                   wp=wp.data_ptr(), bias=b.to(dev).data_ptr(), y=y.data_ptr(), workspace=None,
-                                  workspace_floats=0, tune_cfg=i + 1, tune_ksplit=ks)
+                                  workspace_floats=0, tune_cfg=i + 1, tune_ksplit=ks, wp_wino=None if ww is None else ww.data_ptr())
                 n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
                 ws = torch.empty(max(n, 1), device=dev)
                 a.workspace, a.workspace_floats = ws.data_ptr(), n
@@ -162,6 +163,48 @@ def test_conv_every_tile_configuration_and_split(dev):
                 assert_close(y, ref, OP_TOL, "%s ksplit %d" % (name, ks))
                 tested += 1
         assert tested >= (12 if k == 3 else 4)
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[7] == 3], ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_winograd_configurations(dev, case):
+    """Every Winograd F(2x2,3x3) configuration, forced, on every 3x3 case (pads, upsample + concat, odd sizes, ragged
+    channels, H = 1) against the oracle; the transform costs a little rounding: 5e-5 relative instead of 2e-5."""
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib, ops, tuner
+    B, C1, C2, up, Cout, H, W, k, pad, act = case
+    x1 = t(synth.normal((B, C1, H // up, W // up), "cx1", 3))
+    x2 = t(synth.normal((B, C2, H, W), "cx2", 3)) if C2 else None
+    w, b = [t(a) for a in synth.conv_params("cw", Cout, C1 + C2, k, 3)]
+    xin = R.up2(x1) if up == 2 else x1
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    slope = 0.1
+    ref = {"none": lambda v: v, "elu": torch.nn.functional.elu, "leaky": lambda v: torch.nn.functional.leaky_relu(v, slope),
+           "sigmoid": torch.sigmoid}[act](R.conv3x3(xin, w, b, pad))
+    wd, bd = w.to(dev), b.to(dev)
+    wp, ww = ops.pack_weights(wd), ops.pack_weights_wino(wd)
+    x1d, x2d = x1.to(dev), None if x2 is None else x2.to(dev)
+    l = _lib.lib()
+    tested = 0
+    for i, name in enumerate(tuner.config_names()):
+        if not name.startswith("conv_wino_kernel"):
+            continue
+        for ks in (1, 2):
+            y = torch.full((B, Cout, H, W), float("nan"), device=dev)
+            a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=C2, Cout=Cout, ksize=3, pad_mode=ops.PAD[pad], act=ops.ACT[act],
+                              slope=slope, x1=x1d.data_ptr(), x2=None if x2d is None else x2d.data_ptr(), wp=wp.data_ptr(),
+                              bias=bd.data_ptr(), y=y.data_ptr(), workspace=None, workspace_floats=0, tune_cfg=i + 1,
+                              tune_ksplit=ks, wp_wino=ww.data_ptr())
+            n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
+            ws = torch.empty(max(n, 1), device=dev)
+            a.workspace, a.workspace_floats = ws.data_ptr(), n
+            st = l.wmd_conv_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream)
+            if st == -3 and ks > 1:
+                continue
+            _lib.check(st, name)
+            assert_close(y, ref, 5e-5, "%s ksplit %d" % (name, ks))
+            tested += 1
+    assert tested >= 2
 
 
 def test_conv_rejects_bad_input(dev):

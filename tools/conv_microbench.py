@@ -35,12 +35,13 @@ for name in args.layers:
     w = torch.randn(Cout, C1 + C2, k, k, device=dev) * 0.05
     b = torch.randn(Cout, device=dev)
     wp = ops.pack_weights(w)
+    ww = ops.pack_weights_wino(w)
     for _ in range(3):
-        ops._conv_fwd_raw(x1, x2, wp, b, Cout, k, "reflect", act, 0.1, up)
+        ops._conv_fwd_raw(x1, x2, wp, b, Cout, k, "reflect", act, 0.1, up, ww)
     torch.cuda.synchronize()
     _lib.profile_begin()
     for _ in range(args.iters):
-        ops._conv_fwd_raw(x1, x2, wp, b, Cout, k, "reflect", act, 0.1, up)
+        ops._conv_fwd_raw(x1, x2, wp, b, Cout, k, "reflect", act, 0.1, up, ww)
     recs = _lib.profile_end()
     fl = 2.0 * (C1 + C2) * k * k * Cout * args.batch * H * W
     tot = sum(r["ms"] for r in recs) / args.iters

@@ -21,7 +21,8 @@ class ConvArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
                 ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int), ("slope", C.c_float),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int)]
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
+                ("wp_wino", C.c_void_p)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -114,6 +115,8 @@ SIGNATURES = {
     "wmd_conv_packed_weight_floats": (C.c_size_t, [C.c_int] * 3),
     "wmd_conv_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wmd_conv_pack_weights_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_conv_packed_weight_floats_wino": (C.c_size_t, [C.c_int, C.c_int]),
+    "wmd_conv_pack_weights_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wmd_conv_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "wmd_conv_fwd_workspace_floats": (C.c_size_t, [C.POINTER(ConvArgs)]),
     "wmd_conv_num_configs": (C.c_int, []),

@@ -379,6 +379,288 @@ __global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, con
     }
 }
 
+// ================================================================================================
+// Winograd F(2x2, 3x3) form of the same convolution: 2.25x fewer MFMAs per output.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          d: 4x4 input patch of a 2x2 output tile, g: 3x3 filter
+//
+// In the transformed domain every one of the 16 positions xi is an independent GEMM over the input channels,
+//   M_xi[tile, co] += V_xi[tile, ci] * U_xi[ci, co],
+// so the kernel keeps the staging of the direct kernel (the same LDS-DMA gather of the padded / upsampled /
+// concatenated halo patch, the same fragment-ordered weight image -- now with 16 "taps" = transformed positions, see
+// conv_pack_wino_kernel) and changes what happens between LDS and the matrix pipe:
+//   * a lane owns one tile (l & 15) and one channel of the K-step (l >> 4): it reads the tile's 4x4 patch from LDS at
+//     immediate offsets (16 ds_read_b32), computes B^T d B in registers (32 adds) and so holds the row operand of all
+//     16 positions -- no transformed-input buffer, no extra barrier;
+//   * a wave owns 16 tiles x MRW out-channel tiles x all 16 positions (16*MRW accumulator fragments), so the output
+//     transform A^T M A is lane-local as well: a lane's accumulator registers are 4 consecutive tiles of one channel;
+//   * bias + activation + 2 x (2 x 16-byte) stores per fragment row.
+// Block = WM x WN waves: WN tile groups (16 tiles = 64 output pixels each), WM * MRW * 16 out channels.
+// ================================================================================================
+template <int TH, int TW, int MRW, int WM, int WN, int CK>
+struct WinoTile {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int NPOSITIONS = PH * PW;
+    // per-channel LDS stride: odd (== 1 mod 32), so that the two k-lanes of a 32-lane ds_read_b32 group -- whose tile
+    // origins are 2 floats apart -- fall on even and on odd banks
+    static constexpr int PS = ((NPOSITIONS - 1 + 31) / 32) * 32 + 1;
+    static constexpr int NPOS = (NPOSITIONS + NT - 1) / NT;
+    static constexpr int TXW = TW / 2, TYH = TH / 2, NTILES = TXW * TYH;
+    static constexpr int A_RUN = (CK / 4) * 16 * 64;
+    static constexpr int A_FLOATS = WM * MRW * A_RUN;
+    static constexpr int B_FLOATS = ((CK * PS + 3) / 4) * 4;   // keeps the weight tile 16-byte aligned
+    static constexpr int NAV = (A_FLOATS / 4 + NT - 1) / NT;
+    static constexpr int LDS_FLOATS = 2 * (B_FLOATS + A_FLOATS);
+    static_assert(TH % 2 == 0 && TW % 8 == 0, "whole 2x2 tiles; four consecutive tiles of a lane stay in one tile row");
+    static_assert(WN * 16 >= NTILES, "more tiles than MFMA rows");
+    static_assert(CK % 4 == 0, "CK must be a whole number of 4-channel K-steps");
+};
+
+template <int TH, int TW, int MRW, int WM, int WN, int CK>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKArgs a) {   // <= 256 registers: 2 blocks per CU
+    using T = WinoTile<TH, TW, MRW, WM, WN, CK>;
+    constexpr int NT = T::NT, PW = T::PW, PS = T::PS, NPOS = T::NPOS, KSTEPS = CK / 4;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    float* ldsA = lds + 2 * T::B_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ks = blockIdx.z;
+    const int H = a.H, W = a.W;
+
+    // ---- staging geometry (identical to conv_fwd_kernel: see the comments there) -------------------------------
+    constexpr unsigned kOOB = 0x80000000u;
+    unsigned ob1[NPOS], ob2[NPOS];
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const int p = tid + i * NT;
+        const int py = p / PW, px = p % PW;
+        int gy = y0 + py - 1, gx = x0 + px - 1;
+        bool ok = p < T::NPOSITIONS;
+        ok = pad_coord(gy, H, a.pad_mode) && ok;
+        ok = pad_coord(gx, W, a.pad_mode) && ok;
+        ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
+        gy = min(max(gy, 0), H - 1);
+        gx = min(max(gx, 0), W - 1);
+        ob2[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
+        int sy = gy - a.shift1, sx = gx - a.shift1;
+        if (a.up1 == 2) {
+            sy = gy >> 1;
+            sx = gx >> 1;
+        }
+        const bool ok1 = ok && sy >= 0 && sx >= 0 && sy < a.H1 && sx < a.W1;
+        ob1[i] = ok1 ? (unsigned)(sy * a.W1 + sx) * 4u : kOOB;
+    }
+    const size_t plane1 = (size_t)a.H1 * a.W1, plane2 = (size_t)H * W;
+    const float* x1b = a.x1 + (size_t)b * a.C1 * plane1;
+    const float* x2b = a.x2 ? a.x2 + (size_t)b * a.C2 * plane2 : a.x1;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x1b), 0, (int)(a.C1 * plane1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x2b), 0, (int)(a.C2 * plane2 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wp), 0, (int)((size_t)a.ncot * a.nci4 * 16 * 64 * 4), 0x00020000);
+    const unsigned pb1 = (unsigned)(plane1 * 4), pb2 = (unsigned)(plane2 * 4);
+    unsigned aoff[T::NAV];
+#pragma unroll
+    for (int v = 0; v < T::NAV; ++v) {
+        const int e = tid + v * NT;
+        const int run = (e * 4) / T::A_RUN, rem = (e * 4) % T::A_RUN;
+        const int cot = min((int)blockIdx.y * WM * MRW + run, a.ncot - 1);
+        aoff[v] = (unsigned)(((size_t)cot * a.nci4 * 16 * 64 + rem) * 4);
+    }
+    constexpr int NPB = CK * NPOS, NPIECES = NPB + T::NAV;
+    auto stage_piece = [&](int chunk, int buf, int q) {
+        if (q < NPB) {
+            const int j = q / NPOS, i = q % NPOS;
+            const int ci = chunk * CK + j;
+            const bool from_x1 = ci < a.C1;
+            const bool chan_ok = ci < a.Cin;
+            const unsigned soff = from_x1 ? (unsigned)ci * pb1 : (unsigned)max(ci - a.C1, 0) * pb2;
+            if (NPOS * NT == T::NPOSITIONS || tid + i * NT < T::NPOSITIONS) {
+                const unsigned vo = chan_ok ? (from_x1 ? ob1[i] : ob2[i]) : kOOB;
+                lds_ptr_t d = (lds_ptr_t)(lds + buf * T::B_FLOATS + wave * 64 + j * PS + i * NT);
+                if (from_x1) lds_dma4(r1, d, vo, soff);
+                else lds_dma4(r2, d, vo, soff);
+            }
+        } else {
+            const int v = q - NPB;
+            const unsigned soffA = (unsigned)chunk * (unsigned)(T::A_RUN * 4);
+            if (T::NAV * NT * 4 == T::A_FLOATS || (tid + v * NT) * 4 < T::A_FLOATS)
+                lds_dma16(rw, (lds_ptr_t)(ldsA + buf * T::A_FLOATS + wave * 256 + v * NT * 4), aoff[v], soffA);
+        }
+    };
+
+    // ---- operand addressing -------------------------------------------------------------------------------------
+    // this lane's tile (row operand): tile slot wn*16 + (l & 15) -> patch origin (2 ty, 2 tx); channel lane l >> 4
+    const int tslot = min(wn * 16 + (lane & 15), T::NTILES - 1);
+    const int boff = (tslot / T::TXW) * 2 * PW + (tslot % T::TXW) * 2 + (lane >> 4) * PS;
+    const int a_lane = (wm * MRW) * T::A_RUN + lane;
+
+    f32x4 acc[16][MRW];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int m = 0; m < MRW; ++m) acc[xi][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int c_begin = ks * a.chunks_per_split;
+    const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
+    }
+    __syncthreads();
+
+    // One chunk = S = KSTEPS*16 groups (K-step, position) of MRW MFMAs each.  Explicitly software-pipelined and pinned
+    // with sched_barrier like the direct kernel: the weight fragments of group s+D, the 4x4 patch of the next K-step
+    // (16 ds_reads at group 2) and its transform (32 adds at group 10) are issued in the shadow of earlier MFMAs; the
+    // next chunk's DMA pieces are dealt out over the first two thirds of the groups.
+    auto chunk_body = [&](int c, auto prefetch) {
+        constexpr bool PREFETCH = decltype(prefetch)::value;
+        constexpr int S = KSTEPS * 16, D = 4, RS = D + 1, SP = (S * 2) / 3;
+        const int buf = (c - c_begin) & 1;
+        const float* bsrc = lds + buf * T::B_FLOATS + boff;
+        const float* asrc = ldsA + buf * T::A_FLOATS + a_lane;
+        float d[16], v[2][16], wf[RS][MRW];
+        auto fetch_patch = [&](int kk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) d[r * 4 + cc] = bsrc[kk * 4 * PS + r * PW + cc];
+        };
+        auto transform = [&](int kk) {   // V = B^T d B
+            float tr[16];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                tr[0 * 4 + cc] = d[0 * 4 + cc] - d[2 * 4 + cc];
+                tr[1 * 4 + cc] = d[1 * 4 + cc] + d[2 * 4 + cc];
+                tr[2 * 4 + cc] = d[2 * 4 + cc] - d[1 * 4 + cc];
+                tr[3 * 4 + cc] = d[1 * 4 + cc] - d[3 * 4 + cc];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[kk & 1][r * 4 + 0] = tr[r * 4 + 0] - tr[r * 4 + 2];
+                v[kk & 1][r * 4 + 1] = tr[r * 4 + 1] + tr[r * 4 + 2];
+                v[kk & 1][r * 4 + 2] = tr[r * 4 + 2] - tr[r * 4 + 1];
+                v[kk & 1][r * 4 + 3] = tr[r * 4 + 1] - tr[r * 4 + 3];
+            }
+        };
+        auto fetch_u = [&](int s2) {
+#pragma unroll
+            for (int m = 0; m < MRW; ++m) wf[s2 % RS][m] = asrc[m * T::A_RUN + s2 * 64];
+        };
+        fetch_patch(0);
+#pragma unroll
+        for (int s2 = 0; s2 < D && s2 < S; ++s2) fetch_u(s2);
+        transform(0);
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+            const int kk = s2 / 16, xi = s2 % 16;
+            if (s2 + D < S) fetch_u(s2 + D);
+            if (xi == 2 && kk + 1 < KSTEPS) fetch_patch(kk + 1);
+            if (xi == 10 && kk + 1 < KSTEPS) transform(kk + 1);
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int q = 0; q < NPIECES; ++q)
+                    if (q * SP / NPIECES == s2) stage_piece(c + 1, buf ^ 1, q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MRW; ++m)
+                acc[xi][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[kk & 1][xi], wf[s2 % RS][m], acc[xi][m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    for (int c = c_begin; c + 1 < c_end; ++c) chunk_body(c, std::true_type{});
+    if (c_begin < c_end) chunk_body(c_end - 1, std::false_type{});
+
+    // ---- epilogue: Y = A^T M A per (channel, tile); lane = (channel l & 15, tiles (l >> 4) * 4 + r) ---------------
+    const bool final_out = (a.ksplit == 1);
+    float* ybase = a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
+    const int tfirst = wn * 16 + (lane >> 4) * 4;          // first of this lane's four consecutive tiles (same tile row)
+    const int oy = y0 + (tfirst / T::TXW) * 2, ox = x0 + (tfirst % T::TXW) * 2;
+    const bool vec_ok = (W & 3) == 0;
+#pragma unroll
+    for (int m = 0; m < MRW; ++m) {
+        const int co = ((blockIdx.y * WM + wm) * MRW + m) * 16 + (lane & 15);
+        if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W) continue;
+        const float bv = (final_out && a.bias) ? a.bias[co] : 0.f;
+        float yrow[2][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float tt[2][4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                tt[0][cc] = acc[0 * 4 + cc][m][r] + acc[1 * 4 + cc][m][r] + acc[2 * 4 + cc][m][r];
+                tt[1][cc] = acc[1 * 4 + cc][m][r] - acc[2 * 4 + cc][m][r] - acc[3 * 4 + cc][m][r];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                yrow[j][2 * r + 0] = tt[j][0] + tt[j][1] + tt[j][2];
+                yrow[j][2 * r + 1] = tt[j][1] - tt[j][2] - tt[j][3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (oy + j >= H) continue;
+            float* dst = ybase + (size_t)co * plane2 + (size_t)(oy + j) * W + ox;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (final_out) yrow[j][e] = act_apply(yrow[j][e] + bv, a.act, a.slope);
+            if (vec_ok && ox + 7 < W) {
+                *reinterpret_cast<float4*>(dst) = make_float4(yrow[j][0], yrow[j][1], yrow[j][2], yrow[j][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(yrow[j][4], yrow[j][5], yrow[j][6], yrow[j][7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ox + e < W) dst[e] = yrow[j][e];
+            }
+        }
+    }
+}
+
+// Winograd weight image: the layout of conv_pack_kernel with 16 "taps" = transformed positions xi = 4a + b,
+//   U[a][b] = sum_{i,j} G[a][i] g[i][j] G[b][j],   G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]].
+__global__ void conv_pack_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ncot, int nci4,
+                                      int dgrad) {
+    const size_t total = (size_t)ncot * nci4 * 16 * 64;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int l = i & 63;
+        size_t r = i >> 6;
+        const int xi = r % 16;
+        r /= 16;
+        const int ci4 = r % nci4;
+        const int cot = r / nci4;
+        const int m = cot * 16 + (l & 15);
+        const int k = ci4 * 4 + (l >> 4);
+        float g[9];
+        bool ok;
+        if (!dgrad) {
+            ok = m < Cout && k < Cin;
+            for (int t = 0; t < 9; ++t) g[t] = ok ? w[((size_t)m * Cin + k) * 9 + t] : 0.f;
+        } else {
+            ok = m < Cin && k < Cout;
+            for (int t = 0; t < 9; ++t) g[t] = ok ? w[((size_t)k * Cin + m) * 9 + (8 - t)] : 0.f;
+        }
+        const int pa = xi / 4, pb = xi % 4;
+        float s = 0.f;
+        for (int ii = 0; ii < 3; ++ii)
+            for (int jj = 0; jj < 3; ++jj) s += G[pa][ii] * g[ii * 3 + jj] * G[pb][jj];
+        wp[i] = s;
+    }
+}
+
 // weights [Cout,Cin,k,k] -> fragment image [ncot][nci4][taps][64]; lane l holds
 // W[cot*16 + (l&15)][ci4*4 + (l>>4)][tap], zero outside.
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int taps,
@@ -426,6 +708,18 @@ static void launch_cfg(const ConvKArgs& a, dim3 grid, hipStream_t s) {
             "conv_fwd_kernel<" #TH "," #TW "," #MR "," #NR "," #WM "," #WN "," #CK "," #TAPS ">"         \
     }
 
+template <int TH, int TW, int MRW, int WM, int WN, int CK>
+static void launch_wino(const ConvKArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_wino_kernel<TH, TW, MRW, WM, WN, CK>), grid, dim3(WM * WN * 64), 0, s, a);
+}
+// Winograd entries reuse the table's fields: MR = out-channel tiles per wave, NR = 1 (a wave owns one group of 16
+// tiles = 64 pixels), TAPS = 16 transformed positions (this is what marks them).
+#define WMD_WINO(TH, TW, MRW, WM, WN, CK)                                                               \
+    ConvCfg {                                                                                           \
+        TH, TW, MRW, 1, WM, WN, CK, 16, (int)sizeof(float) * WinoTile<TH, TW, MRW, WM, WN, CK>::LDS_FLOATS, \
+            &launch_wino<TH, TW, MRW, WM, WN, CK>, "conv_wino_kernel<" #TH "," #TW "," #MRW "," #WM "," #WN "," #CK ">" \
+    }
+
 static const ConvCfg kCfgs[] = {
     // 3x3, 32-wide rows (W % 32 == 0: 160/320, 1024-wide pyramids)
     WMD_CFG(16, 32, 2, 8, 1, 4, 8, 9),  // co32  x 512px
@@ -468,6 +762,9 @@ static const ConvCfg kCfgs[] = {
     // generic small tile (any W)
     WMD_CFG(4, 16, 4, 4, 1, 1, 8, 9),   // co64 x 64px
     WMD_CFG(8, 16, 2, 4, 1, 2, 8, 9),   // co32 x 128px
+    // Winograd F(2x2,3x3): needs wmd_conv_args.wp_wino
+    WMD_WINO(8, 32, 2, 1, 4, 8),    // co32 x 256px (64 tiles)
+    WMD_WINO(8, 16, 2, 2, 2, 8),    // co64 x 128px (32 tiles)
     // 1x1 on the flattened image (TH = 1)
     WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
     WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px
@@ -500,7 +797,8 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
     bool found = false;
     for (int i = 0; i < kNumCfgs; ++i) {
         const ConvCfg& c = kCfgs[i];
-        if (c.TAPS != taps) continue;
+        const bool wino = c.TAPS == 16;
+        if (wino ? (taps != 9 || !g->wp_wino) : c.TAPS != taps) continue;
         if (force >= 0 && force != i) continue;
         const int tiles_x = (W + c.TW - 1) / c.TW, tiles_y = (H + c.TH - 1) / c.TH;
         const long tiles = (long)g->B * tiles_x * tiles_y;
@@ -511,7 +809,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         // blocks resident per CU: LDS (160 KiB) and ~2 waves/SIMD of these register-heavy kernels
         int bpc = std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, 8 / waves));
         bpc = std::max(bpc, 1);
-        const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * taps;
+        const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * c.TAPS;   // MFMA work (Winograd: 16 positions x 16 tiles)
         for (int ks = 1; ks <= 32; ++ks) {
             if (force_ks > 0 ? ks != force_ks : (ks & (ks - 1)) != 0 || ks > 16) continue;  // model: powers of two
             if (ks > 1 && (!have_ws || nchunks < ks)) continue;
@@ -526,6 +824,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             double per_cu_blocks = (double)rounds * std::min<double>(bpc, std::max(1.0, (double)nblk / kNumCU / rounds));
             double cycles = per_cu_blocks * block_macs_per_chunk * cps / std::max(rate, 1.0);
             cycles += 3000.0 * rounds;            // prologue/epilogue per block round
+            if (wino) cycles *= 1.3;              // transforms + 1.5 LDS reads per MFMA: measured, not modelled
             if (ks_eff > 1) cycles += 6000.0;     // reduce pass launch
             if (cycles < best) {
                 best = cycles;
@@ -635,6 +934,25 @@ extern "C" int wmd_conv_pack_weights_dgrad(const float* w, float* wp, int Cout, 
     return pack_common(w, wp, Cout, Cin, ksize, 1, stream);
 }
 
+extern "C" size_t wmd_conv_packed_weight_floats_wino(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    const size_t ncot = (Cout + 15) / 16;
+    const size_t nci4 = ((Cin + 15) / 16) * 4;
+    return ncot * nci4 * 16 * 64;
+}
+
+extern "C" int wmd_conv_pack_weights_wino(const float* w, float* wp, int Cout, int Cin, int dgrad, void* stream) {
+    if (!w || !wp) return fail(WMD_ERR_BAD_ARG, "wmd_conv_pack_weights_wino: null pointer");
+    if (Cout <= 0 || Cin <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_conv_pack_weights_wino: Cout=%d Cin=%d", Cout, Cin);
+    const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
+    const int ncot = (rows + 15) / 16, nci4 = ((red + 15) / 16) * 4;
+    const size_t total = (size_t)ncot * nci4 * 16 * 64;
+    ProfScope prof("conv_pack_wino_kernel", 0.0, 8.0 * total, (hipStream_t)stream);
+    hipLaunchKernelGGL(conv_pack_wino_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       wp, Cout, Cin, ncot, nci4, dgrad ? 1 : 0);
+    return check_launch("conv_pack_wino_kernel");
+}
+
 static int validate_conv(const wmd_conv_args* g, const char* who) {
     if (!g) return fail(WMD_ERR_BAD_ARG, "%s: null args", who);
     if (!g->x1 || !g->wp || !g->y) return fail(WMD_ERR_BAD_ARG, "%s: null tensor pointer", who);
@@ -683,11 +1001,12 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     ConvPlan plan;
     if (!plan_conv(g, &plan, g->workspace != nullptr, g->workspace_floats)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_fwd: no kernel configuration");
     const ConvCfg& c = *plan.cfg;
-    const int taps = c.TAPS;
+    const bool wino = c.TAPS == 16;           // Winograd configuration: transformed weight image, 3x3 semantics
+    const int taps = wino ? 9 : c.TAPS;
     ConvKArgs a;
     a.x1 = g->x1;
     a.x2 = g->C2 > 0 ? g->x2 : nullptr;
-    a.wp = g->wp;
+    a.wp = wino ? g->wp_wino : g->wp;
     a.bias = g->bias;
     a.B = g->B;
     a.H = plan.H;

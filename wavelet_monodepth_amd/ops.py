@@ -67,11 +67,39 @@ def pack_weights(weight, dgrad=False):
     return wp
 
 
+_WINOGRAD = os.environ.get("WMD_WINOGRAD", "1") != "0"
+
+
+def pack_weights_wino(weight, dgrad=False):
+    """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) fragment image U = G g G^T (wmd_conv_pack_weights_wino); memoised like
+    pack_weights.  Returns None for other kernel sizes or when WMD_WINOGRAD=0."""
+    if not _WINOGRAD or weight.shape[-1] != 3:
+        return None
+    l = _lib.lib()
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    slot = "_wmd_pack_wd" if dgrad else "_wmd_pack_wf"
+    if _PACK_CACHE:
+        hit = getattr(weight, slot, None)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+    cout, cin = weight.shape[:2]
+    rows, red = (cin, cout) if dgrad else (cout, cin)
+    wp = torch.empty(l.wmd_conv_packed_weight_floats_wino(rows, red), device=weight.device, dtype=torch.float32)
+    check(l.wmd_conv_pack_weights_wino(ptr(_c(weight.detach())), ptr(wp), cout, cin, int(dgrad), current_stream()),
+          "wmd_conv_pack_weights_wino")
+    if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
+        try:
+            setattr(weight, slot, (tag, wp))
+        except AttributeError:
+            pass
+    return wp
+
+
 # ---------------------------------------------------------------------------------------------
 # dense convolution
 # ---------------------------------------------------------------------------------------------
 
-def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1):
+def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None):
     l = _lib.lib()
     B, C1 = x1.shape[0], x1.shape[1]
     H, W = x1.shape[2] * up1, x1.shape[3] * up1
@@ -81,7 +109,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1):
     y = torch.empty((B, cout, H, W), device=x1.device, dtype=torch.float32)
     a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad], act=ACT[act],
                       slope=float(slope), x1=ptr(x1), x2=ptr(x2), wp=ptr(wp), bias=ptr(bias), y=ptr(y),
-                      workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0)
+                      workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_wino=ptr(wp_wino))
     stream = current_stream()
     keep = []
 
@@ -100,6 +128,8 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1):
     choice = (0, 0)
     if tuner.enabled:
         key = "conv|%d|%d|%d|%d|%d|%d|%d|%d" % (B, H, W, C1, up1, C2, cout, ksize)  # str: JSON-cacheable
+        if wp_wino is None and ksize == 3:
+            key += "|direct"   # a choice made with the Winograd configurations on offer must not be reused without them
         choice = tuner.lookup(key)
         if choice is None:
             if torch.cuda.is_current_stream_capturing():
@@ -115,7 +145,7 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x1, x2, weight, bias, ksize, pad, act, slope, up1):
         x1c, x2c = _c(x1), _c(x2)
         wp = pack_weights(weight)
-        y = _conv_fwd_raw(x1c, x2c, wp, _c(bias), weight.shape[0], ksize, pad, act, slope, up1)
+        y = _conv_fwd_raw(x1c, x2c, wp, _c(bias), weight.shape[0], ksize, pad, act, slope, up1, pack_weights_wino(weight))
         ctx.save_for_backward(x1c, x2c, weight, y)
         ctx.has_x2 = x2 is not None
         ctx.has_bias = bias is not None
