@@ -158,6 +158,7 @@ typedef struct {
     size_t workspace_floats;
     int tune_cfg;       /* as in wmd_conv_args: 0 = cost model, k > 0 forces configuration k-1 */
     int tune_ksplit;
+    const float* wp_dgrad_wino; /* optional (3x3): wmd_conv_pack_weights_wino(..., dgrad = 1) image, enables Winograd */
 } wmd_conv_dgrad_args;
 
 size_t wmd_conv_dgrad_workspace_floats(const wmd_conv_dgrad_args* args);

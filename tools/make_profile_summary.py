@@ -39,9 +39,9 @@ for k in f:
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
         row["mfma_busy_frac"] = (sum(mb[k]) / len(mb[k])) / ((sum(ga[k]) / len(ga[k])) / 8 * 1024)
     out[k] = row
-    m = re.search(r"conv_fwd_kernel<([0-9a-z, ]+)>", k)
+    m = re.search(r"(conv_fwd_kernel|conv_wino_kernel)<([0-9a-z, ]+)>", k)
     if m:
-        name = "conv_fwd_kernel<" + m.group(1).replace(" ", "").replace(",false,2", "") + ">"
+        name = m.group(1) + "<" + m.group(2).replace(" ", "").replace(",false,2", "") + ">"
         if "true" in name:
             continue
         traffic[name] = {"traffic_bytes_per_launch": int((2 * row["FETCH_SIZE_KiB_avg"] + row["WRITE_SIZE_KiB_avg"]) * 1024),

@@ -29,7 +29,8 @@ class ConvDgradArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
                 ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int),
                 ("dz", C.c_void_p), ("wp_dgrad", C.c_void_p), ("dx1", C.c_void_p), ("dx2", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int)]
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
+                ("wp_dgrad_wino", C.c_void_p)]
 
 
 class ConvWgradArgs(C.Structure):

@@ -497,6 +497,7 @@ static void dgrad_conv_args(const wmd_conv_dgrad_args* g, wmd_conv_args* c, floa
     c->act = WMD_ACT_NONE;
     c->x1 = g->dz;
     c->wp = g->wp_dgrad;
+    c->wp_wino = g->ksize == 3 ? g->wp_dgrad_wino : nullptr;
     c->y = gbuf;
     c->workspace = ws;
     c->workspace_floats = ws_floats;

@@ -765,6 +765,18 @@ static const ConvCfg kCfgs[] = {
     // Winograd F(2x2,3x3): needs wmd_conv_args.wp_wino
     WMD_WINO(8, 32, 2, 1, 4, 8),    // co32 x 256px (64 tiles)
     WMD_WINO(8, 16, 2, 2, 2, 8),    // co64 x 128px (32 tiles)
+    WMD_WINO(16, 16, 2, 1, 4, 8),   // co32 x 256px, square tile
+    WMD_WINO(4, 32, 2, 2, 2, 8),    // co64 x 128px, one tile row pair
+    WMD_WINO(4, 64, 2, 1, 4, 8),    // co32 x 256px, 64-wide
+    WMD_WINO(8, 32, 2, 2, 4, 8),    // co64 x 256px, 8 waves
+    WMD_WINO(6, 40, 2, 1, 4, 8),    // co32 x 240px (60 of 64 tile slots): 40-wide rows, H % 6 == 0
+    WMD_WINO(6, 40, 2, 2, 4, 8),    // co64 x 240px, 8 waves
+    WMD_WINO(4, 40, 2, 1, 3, 8),    // co32 x 160px (40 of 48 tile slots), 3 waves
+    WMD_WINO(4, 40, 2, 2, 3, 8),    // co64 x 160px, 6 waves
+    WMD_WINO(8, 16, 2, 4, 2, 8),    // co128 x 128px, 8 waves
+    WMD_WINO(8, 32, 1, 2, 4, 8),    // co32 x 256px, 8 waves with one out-channel tile each (<= 128 registers: 4 waves / SIMD)
+    WMD_WINO(8, 16, 1, 4, 2, 8),    // co64 x 128px, 8 waves, one out-channel tile each
+    WMD_WINO(8, 16, 1, 2, 2, 8),    // co32 x 128px, 4 waves, one out-channel tile each
     // 1x1 on the flattened image (TH = 1)
     WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
     WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px

@@ -171,11 +171,12 @@ class _ConvFn(torch.autograd.Function):
         dx1 = dx2 = dw = db = None
         if need_x1 or need_x2:
             wpd = pack_weights(weight, dgrad=True)
+            wpdw = pack_weights_wino(weight, dgrad=True)   # kept alive in this scope for the launch
             dx1 = torch.empty_like(x1) if need_x1 else None
             dx2 = torch.empty_like(x2) if need_x2 else None
             a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
                                    dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=ptr(dx2), workspace=None,
-                                   workspace_floats=0, tune_cfg=0, tune_ksplit=0)
+                                   workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_dgrad_wino=ptr(wpdw))
             _dgrad_launch(a, dy.device, 9 if ksize == 3 else 1)
         if need_w or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw = torch.empty_like(weight)
@@ -276,6 +277,8 @@ def _dgrad_launch(a, device, taps):
     choice = (0, 0)
     if tuner.enabled:
         key = "dgrad|%d|%d|%d|%d|%d|%d|%d|%d|%d" % (a.B, a.H, a.W, a.C1, a.up1, a.C2, a.Cout, a.ksize, int(bool(a.dx1)) + 2 * int(bool(a.dx2)))
+        if a.ksize == 3 and not a.wp_dgrad_wino:
+            key += "|direct"
         choice = tuner.lookup(key)
         if choice is None:
             if torch.cuda.is_current_stream_capturing():
@@ -296,10 +299,11 @@ def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, ne
     dx1 = dw = db = None
     if need_x:
         wpd = pack_weights(weight, dgrad=True)
+        wpdw = pack_weights_wino(weight, dgrad=True)
         dx1 = torch.empty_like(x1)
         a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
                                dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=None, workspace=None, workspace_floats=0,
-                               tune_cfg=0, tune_ksplit=0)
+                               tune_cfg=0, tune_ksplit=0, wp_dgrad_wino=ptr(wpdw))
         _dgrad_launch(a, dz.device, 9 if ksize == 3 else 1)
     if need_w:
         dw = torch.empty_like(weight)
