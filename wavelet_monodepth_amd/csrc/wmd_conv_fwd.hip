@@ -81,6 +81,14 @@ struct ConvTile {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and every XCD has its own L2.  Spatially adjacent
+// tiles share halo rows and 128-byte lines, so give each XCD one contiguous run of the tile sequence instead of every
+// eighth tile (speed only: correctness never depends on the placement).
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // LDS-DMA wrappers.  They are deliberately NOT templates: inside a dependent context hipcc's host pass rejects
 // the 16-byte form (a gfx950 feature check against the host target) and silently drops the kernel's host stub.
 __device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const int wm = wave % WM;
     const int wn = wave / WM;
 
-    int t = blockIdx.x;
+    int t = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     const int wm = wave % WM;
     const int wn = wave / WM;
 
-    int t = blockIdx.x;
+    int t = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
@@ -777,6 +785,9 @@ static const ConvCfg kCfgs[] = {
     WMD_WINO(8, 32, 1, 2, 4, 8),    // co32 x 256px, 8 waves with one out-channel tile each (<= 128 registers: 4 waves / SIMD)
     WMD_WINO(8, 16, 1, 4, 2, 8),    // co64 x 128px, 8 waves, one out-channel tile each
     WMD_WINO(8, 16, 1, 2, 2, 8),    // co32 x 128px, 4 waves, one out-channel tile each
+    WMD_WINO(4, 32, 1, 2, 2, 8),    // co32 x 128px, 4 waves; a tile group = one row of 16 tiles: no LDS bank conflicts
+    WMD_WINO(4, 32, 1, 4, 2, 8),    // co64 x 128px, 8 waves
+    WMD_WINO(6, 40, 1, 2, 4, 8),    // co32 x 240px, 8 waves
     // 1x1 on the flattened image (TH = 1)
     WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
     WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px
