@@ -490,15 +490,24 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     auto stage_piece = [&](int chunk, int buf, int q) {
         if (q < NPB) {
             const int j = q / NPOS, i = q % NPOS;
-            const int ci = chunk * CK + j;
-            const bool from_x1 = ci < a.C1;
-            const bool chan_ok = ci < a.Cin;
-            const unsigned soff = from_x1 ? (unsigned)ci * pb1 : (unsigned)max(ci - a.C1, 0) * pb2;
+            const int ci0 = chunk * CK;
             if (NPOS * NT == T::NPOSITIONS || tid + i * NT < T::NPOSITIONS) {
-                const unsigned vo = chan_ok ? (from_x1 ? ob1[i] : ob2[i]) : kOOB;
                 lds_ptr_t d = (lds_ptr_t)(lds + buf * T::B_FLOATS + wave * 64 + j * PS + i * NT);
-                if (from_x1) lds_dma4(r1, d, vo, soff);
-                else lds_dma4(r2, d, vo, soff);
+                // a chunk that lies entirely in one source tensor (the usual case: C1, C2 multiples of CK) needs no
+                // per-channel descriptor / offset selection: one wave-uniform branch, one scalar add per piece
+                if (ci0 + CK <= a.C1) {
+                    lds_dma4(r1, d, ob1[i], (unsigned)(ci0 + j) * pb1);
+                } else if (ci0 >= a.C1 && ci0 + CK <= a.Cin) {
+                    lds_dma4(r2, d, ob2[i], (unsigned)(ci0 + j - a.C1) * pb2);
+                } else {
+                    const int ci = ci0 + j;
+                    const bool from_x1 = ci < a.C1;
+                    const bool chan_ok = ci < a.Cin;
+                    const unsigned soff = from_x1 ? (unsigned)ci * pb1 : (unsigned)max(ci - a.C1, 0) * pb2;
+                    const unsigned vo = chan_ok ? (from_x1 ? ob1[i] : ob2[i]) : kOOB;
+                    if (from_x1) lds_dma4(r1, d, vo, soff);
+                    else lds_dma4(r2, d, vo, soff);
+                }
             }
         } else {
             const int v = q - NPB;
