@@ -103,3 +103,32 @@ def test_photo_errors(dev):
         ph.SSIM()(torch.zeros(1, 3, 1, 4, device=dev), torch.zeros(1, 3, 1, 4, device=dev))   # reflection padding needs H >= 2
     with pytest.raises(_lib.WmdError):
         ph.get_smooth_loss(torch.zeros(1, 2, 4, 4, device=dev), torch.zeros(1, 3, 4, 4, device=dev))
+
+
+@pytest.mark.parametrize("hints", [False, True])
+def test_trainer_loss_orchestration_vs_oracle(dev, hints):
+    """generate_images_pred + compute_losses (KITTI/trainer.py:329-560) on the HIP operators vs the torch-CPU oracle:
+    scalar losses, auto-mask agreement and gradients w.r.t. every disparity scale and the poses."""
+    from util import loss_case
+    inp, out = loss_case(hints=hints)
+    opt = ph.LossOptions(height=32, width=64, frame_ids=[0, -1, 1] + (["s"] if hints else []), use_depth_hints=hints)
+    grad_keys = [("disp", s) for s in range(4)] + [("cam_T_cam", 0, -1), ("cam_T_cam", 0, 1)]
+
+    def run(device, mod):
+        i2 = {k: torch.from_numpy(v).to(device) for k, v in inp.items()}
+        o2 = {k: torch.from_numpy(v).to(device).requires_grad_(k in grad_keys) for k, v in out.items()}
+        mod.generate_images_pred(i2, o2, opt)
+        losses = mod.compute_losses(i2, o2, opt, tie_break_noise=0.0) if mod is ph else mod.compute_losses(i2, o2, opt)
+        losses["loss"].backward()
+        return losses, o2
+
+    lg, og = run(dev, ph)
+    lc, oc = run(torch.device("cpu"), P)
+    for k in lc:
+        np.testing.assert_allclose(float(lg[k]), float(lc[k]), rtol=2e-4, atol=1e-6, err_msg=k)
+    for s in range(4):
+        a, b = og["identity_selection/%d" % s].cpu(), oc["identity_selection/%d" % s]
+        assert float((a != b).float().mean()) < 2e-3          # ties within rounding may fall either way
+    for k in grad_keys:
+        ga, gb = og[k].grad.cpu().numpy(), oc[k].grad.numpy()
+        assert np.abs(ga - gb).max() <= 2e-3 * np.abs(gb).max() + 1e-7, k

@@ -72,3 +72,34 @@ def photo_case(B=2, H=24, W=40, seed=31):
         T[b, :3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
         T[b, :3, 3] = [0.3 * (b + 1), -0.05, 0.4]
     return tgt, src, depth, K, inv_K, T
+
+
+def loss_case(B=2, H=32, W=64, seed=17, hints=False):
+    """A synthetic minibatch for the photometric loss: colour pyramids of frames 0, -1, 1 (and "s"), intrinsics, poses,
+    4 disparity scales.  -> (inputs, outputs) dicts of numpy arrays keyed like the reference trainer's."""
+    from wavelet_monodepth_amd import synth
+    frame_ids = [0, -1, 1] + (["s"] if hints else [])
+    inputs, outputs = {}, {}
+    k3 = np.ones((3, 3), np.float32) / 9
+    for f in frame_ids:
+        img = synth.uniform((B, 3, H, W), "lc_img%s" % f, seed, 0.0, 1.0).astype(np.float32)
+        pad = np.pad(img, ((0, 0), (0, 0), (1, 1), (1, 1)), mode="edge")
+        img = sum(pad[:, :, i:i + H, j:j + W] * k3[i, j] for i in range(3) for j in range(3)).astype(np.float32)
+        for s in range(4):
+            h, w = H >> s, W >> s
+            inputs[("color", f, s)] = img.reshape(B, 3, h, 1 << s, w, 1 << s).mean((3, 5)).astype(np.float32)
+    K = np.tile(np.array([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32), (B, 1, 1))
+    inputs[("K", 0)], inputs[("inv_K", 0)] = K, np.linalg.inv(K).astype(np.float32)
+    for f, tx in ((-1, -0.2), (1, 0.25)):
+        T = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+        T[:, 0, 3], T[:, 2, 3] = tx, 0.1 * tx
+        outputs[("cam_T_cam", 0, f)] = T
+    st = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    st[:, 0, 3] = 0.1
+    inputs["stereo_T"] = st
+    for s in range(4):
+        outputs[("disp", s)] = synth.uniform((B, 1, H >> s, W >> s), "lc_disp%d" % s, seed, 0.05, 0.9).astype(np.float32)
+    if hints:
+        inputs["depth_hint"] = synth.uniform((B, 1, H, W), "lc_hint", seed, 1.0, 40.0).astype(np.float32)
+        inputs["depth_hint_mask"] = (synth.uniform((B, 1, H, W), "lc_hmask", seed, 0.0, 1.0) > 0.3).astype(np.float32)
+    return inputs, outputs

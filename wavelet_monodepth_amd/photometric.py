@@ -6,6 +6,7 @@ libwmd_hip.so (csrc/wmd_photo.hip).  Names follow the reference:
     warp_frame(color, depth, K, inv_K, T)         BackprojectDepth + Project3D + F.grid_sample(padding_mode="border")
                                                   (KITTI/layers.py:176-229, KITTI/trainer.py:352-372) fused
     get_smooth_loss(disp, img, gamma=2)           KITTI/layers.py:238-252
+    generate_images_pred / compute_loss_masks / compute_losses   the trainer's orchestration (KITTI/trainer.py:329-560)
 No CPU fallback: CPU tensors raise.
 """
 import ctypes as C
@@ -141,3 +142,117 @@ def get_smooth_loss(disp, img, gamma=2):
     if disp.shape[1] != 1:
         raise _lib.WmdError("disp must be [B,1,H,W]")
     return _SmoothFn.apply(disp, img, gamma)
+
+
+# ---------------------------------------------------------------------------------------------
+# The trainer's loss orchestration on top of the operators above (KITTI/trainer.py:329-560).  Plain tensor bookkeeping:
+# which frames are warped, the per-pixel minimum over frames, auto-masking against the identity reprojection, the
+# depth-hint selection, the per-scale weighting.  Option names follow the reference's `opt`.
+# ---------------------------------------------------------------------------------------------
+
+class LossOptions:
+    """The fields of the reference's option object that the loss uses (KITTI/options.py defaults)."""
+
+    def __init__(self, height=192, width=640, frame_ids=(0, -1, 1), loss_scales=(0, 1, 2, 3), min_depth=0.1, max_depth=100.0,
+                 v1_multiscale=False, disable_automasking=False, avg_reprojection=False, no_ssim=False, use_depth_hints=False,
+                 disparity_smoothness=1e-3):
+        self.height, self.width = height, width
+        self.frame_ids, self.loss_scales = list(frame_ids), list(loss_scales)
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self.v1_multiscale, self.disable_automasking, self.avg_reprojection = v1_multiscale, disable_automasking, avg_reprojection
+        self.no_ssim, self.use_depth_hints, self.disparity_smoothness = no_ssim, use_depth_hints, disparity_smoothness
+
+
+def generate_images_pred(inputs, outputs, opt):
+    """trainer.py:329-392 (pose_model_type != "posecnn"): every ("disp", s) -> full-resolution depth -> the source frames
+    warped into the target view, stored as outputs[("depth", 0, s)] and outputs[("color", frame_id, s)]."""
+    from . import ops
+    for scale in opt.loss_scales:
+        disp = outputs[("disp", scale)]
+        if opt.v1_multiscale:
+            source_scale = scale
+            min_disp, max_disp = 1 / opt.max_depth, 1 / opt.min_depth
+            depth = 1 / (min_disp + (max_disp - min_disp) * disp)
+        else:
+            source_scale = 0
+            _, depth = ops.upsample_bilinear(disp, (opt.height, opt.width), align_corners=False,
+                                             depth_range=(opt.min_depth, opt.max_depth))   # upsample + disp_to_depth, one kernel
+        outputs[("depth", 0, scale)] = depth
+        for frame_id in opt.frame_ids[1:]:
+            T = inputs["stereo_T"] if frame_id == "s" else outputs[("cam_T_cam", 0, frame_id)]
+            outputs[("color", frame_id, scale)] = warp_frame(inputs[("color", frame_id, source_scale)], depth,
+                                                             inputs[("K", source_scale)], inputs[("inv_K", source_scale)], T)
+            if not opt.disable_automasking:
+                outputs[("color_identity", frame_id, scale)] = inputs[("color", frame_id, source_scale)]
+    if opt.use_depth_hints and "s" in opt.frame_ids[1:]:
+        outputs[("color_depth_hint", "s", 0)] = warp_frame(inputs[("color", "s", 0)], inputs["depth_hint"], inputs[("K", 0)],
+                                                           inputs[("inv_K", 0)], inputs["stereo_T"])
+    return outputs
+
+
+def compute_loss_masks(reprojection_loss, identity_reprojection_loss, depth_hint_reprojection_loss):
+    """trainer.py:425-458."""
+    depth_hint_loss_mask = None
+    if identity_reprojection_loss is None:
+        reprojection_loss_mask = torch.ones_like(reprojection_loss)
+        if depth_hint_reprojection_loss is not None:
+            idxs = torch.argmin(torch.cat([reprojection_loss, depth_hint_reprojection_loss], dim=1), dim=1, keepdim=True)
+            depth_hint_loss_mask = (idxs == 1).float()
+    else:
+        parts = [reprojection_loss, identity_reprojection_loss]
+        if depth_hint_reprojection_loss is not None:
+            parts.append(depth_hint_reprojection_loss)
+        idxs = torch.argmin(torch.cat(parts, dim=1), dim=1, keepdim=True)
+        reprojection_loss_mask = (idxs != 1).float()   # the auto-mask has index 1
+        if depth_hint_reprojection_loss is not None:
+            depth_hint_loss_mask = (idxs == 2).float()
+    return reprojection_loss_mask, depth_hint_loss_mask
+
+
+def compute_losses(inputs, outputs, opt, tie_break_noise=None):
+    """trainer.py:460-560 (compute_losses_hints; without depth hints it is Monodepth2's loss with the minimum taken as we
+    go).  `tie_break_noise`: None draws the reference's randn * 1e-5 on the identity loss; a float (0.0 in the tests)
+    multiplies a fixed zero field instead."""
+    losses = {}
+    total_loss = 0
+    depth_hint_reproj_loss = None
+    if opt.use_depth_hints:
+        depth_hint_reproj_loss = compute_reprojection_loss(outputs[("color_depth_hint", "s", 0)], inputs[("color", 0, 0)],
+                                                           no_ssim=opt.no_ssim)
+        depth_hint_reproj_loss = depth_hint_reproj_loss + 1000 * (1 - inputs["depth_hint_mask"])
+    for scale in opt.loss_scales:
+        source_scale = scale if opt.v1_multiscale else 0
+        disp = outputs[("disp", scale)]
+        color = inputs[("color", 0, scale)]
+        target = inputs[("color", 0, source_scale)]
+        reproj = torch.cat([compute_reprojection_loss(outputs[("color", f, scale)], target, no_ssim=opt.no_ssim)
+                            for f in opt.frame_ids[1:]], 1)
+        if opt.disable_automasking:
+            raise NotImplementedError   # as the reference (trainer.py:506)
+        ident = torch.cat([compute_reprojection_loss(inputs[("color", f, source_scale)], target, no_ssim=opt.no_ssim)
+                           for f in opt.frame_ids[1:]], 1)
+        if opt.avg_reprojection:
+            identity_loss = ident.mean(1, keepdim=True)
+            reprojection_loss = reproj.mean(1, keepdim=True)
+        else:
+            identity_loss, _ = torch.min(ident, dim=1, keepdim=True)
+            reprojection_loss, _ = torch.min(reproj, dim=1, keepdim=True)
+        if tie_break_noise is None:   # "add random numbers to break ties" (trainer.py:517-520)
+            identity_loss = identity_loss + torch.randn(identity_loss.shape, device=identity_loss.device) * 0.00001
+        reprojection_loss_mask, depth_hint_loss_mask = compute_loss_masks(reprojection_loss, identity_loss, depth_hint_reproj_loss)
+        reprojection_loss = (reprojection_loss * reprojection_loss_mask).sum() / (reprojection_loss_mask.sum() + 1e-7)
+        outputs["identity_selection/{}".format(scale)] = (1 - reprojection_loss_mask).float()
+        losses["reproj_loss/{}".format(scale)] = reprojection_loss
+        depth_hint_loss = 0
+        if opt.use_depth_hints:
+            dh = torch.log(torch.abs(inputs["depth_hint"] - outputs[("depth", 0, scale)]) + 1) * inputs["depth_hint_mask"]
+            depth_hint_loss = (dh * depth_hint_loss_mask).sum() / (depth_hint_loss_mask.sum() + 1e-7)
+            outputs["depth_hint_pixels/{}".format(scale)] = depth_hint_loss_mask
+            losses["depth_hint_loss/{}".format(scale)] = depth_hint_loss
+        loss = reprojection_loss + depth_hint_loss
+        norm_disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
+        loss = loss + opt.disparity_smoothness * get_smooth_loss(norm_disp, color) / (2 ** scale)
+        total_loss = total_loss + loss
+        losses["loss/{}".format(scale)] = loss
+    losses["loss"] = total_loss / len(opt.loss_scales)
+    return losses
