@@ -181,6 +181,21 @@ size_t wmd_conv_wgrad_workspace_floats(const wmd_conv_wgrad_args* args);
 /* Weight + bias gradient (deterministic two-stage split over the B*H*W reduction). */
 int wmd_conv_wgrad(const wmd_conv_wgrad_args* args, void* stream);
 
+/* Depthwise 3x3 + ReLU over the same virtual input (upsample(x1) ++ x2, padded): the first half of the NYUv2 decoders'
+ * optional `is_depthwise` Conv3x3 (NYUv2/networks/layers.py:23-25,70-79); its bias-free 1x1 second half is an
+ * ordinary wmd_conv_fwd.  w [C1+C2,1,3,3]; y, dy [B,C1+C2,H,W].  Backward: dx1 / dx2 / dw may each be NULL.          */
+typedef struct {
+    int B, H, W;
+    int C1, up1, C2, pad_mode;
+    const float* x1;
+    const float* x2;
+    const float* w;
+} wmd_dwconv_args;
+int wmd_dwconv3x3_fwd(const wmd_dwconv_args* args, float* y, void* stream);
+size_t wmd_dwconv3x3_bwd_workspace_floats(const wmd_dwconv_args* args);
+int wmd_dwconv3x3_bwd(const wmd_dwconv_args* args, const float* y, const float* dy, float* dx1, float* dx2, float* dw,
+                      float* workspace, size_t workspace_floats, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Wavelet heads: 3x3 convolutions with 1..3 output channels (HBM-bound)
  * ------------------------------------------------------------------ */

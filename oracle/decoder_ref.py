@@ -435,23 +435,41 @@ def kitti_sparse_decoder(feats, sd, thresh_ratio=0.05, sparse_scales=(0, 1, 2, 3
 # --------------------------------------------------------------------------------------------
 
 
-def nyu_wave_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0.5):
+def _nyu_conv_shapes(sh, key, cout, cin, depthwise):
+    if depthwise:
+        sh[key + ".conv.0.0.weight"] = (cin, 1, 3, 3)
+        sh[key + ".conv.1.weight"] = (cout, cin, 1, 1)
+    else:
+        sh[key + ".conv.weight"] = (cout, cin, 3, 3)
+        sh[key + ".conv.bias"] = (cout,)
+
+
+def nyu_wave_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0.5, dw_waveconv=False, dw_upconv=False):
     """DecoderWave parameters (NYUv2/networks/decoders/densedepth_decoder.py:93-115)."""
     f = int(enc_features[-1] * decoder_width)
     e = list(enc_features)
-    return {
-        "conv2.conv.weight": (f, e[-1], 3, 3), "conv2.conv.bias": (f,),
-        "up1.convA.conv.weight": (f // 2, f + e[-2], 3, 3), "up1.convA.conv.bias": (f // 2,),
-        "wave1_ll.conv.weight": (1, f // 2, 3, 3), "wave1_ll.conv.bias": (1,),
-        "wave1.conv.weight": (3, f // 2, 3, 3), "wave1.conv.bias": (3,),
-        "up2.convA.conv.weight": (f // 4, f // 2 + e[-3], 3, 3), "up2.convA.conv.bias": (f // 4,),
-        "wave2.conv.weight": (3, f // 4, 3, 3), "wave2.conv.bias": (3,),
-        "up3.convA.conv.weight": (f // 8, f // 4 + e[-4], 3, 3), "up3.convA.conv.bias": (f // 8,),
-        "wave3.conv.weight": (3, f // 8, 3, 3), "wave3.conv.bias": (3,),
-    }
+    sh = {"conv2.conv.weight": (f, e[-1], 3, 3), "conv2.conv.bias": (f,),
+          "wave1_ll.conv.weight": (1, f // 2, 3, 3), "wave1_ll.conv.bias": (1,)}
+    cin = f
+    for k in (1, 2, 3):
+        cout = f // (2 ** k)
+        _nyu_conv_shapes(sh, "up%d.convA" % k, cout, cin + e[-1 - k], dw_upconv)
+        _nyu_conv_shapes(sh, "wave%d" % k, 3, cout, dw_waveconv)
+        cin = cout
+    return sh
 
 
-def nyu_baseline_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0.5, variant224=False):
+def nyu_conv3x3(x, sd, key, pad):
+    """NYUv2 Conv3x3 (NYUv2/networks/layers.py:11-32): plain (key.conv.weight/bias) or, with is_depthwise, depthwise 3x3
+    without bias -> ReLU -> 1x1 without bias (key.conv.0.0.weight, key.conv.1.weight; :23-25,70-79)."""
+    if key + ".conv.weight" in sd:
+        return conv3x3(x, sd[key + ".conv.weight"], sd[key + ".conv.bias"], pad)
+    wd = sd[key + ".conv.0.0.weight"]
+    mid = F.relu(F.conv2d(pad1(x, pad), wd, None, groups=wd.shape[0]))
+    return F.conv2d(mid, sd[key + ".conv.1.weight"], None)
+
+
+def nyu_baseline_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_width=0.5, variant224=False, is_depthwise=False):
     """Decoder / Decoder224 parameters (densedepth_decoder.py:16-34, 50-74)."""
     f = int(enc_features[-1] * decoder_width)
     e = list(enc_features)
@@ -459,15 +477,16 @@ def nyu_baseline_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_wid
     cin = f
     for k in (1, 2, 3, 4):
         cout = f // (2 ** k)
-        sh["up%d.convA.conv.weight" % k] = (cout, cin + e[-1 - k], 3, 3)
-        sh["up%d.convA.conv.bias" % k] = (cout,)
+        _nyu_conv_shapes(sh, "up%d.convA" % k, cout, cin + e[-1 - k], is_depthwise)
         cin = cout
     if variant224:
-        sh["conv5.0.conv.weight"] = (f // 32, f // 16, 3, 3)
-        sh["conv5.0.conv.bias"] = (f // 32,)
+        _nyu_conv_shapes(sh, "conv5.0", f // 32, f // 16, is_depthwise)
         cin = f // 32
-    sh["conv3.weight"] = (1, cin, 3, 3)
-    sh["conv3.bias"] = (1,)
+    if is_depthwise:
+        _nyu_conv_shapes(sh, "conv3", 1, cin, True)
+    else:
+        sh["conv3.weight"] = (1, cin, 3, 3)
+        sh["conv3.bias"] = (1,)
     return sh
 
 
@@ -491,7 +510,7 @@ def nyu_wave224_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_widt
 def nyu_up_block(x, skip, sd, key, pad="reflect"):
     """UpSampleBlock (NYUv2/networks/layers.py:57-67): up2 -> cat -> Conv3x3(padding) -> LeakyReLU(0.2)."""
     t = torch.cat([up2(x), skip], 1)
-    return F.leaky_relu(conv3x3(t, sd[key + ".convA.conv.weight"], sd[key + ".convA.conv.bias"], pad), 0.2)
+    return F.leaky_relu(nyu_conv3x3(t, sd, key + ".convA", pad), 0.2)
 
 
 def nyu_baseline_decoder(x_blocks, sd, variant224=False):
@@ -501,8 +520,10 @@ def nyu_baseline_decoder(x_blocks, sd, variant224=False):
     for k, skip in zip((1, 2, 3, 4), (x_blocks[3], x_blocks[2], x_blocks[1], x_blocks[0])):
         x = nyu_up_block(x, skip, sd, "up%d" % k, "zero")
     if variant224:
-        x = F.leaky_relu(conv3x3(up2(x), sd["conv5.0.conv.weight"], sd["conv5.0.conv.bias"], "zero"), 0.2)
-    return {("disp", 0): conv3x3(x, sd["conv3.weight"], sd["conv3.bias"], "zero")}
+        x = F.leaky_relu(nyu_conv3x3(up2(x), sd, "conv5.0", "zero"), 0.2)
+    if "conv3.weight" in sd:
+        return {("disp", 0): conv3x3(x, sd["conv3.weight"], sd["conv3.bias"], "zero")}
+    return {("disp", 0): nyu_conv3x3(x, sd, "conv3", "zero")}   # is_depthwise: Conv3x3(C, 1, is_depthwise=True), :35,73
 
 
 def nyu_wave224_decoder(x_blocks, sd):
@@ -529,18 +550,18 @@ def nyu_wave_decoder(x_blocks, sd):
     x_d1 = nyu_up_block(x_d0, x_blocks[-2], sd, "up1")
     ll = 8 * conv3x3(x_d1, sd["wave1_ll.conv.weight"], sd["wave1_ll.conv.bias"], "replicate")
     out[("disp", 3)] = ll / 8
-    h = 4 * conv3x3(x_d1, sd["wave1.conv.weight"], sd["wave1.conv.bias"], "zero").unsqueeze(1)
+    h = 4 * nyu_conv3x3(x_d1, sd, "wave1", "zero").unsqueeze(1)
     out[("wavelets", 2, "LL")] = ll
     out[("wavelets", 2, "LH")], out[("wavelets", 2, "HL")], out[("wavelets", 2, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
     ll = haar_idwt(ll, h)
     out[("disp", 2)] = ll / 4
     x_d2 = nyu_up_block(x_d1, x_blocks[-3], sd, "up2")
-    h = 2 * conv3x3(x_d2, sd["wave2.conv.weight"], sd["wave2.conv.bias"], "zero").unsqueeze(1)
+    h = 2 * nyu_conv3x3(x_d2, sd, "wave2", "zero").unsqueeze(1)
     out[("wavelets", 1, "LH")], out[("wavelets", 1, "HL")], out[("wavelets", 1, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
     ll = haar_idwt(ll, h)
     out[("disp", 1)] = ll / 2
     x_d3 = nyu_up_block(x_d2, x_blocks[-4], sd, "up3")
-    h = conv3x3(x_d3, sd["wave3.conv.weight"], sd["wave3.conv.bias"], "zero").unsqueeze(1)
+    h = nyu_conv3x3(x_d3, sd, "wave3", "zero").unsqueeze(1)
     out[("wavelets", 0, "LH")], out[("wavelets", 0, "HL")], out[("wavelets", 0, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
     ll = haar_idwt(ll, h)
     out[("disp", 0)] = ll

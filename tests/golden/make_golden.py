@@ -173,13 +173,30 @@ def gen_nyu_variants():
     enc = [8, 8, 16, 32, 64]
     H, W, B = 64, 96, 2
     blocks = [t(synth.normal((B, c, H >> (k + 1), W >> (k + 1)), "nyu_feat%d" % k, 8)) for k, c in enumerate(enc)]
-    for name, cls, seed in (("decoder", Decoder, 21), ("decoder224", Decoder224, 22), ("decoderwave224", DecoderWave224, 23)):
-        dec = synth.fill_state_dict(quiet(cls, enc_features=enc), seed=seed)
+    from networks.decoders import DecoderWave
+    import networks.layers as NL
+    # depthwise Conv3x3 (layers.py:23-25,70-79): layer-level outputs and gradients, three paddings
+    lc = {}
+    for name, cin, cout, h, w, pad in [("reflection_6_5", 6, 5, 5, 7, "reflection"), ("replicate_19_3", 19, 3, 4, 6, "replicate"),
+                                       ("zero_9_3", 9, 3, 6, 8, "zero")]:
+        m = synth.fill_state_dict(NL.Conv3x3(cin, cout, padding=pad, is_depthwise=True), seed=7)
+        x = t(synth.normal((2, cin, h, w), "dwx_" + name, 7)).requires_grad_(True)
+        y = m(x)
+        (y * y).sum().backward()
+        lc["y_" + name], lc["dx_" + name] = y.detach().numpy(), x.grad.numpy()
+        for n, p in m.named_parameters():
+            lc["d|%s|%s" % (name, n)] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "nyu_depthwise_layers.npz"), **lc)
+    cases = (("decoder", Decoder, 21, {}), ("decoder224", Decoder224, 22, {}), ("decoderwave224", DecoderWave224, 23, {}),
+             ("decoder_dw", Decoder, 24, {"is_depthwise": True}), ("decoder224_dw", Decoder224, 25, {"is_depthwise": True}),
+             ("decoderwave_dw", DecoderWave, 26, {"dw_waveconv": True, "dw_upconv": True}))
+    for name, cls, seed, kw in cases:
+        dec = synth.fill_state_dict(quiet(cls, enc_features=enc, **kw), seed=seed)
         bg = [b_.clone().requires_grad_(True) for b_ in blocks]
         out = dec(bg)
         res = outputs_to_np(out)
         # ("disp", 1) of DecoderWave224 comes out of `//` (floor_divide: no derivative in torch) -- leave it out of the loss
-        loss = sum(v.mean() for k, v in out.items() if k[0] == "disp" and not (name == "decoderwave224" and k[1] == 1))
+        loss = sum((v * v).mean() for k, v in out.items() if k[0] == "disp" and not (name == "decoderwave224" and k[1] == 1))
         loss.backward()
         res["loss"] = loss.detach().numpy()
         for k, f in enumerate(bg):

@@ -77,6 +77,11 @@ class WarpArgs(C.Structure):
                 ("T", C.c_void_p)]
 
 
+class DwConvArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
+                ("pad_mode", C.c_int), ("x1", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p)]
+
+
 class HeadShiftsumArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pad_mode", C.c_int), ("scale", C.c_float),
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
@@ -153,6 +158,9 @@ SIGNATURES = {
     "wmd_smooth_workspace_floats": (C.c_size_t, [C.c_int] * 3),
     "wmd_smooth_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wmd_smooth_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "wmd_dwconv3x3_fwd": (C.c_int, [C.POINTER(DwConvArgs), C.c_void_p, C.c_void_p]),
+    "wmd_dwconv3x3_bwd_workspace_floats": (C.c_size_t, [C.POINTER(DwConvArgs)]),
+    "wmd_dwconv3x3_bwd": (C.c_int, [C.POINTER(DwConvArgs)] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]),
     "wmd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wmd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "wmd_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),

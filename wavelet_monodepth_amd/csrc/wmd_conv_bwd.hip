@@ -670,3 +670,167 @@ extern "C" int wmd_conv_wgrad(const wmd_conv_wgrad_args* g, void* stream) {
     st = check_launch("wgrad_reduce_kernel");
     return st;
 }
+
+// ================================================================================================
+// Depthwise 3x3 + ReLU: the first half of the NYUv2 decoders' optional `is_depthwise` Conv3x3
+// (NYUv2/networks/layers.py:23-25,70-75: Conv2d(C, C, 3, groups=C, bias=False) -> ReLU, then a bias-free 1x1 which
+// runs through the regular MFMA 1x1 convolution).  Same virtual input as the dense kernels: nearest-upsampled x1
+// concatenated with x2, padded by 1 in the layer's padding mode -- never materialised.  HBM-bound VALU stencils.
+// ================================================================================================
+namespace wmd {
+
+__device__ __forceinline__ float dw_input(const float* __restrict__ x1, const float* __restrict__ x2, int b, int c, int gy, int gx,
+                                          int C1, int C2, int H, int W, int up1, int pad_mode) {
+    const bool ok = pad_coord(gy, H, pad_mode) & pad_coord(gx, W, pad_mode);
+    gy = min(max(gy, 0), H - 1);
+    gx = min(max(gx, 0), W - 1);
+    float v;
+    if (c < C1) {
+        const int h1 = H / up1, w1 = W / up1;
+        v = x1[(((size_t)b * C1 + c) * h1 + gy / up1) * w1 + gx / up1];
+    } else {
+        v = x2[(((size_t)b * C2 + (c - C1)) * H + gy) * W + gx];
+    }
+    return ok ? v : 0.f;
+}
+
+__global__ void dwconv_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ w,
+                                  float* __restrict__ y, int B, int C1, int C2, int H, int W, int up1, int pad_mode) {
+    const int C = C1 + C2, plane = H * W;
+    const int bc = blockIdx.y, b = bc / C, c = bc % C;
+    float wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + t];
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += gridDim.x * blockDim.x) {
+        const int yy = p / W, xx = p - yy * W;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s = fmaf(wt[t], dw_input(x1, x2, b, c, yy + t / 3 - 1, xx + t % 3 - 1, C1, C2, H, W, up1, pad_mode), s);
+        y[(size_t)bc * plane + p] = fmaxf(s, 0.f);
+    }
+}
+
+// padded-domain gradient gP[b,c,Y,X] (Y in [0,H+2), X in [0,W+2)) = sum_t w[c,t] dz[Y-ky, X-kx],  dz = dy * (y > 0);
+// conv_dgrad_fold_kernel then applies the adjoint of pad + concat + upsample
+__global__ void dwconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ w,
+                                       float* __restrict__ gp, int C, int H, int W) {
+    const int bc = blockIdx.y, c = bc % C;
+    const int Hp = H + 2, Wp = W + 2, pplane = Hp * Wp;
+    float wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + t];
+    const float* dyp = dy + (size_t)bc * H * W;
+    const float* yp = y + (size_t)bc * H * W;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < pplane; p += gridDim.x * blockDim.x) {
+        const int Y = p / Wp, X = p - Y * Wp;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int oy = Y - t / 3, ox = X - t % 3;   // output pixel whose tap t reads padded position (Y, X)
+            if (oy >= 0 && oy < H && ox >= 0 && ox < W) {
+                const int q = oy * W + ox;
+                s = fmaf(wt[t], yp[q] > 0.f ? dyp[q] : 0.f, s);
+            }
+        }
+        gp[(size_t)bc * pplane + p] = s;
+    }
+}
+
+// dW[c,t] = sum_{b,y,x} dz * P(b,c,y+ky-1,x+kx-1): one block per channel, threads stride over (b, pixel)
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                                const float* __restrict__ dy, const float* __restrict__ y,
+                                                                float* __restrict__ dw, int B, int C1, int C2, int H, int W,
+                                                                int up1, int pad_mode) {
+    const int C = C1 + C2, plane = H * W, c = blockIdx.x;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int i = threadIdx.x; i < B * plane; i += blockDim.x) {
+        const int b = i / plane, p = i - b * plane, yy = p / W, xx = p - yy * W;
+        const size_t o = ((size_t)b * C + c) * plane + p;
+        const float g = y[o] > 0.f ? dy[o] : 0.f;
+        if (g == 0.f) continue;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = fmaf(g, dw_input(x1, x2, b, c, yy + t / 3 - 1, xx + t % 3 - 1, C1, C2, H, W, up1, pad_mode), acc[t]);
+    }
+    __shared__ float red[4][9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float s = acc[t];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) dw[c * 9 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+}  // namespace wmd
+
+static int dw_check(const char* who, const wmd_dwconv_args* g) {
+    if (!g) return fail(WMD_ERR_BAD_ARG, "%s: null args", who);
+    if (!g->x1 || !g->w) return fail(WMD_ERR_BAD_ARG, "%s: null tensor pointer", who);
+    if (g->C2 > 0 && !g->x2) return fail(WMD_ERR_BAD_ARG, "%s: C2=%d but x2 is null", who, g->C2);
+    int st = validate_bwd(g->B, g->H, g->W, g->C1, g->up1, g->C2, 1, 3, g->pad_mode, who);
+    if (st) return st;
+    if ((double)(g->C1 + g->C2) * g->B > 65535.0) return fail(WMD_ERR_UNSUPPORTED, "%s: B*C > 65535", who);
+    if ((double)g->B * (g->C1 + g->C2) * (g->H + 2) * (g->W + 2) > 2147483647.0) return fail(WMD_ERR_UNSUPPORTED, "%s: more than 2^31 elements", who);
+    return WMD_OK;
+}
+
+extern "C" int wmd_dwconv3x3_fwd(const wmd_dwconv_args* g, float* y, void* stream) {
+    int st = dw_check("wmd_dwconv3x3_fwd", g);
+    if (st) return st;
+    if (!y) return fail(WMD_ERR_BAD_ARG, "wmd_dwconv3x3_fwd: null output");
+    const int C = g->C1 + g->C2, plane = g->H * g->W;
+    hipStream_t s = (hipStream_t)stream;
+    const double n = (double)g->B * C * plane;
+    ProfScope prof("dwconv_fwd_kernel", 18.0 * n, 8.0 * n, s);
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(std::max(1, std::min((plane + 255) / 256, 64)), g->B * C), dim3(256), 0, s, g->x1, g->x2, g->w, y,
+                       g->B, g->C1, g->C2, g->H, g->W, g->up1, g->pad_mode);
+    return check_launch("dwconv_fwd_kernel");
+}
+
+extern "C" size_t wmd_dwconv3x3_bwd_workspace_floats(const wmd_dwconv_args* g) {
+    return g ? (size_t)g->B * (g->C1 + g->C2) * (g->H + 2) * (g->W + 2) : 0;
+}
+
+extern "C" int wmd_dwconv3x3_bwd(const wmd_dwconv_args* g, const float* y, const float* dy, float* dx1, float* dx2, float* dw,
+                                 float* workspace, size_t workspace_floats, void* stream) {
+    int st = dw_check("wmd_dwconv3x3_bwd", g);
+    if (st) return st;
+    if (!y || !dy) return fail(WMD_ERR_BAD_ARG, "wmd_dwconv3x3_bwd: null tensor pointer");
+    if (dx2 && g->C2 <= 0) return fail(WMD_ERR_BAD_ARG, "wmd_dwconv3x3_bwd: dx2 given but C2=%d", g->C2);
+    const int C = g->C1 + g->C2, plane = g->H * g->W, pplane = (g->H + 2) * (g->W + 2);
+    hipStream_t s = (hipStream_t)stream;
+    const double n = (double)g->B * C * plane;
+    if (dx1 || dx2) {
+        if (!workspace || workspace_floats < wmd_dwconv3x3_bwd_workspace_floats(g))
+            return fail(WMD_ERR_WORKSPACE, "wmd_dwconv3x3_bwd: workspace %zu < %zu floats", workspace_floats, wmd_dwconv3x3_bwd_workspace_floats(g));
+        {
+            ProfScope prof("dwconv_bwd_data_kernel", 18.0 * n, 12.0 * n, s);
+            hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(std::max(1, std::min((pplane + 255) / 256, 64)), g->B * C), dim3(256), 0, s, dy, y,
+                               g->w, workspace, C, g->H, g->W);
+        }
+        st = check_launch("dwconv_bwd_data_kernel");
+        if (st) return st;
+        const bool vec = g->W % 4 == 0 && ((uintptr_t)dx1 % 16 == 0) && ((uintptr_t)dx2 % 16 == 0);
+        const int work = plane / (vec ? 4 : 1);
+        const dim3 grid(std::max(1, std::min((work + 255) / 256, 64)), g->B * C);
+        ProfScope prof("conv_dgrad_fold_kernel", n, 8.0 * n, s);
+        if (vec)
+            hipLaunchKernelGGL(conv_dgrad_fold_kernel<true>, grid, dim3(256), 0, s, workspace, dx1, dx2, g->B, g->C1, g->C2, g->H, g->W, g->up1,
+                               g->pad_mode, 1);
+        else
+            hipLaunchKernelGGL(conv_dgrad_fold_kernel<false>, grid, dim3(256), 0, s, workspace, dx1, dx2, g->B, g->C1, g->C2, g->H, g->W, g->up1,
+                               g->pad_mode, 1);
+        st = check_launch("conv_dgrad_fold_kernel");
+        if (st) return st;
+    }
+    if (dw) {
+        ProfScope prof("dwconv_bwd_weight_kernel", 18.0 * n, 12.0 * n, s);
+        hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(C), dim3(256), 0, s, g->x1, g->x2, dy, y, dw, g->B, g->C1, g->C2, g->H, g->W, g->up1,
+                           g->pad_mode);
+        st = check_launch("dwconv_bwd_weight_kernel");
+    }
+    return st;
+}

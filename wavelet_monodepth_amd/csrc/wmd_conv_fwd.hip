@@ -797,6 +797,10 @@ static const ConvCfg kCfgs[] = {
     WMD_WINO(4, 32, 1, 2, 2, 8),    // co32 x 128px, 4 waves; a tile group = one row of 16 tiles: no LDS bank conflicts
     WMD_WINO(4, 32, 1, 4, 2, 8),    // co64 x 128px, 8 waves
     WMD_WINO(6, 40, 1, 2, 4, 8),    // co32 x 240px, 8 waves
+    WMD_WINO(8, 32, 1, 1, 4, 8),    // co16 x 256px, 4 waves: small blocks, many independent phases per CU
+    WMD_WINO(8, 16, 1, 1, 2, 8),    // co16 x 128px, 2 waves
+    WMD_WINO(16, 32, 1, 1, 8, 8),   // co16 x 512px, 8 waves
+    WMD_WINO(16, 32, 1, 2, 8, 8),   // co32 x 512px, 16 waves
     // 1x1 on the flattened image (TH = 1)
     WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
     WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px

@@ -60,21 +60,34 @@ class ConvBlock(nn.Module):
 
 
 class NyuConv3x3(nn.Module):
-    """NYUv2/networks/layers.py:11-32 (`padding` in {"reflection","replicate","zero"}); the optional
-    depthwise variant (is_depthwise) is a SURVEY §8(f) "next" item."""
+    """NYUv2/networks/layers.py:11-32 (`padding` in {"reflection","replicate","zero"}).  With is_depthwise the layer is
+    depthwise 3x3 (no bias) -> ReLU -> 1x1 (no bias) (:23-25,70-79; state_dict keys conv.0.0.weight, conv.1.weight)."""
 
     def __init__(self, in_channels, out_channels, padding="zero", stride=1, is_depthwise=False):
         super().__init__()
-        if is_depthwise:
-            raise NotImplementedError("depthwise decoder variants are not built yet (SURVEY.md §8f rank 4)")
         if stride != 1:
             raise NotImplementedError
         self.pad_mode = {"reflection": "reflect", "replicate": "replicate"}.get(padding, "zero")
-        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3, stride=stride, padding=0)
+        self.is_depthwise = bool(is_depthwise)
+        if self.is_depthwise:
+            dw = nn.Sequential(nn.Conv2d(int(in_channels), int(in_channels), 3, stride=1, padding=0, bias=False, groups=int(in_channels)),
+                               nn.ReLU(inplace=True))
+            self.conv = nn.Sequential(dw, nn.Conv2d(int(in_channels), int(out_channels), 1, 1, 0, bias=False))
+        else:
+            self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3, stride=stride, padding=0)
 
     def forward(self, x, skip=None, up=1, act="none", slope=0.0):
+        if self.is_depthwise:
+            mid = ops.dwconv3x3_relu(x, self.conv[0][0].weight, x2=skip, up1=up, pad=self.pad_mode)
+            return ops.conv2d_fused(mid, self.conv[1].weight, None, pad="zero", act=act, slope=slope)
         return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, x2=skip, up1=up, pad=self.pad_mode, act=act,
                                 slope=slope)
+
+    def head(self, x, scale):
+        """scale * layer(x) for the 1- and 3-channel wavelet heads."""
+        if self.is_depthwise:
+            return self.forward(x) * scale
+        return ops.head3x3(x, self.conv.weight, self.conv.bias, pad=self.pad_mode, mode=0, scale=scale)
 
 
 class UpSampleBlock(nn.Module):

@@ -8,8 +8,8 @@
   SparseDecoderWave  :224-409   two sparse levels (see sparse_decoder.py)
 
 Same constructors, `state_dict` names (conv2.conv.*, up{1..4}.convA.conv.*, conv5.0.conv.*, conv3.*, wave1_ll.conv.*,
-wave{1..4}.conv.*, iwt.*, iwt_LL.*) and output keys.  The depthwise options (is_depthwise / dw_waveconv / dw_upconv,
-off by default in the reference) raise NotImplementedError: SURVEY §8(f) rank 4, not built.
+wave{1..4}.conv.*, iwt.*, iwt_LL.*) and output keys, incl. the depthwise options (is_depthwise / dw_waveconv / dw_upconv:
+depthwise 3x3 -> ReLU -> 1x1, keys *.conv.0.0.weight / *.conv.1.weight).
 """
 import torch
 import torch.nn as nn
@@ -45,7 +45,8 @@ class Decoder(nn.Module):
                                  is_depthwise=is_depthwise)
         self.up4 = UpSampleBlock(skip_input=features // 8 + enc_features[-5], output_features=features // 16, padding=padding,
                                  is_depthwise=is_depthwise)
-        self.conv3 = _OutConv3x3(features // 16, 1)
+        # (:32-35) a bare nn.Conv2d unless the depthwise option is on
+        self.conv3 = NyuConv3x3(features // 16, 1, is_depthwise=True) if is_depthwise else _OutConv3x3(features // 16, 1)
 
     def _trunk(self, features):
         x_block0, x_block1, x_block2, x_block3, x_block4 = tuple(features)
@@ -65,8 +66,8 @@ class Decoder224(Decoder):
         features = int(enc_features[-1] * decoder_width)
         # nn.Sequential(Conv3x3, LeakyReLU(0.2)) in the reference (:66-67): key conv5.0.conv.*; the nearest x2 in front of
         # it (:87) and the activation are fused into the convolution
-        self.conv5 = nn.Sequential(NyuConv3x3(features // 16, features // 32), nn.LeakyReLU(0.2))
-        self.conv3 = _OutConv3x3(features // 32, 1)
+        self.conv5 = nn.Sequential(NyuConv3x3(features // 16, features // 32, is_depthwise=is_depthwise), nn.LeakyReLU(0.2))
+        self.conv3 = NyuConv3x3(features // 32, 1, is_depthwise=True) if is_depthwise else _OutConv3x3(features // 32, 1)
 
     def forward(self, features):
         x_d5 = self.conv5[0](self._trunk(features), up=2, act="leaky", slope=0.2)
@@ -97,8 +98,8 @@ class DecoderWave(nn.Module):
 
     @staticmethod
     def _wave(conv, x, scale):
-        """scale * Conv3x3(C, 1|3)(x) through the small-Cout head kernel."""
-        return ops.head3x3(x, conv.conv.weight, conv.conv.bias, pad=conv.pad_mode, mode=0, scale=scale)
+        """scale * Conv3x3(C, 1|3)(x): the small-Cout head kernel, or depthwise + 1x1 for the dw_waveconv option."""
+        return conv.head(x, scale)
 
     def enable_graph(self, on=True):
         self._graph_mode = bool(on)

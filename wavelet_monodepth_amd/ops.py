@@ -201,6 +201,48 @@ def conv2d_fused(x1, weight, bias=None, x2=None, up1=1, pad="reflect", act="none
     return _ConvFn.apply(x1, x2, weight, bias, ksize, pad, act, slope, up1)
 
 
+class _DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight, pad, up1):
+        x1c, x2c, wc = _c(x1), _c(x2), _c(weight)
+        B, C1 = x1c.shape[:2]
+        H, W = x1c.shape[2] * up1, x1c.shape[3] * up1
+        C2 = 0 if x2c is None else x2c.shape[1]
+        y = torch.empty((B, C1 + C2, H, W), device=x1c.device, dtype=torch.float32)
+        a = _lib.DwConvArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, pad_mode=PAD[pad], x1=ptr(x1c), x2=ptr(x2c), w=ptr(wc))
+        check(_lib.lib().wmd_dwconv3x3_fwd(C.byref(a), ptr(y), current_stream()), "wmd_dwconv3x3_fwd")
+        ctx.save_for_backward(x1c, x2c, wc, y)
+        ctx.cfg = (pad, up1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w, y = ctx.saved_tensors
+        pad, up1 = ctx.cfg
+        l = _lib.lib()
+        B, Cc, H, W = y.shape
+        C1 = x1.shape[1]
+        a = _lib.DwConvArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=Cc - C1, pad_mode=PAD[pad], x1=ptr(x1), x2=ptr(x2), w=ptr(w))
+        dx1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        dx2 = torch.empty_like(x2) if (x2 is not None and ctx.needs_input_grad[1]) else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[2] else None
+        n = l.wmd_dwconv3x3_bwd_workspace_floats(C.byref(a))
+        ws = torch.empty(max(n, 1), device=y.device, dtype=torch.float32)
+        check(l.wmd_dwconv3x3_bwd(C.byref(a), ptr(y), ptr(_c(dy)), ptr(dx1), ptr(dx2), ptr(dw), ptr(ws), n, current_stream()),
+              "wmd_dwconv3x3_bwd")
+        return dx1, dx2, dw, None, None
+
+
+def dwconv3x3_relu(x1, weight, x2=None, up1=1, pad="zero"):
+    """relu( depthwise_conv3x3( pad( cat[ nearest_up(x1, up1), x2 ] ) ) ), weight [C1+C2,1,3,3] -- the first half of the
+    NYUv2 `is_depthwise` Conv3x3 (NYUv2/networks/layers.py:70-75).  Differentiable."""
+    _require_gpu(x1, x2, weight)
+    cin = x1.shape[1] + (0 if x2 is None else x2.shape[1])
+    if tuple(weight.shape) != (cin, 1, 3, 3):
+        raise _lib.WmdError("depthwise weight must be [%d,1,3,3], got %s" % (cin, tuple(weight.shape)))
+    return _DwConvFn.apply(x1, x2, weight, pad, up1)
+
+
 # ---------------------------------------------------------------------------------------------
 # wavelet heads
 # ---------------------------------------------------------------------------------------------
