@@ -379,9 +379,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 __global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                           float* __restrict__ y, size_t n, size_t plane, int Cout, int ksplit,
                                           int act, float slope) {
+    // the ksplit partial loads of an element are independent: issue them four at a time (a plain `v += partial[...]` loop
+    // with a run-time trip count waits for every round trip in turn), summing in the fixed order s = 0 .. ksplit-1
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float v = 0.f;
-        for (int s = 0; s < ksplit; ++s) v += partial[(size_t)s * n + i];
+        int s = 0;
+        for (; s + 4 <= ksplit; s += 4) {
+            const float p0 = partial[(size_t)s * n + i], p1 = partial[(size_t)(s + 1) * n + i];
+            const float p2 = partial[(size_t)(s + 2) * n + i], p3 = partial[(size_t)(s + 3) * n + i];
+            v = (((v + p0) + p1) + p2) + p3;
+        }
+        for (; s < ksplit; ++s) v += partial[(size_t)s * n + i];
         if (bias) v += bias[(i / plane) % Cout];
         y[i] = act_apply(v, act, slope);
     }

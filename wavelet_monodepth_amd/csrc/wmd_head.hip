@@ -296,24 +296,35 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
         const int x = i % W;
         const int y = (i / W) % H;
         const size_t b = i / plane;
+        // all 54 loads are unconditional (clamped offset, 0/1 weight) so that they are issued back to back: with the tap
+        // test around them the compiler serialises the round trips and this small kernel took 14 us per level
         int off[9];
+        float okf[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             int gy = y + t / 3 - 1, gx = x + t % 3 - 1;
             const bool ok = pad_coord(gy, H, a.pad_mode) & pad_coord(gx, W, a.pad_mode);
-            off[t] = ok ? gy * W + gx : -1;
+            gy = min(max(gy, 0), H - 1);
+            gx = min(max(gx, 0), W - 1);
+            off[t] = gy * W + gx;
+            okf[t] = ok ? 1.f : 0.f;
         }
         const float* tb = a.t + b * 54 * plane;
+        float vp[27], vn[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            vp[k] = tb[(size_t)k * plane + off[k % 9]];
+            vn[k] = tb[(size_t)(27 + k) * plane + off[k % 9]];
+        }
         float yh[3];
 #pragma unroll
         for (int co = 0; co < 3; ++co) {
             float sp = a.bias_p ? a.bias_p[co] : 0.f, sn = a.bias_n ? a.bias_n[co] : 0.f;
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-                if (off[t] >= 0) {
-                    sp += tb[(size_t)(co * 9 + t) * plane + off[t]];
-                    sn += tb[(size_t)(27 + co * 9 + t) * plane + off[t]];
-                }
+            for (int t = 0; t < 9; ++t) {
+                sp += okf[t] * vp[co * 9 + t];
+                sn += okf[t] * vn[co * 9 + t];
+            }
             const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
             yh[co] = a.scale * a1 - a.scale * a2;
             a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
@@ -417,6 +428,8 @@ extern "C" int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* g, void* stre
     const size_t n = (size_t)g->B * g->H * g->W;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("head_shiftsum_kernel", 60.0 * n, 4.0 * n * (54 + 3 + (g->out ? (g->disp ? 9 : 5) : 0)), s);
-    hipLaunchKernelGGL(head_shiftsum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 16)), dim3(256), 0, s, *g);
+    const unsigned threads = n < 65536 ? 64 : 256;   // coarse levels: one wavefront per block spreads the few pixels over the CUs
+    hipLaunchKernelGGL(head_shiftsum_kernel, dim3((unsigned)std::min<size_t>((n + threads - 1) / threads, (size_t)kNumCU * 16)), dim3(threads),
+                       0, s, *g);
     return check_launch("head_shiftsum_kernel");
 }
