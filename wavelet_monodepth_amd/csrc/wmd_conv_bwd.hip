@@ -292,8 +292,15 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     const size_t n = nw + Cout;
     const size_t i = (size_t)blockIdx.x * 64 + w;
     float v = 0.f;
-    if (i < n)
-        for (int s = g; s < nsplit; s += 16) v += partial[(size_t)s * n + i];
+    if (i < n) {
+        int s = g;
+        for (; s + 48 < nsplit; s += 64) {   // four independent loads in flight per trip, fixed summation order
+            const float p0 = partial[(size_t)s * n + i], p1 = partial[(size_t)(s + 16) * n + i];
+            const float p2 = partial[(size_t)(s + 32) * n + i], p3 = partial[(size_t)(s + 48) * n + i];
+            v = (((v + p0) + p1) + p2) + p3;
+        }
+        for (; s < nsplit; s += 16) v += partial[(size_t)s * n + i];
+    }
     red[g][w] = v;
     __syncthreads();
     if (g == 0 && i < n) {
