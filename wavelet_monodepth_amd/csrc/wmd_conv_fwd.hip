@@ -225,6 +225,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 #pragma unroll
         for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
     }
+    // epilogue operands requested now: a global load at the start of the epilogue is an exposed round trip per block
+    float bias_v[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const int co = FUSE ? (int)(blockIdx.y * (WM * MR * 16)) + (wm * MR + m) * 16 + (lane & 15)
+                            : ((blockIdx.y * WM + wm) * MR + m) * 16 + (lane & 15);
+        bias_v[m] = (a.bias && (FUSE || co < a.Cout)) ? a.bias[co] : 0.f;
+    }
     __syncthreads();  // (hipcc drains the DMA with vmcnt(0) ahead of the barrier)
 
     // One chunk of the reduction.  Software pipeline over its S = KSTEPS*TAPS (K-step, tap) groups: the fragments of
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             const int chl = (wm * MR + m) * 16 + (lane & 15);
-            const float bv = a.bias ? a.bias[blockIdx.y * CO_T + chl] : 0.f;
+            const float bv = bias_v[m];
 #pragma unroll
             for (int n = 0; n < NR; ++n) {
                 const int q = (wn * NR + n) * 16 + (lane >> 4) * 4;
@@ -310,11 +318,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         constexpr int NCI4_2 = CO_T / 4;   // CO_T is a multiple of 16
         const float* w2 = a.wp2 + (size_t)blockIdx.y * (2 * NCI4_2 * 64) + lane;
         const float* msrc = mid + (lane >> 4) * PS2 + (lane & 15);
-#pragma unroll 4
+        // the tap-partial weights come straight from L2 (they do not fit beside `mid`): a ring of QD K-steps of fragments
+        // keeps QD global loads per lane in flight so that none of them is waited for in the MFMA stream
+        constexpr int QD = NCI4_2 < 8 ? NCI4_2 : 8;
+        float wq[QD][R2W];
+#pragma unroll
+        for (int q = 0; q < QD; ++q)
+#pragma unroll
+            for (int j = 0; j < R2W; ++j) wq[q][j] = w2[((WM == 1 ? j : wm) * NCI4_2 + q) * 64];
+#pragma unroll
         for (int k4 = 0; k4 < NCI4_2; ++k4) {
             float pf[NR], wf[R2W];
 #pragma unroll
-            for (int j = 0; j < R2W; ++j) wf[j] = w2[((WM == 1 ? j : wm) * NCI4_2 + k4) * 64];
+            for (int j = 0; j < R2W; ++j) wf[j] = wq[k4 % QD][j];
+            if (k4 + QD < NCI4_2) {
+#pragma unroll
+                for (int j = 0; j < R2W; ++j) wq[k4 % QD][j] = w2[((WM == 1 ? j : wm) * NCI4_2 + k4 + QD) * 64];
+            }
 #pragma unroll
             for (int n = 0; n < NR; ++n) pf[n] = msrc[k4 * 4 * PS2 + (wn * NR + n) * 16];
 #pragma unroll
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const int co = ((blockIdx.y * WM + wm) * MR + m) * 16 + (lane & 15);
-        const float bv = (final_out && a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        const float bv = final_out ? bias_v[m] : 0.f;
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             const int q = (wn * NR + n) * 16 + (lane >> 4) * 4;  // first of this lane's 4 consecutive pixels
@@ -543,6 +563,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
 #pragma unroll
         for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
     }
+    float bias_v[MRW];   // requested now, used in the epilogue (see conv_fwd_kernel)
+#pragma unroll
+    for (int m = 0; m < MRW; ++m) {
+        const int co = ((blockIdx.y * WM + wm) * MRW + m) * 16 + (lane & 15);
+        bias_v[m] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
     __syncthreads();
 
     // One chunk = S = KSTEPS*16 groups (K-step, position) of MRW MFMAs each.  Explicitly software-pipelined and pinned
@@ -619,7 +645,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     for (int m = 0; m < MRW; ++m) {
         const int co = ((blockIdx.y * WM + wm) * MRW + m) * 16 + (lane & 15);
         if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W) continue;
-        const float bv = (final_out && a.bias) ? a.bias[co] : 0.f;
+        const float bv = final_out ? bias_v[m] : 0.f;
         float yrow[2][8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
