@@ -25,11 +25,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("layers", nargs="*", default=list(LAYERS))
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--batch", type=int, default=12)
+ap.add_argument("--act", default=None, help="override the activation (none | elu | leaky)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 for name in args.layers:
     C1, up, C2, Cout, H, W, k, act = LAYERS[name]
+    act = args.act or act
     x1 = torch.randn(args.batch, C1, H // up, W // up, device=dev)
     x2 = torch.randn(args.batch, C2, H, W, device=dev) if C2 else None
     w = torch.randn(Cout, C1 + C2, k, k, device=dev) * 0.05
