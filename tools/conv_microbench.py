@@ -17,6 +17,7 @@ LAYERS = {
     "5": (256, 1, 0, 128, 12, 40, 3, "elu"), "6": (128, 2, 128, 128, 24, 80, 3, "elu"),
     "9": (128, 1, 0, 64, 24, 80, 3, "elu"), "10": (64, 2, 64, 64, 48, 160, 3, "elu"),
     "13": (64, 1, 0, 32, 48, 160, 3, "elu"), "14": (32, 2, 64, 32, 96, 320, 3, "elu"),
+    "14k2": (64, 2, 128, 32, 96, 320, 3, "elu"), "14k4": (128, 2, 256, 32, 96, 320, 3, "elu"),   # L14 with 2x / 4x the reduction: per-block fixed cost
     "h4": (256, 1, 0, 256, 12, 40, 1, "leaky"), "h3": (128, 1, 0, 128, 24, 80, 1, "leaky"),
     "h2": (64, 1, 0, 64, 48, 160, 1, "leaky"), "h1": (32, 1, 0, 32, 96, 320, 1, "leaky"),
 }
