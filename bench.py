@@ -279,6 +279,7 @@ def main():
         }
         print(json.dumps(res))
     if world > 1:
+        barrier()   # rank 0's per-launch roofline pass ends before any rank tears the communicator down
         dist.destroy_process_group()
 
 
