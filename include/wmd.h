@@ -313,6 +313,14 @@ typedef struct {
 /* All dilated variants of one mask in a single launch (n <= 8). */
 int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wmd_dilate_spec* specs, int n, void* stream);
 
+/* wmd_minmax + wmd_mask_threshold + wmd_mask_dilate_multi of one decoder level in ONE launch
+ * (depth_decoder.py:308-319): thr = (max(yl) - min(yl)) * thresh_ratio over yl[n_yl]; base[p] = max_b |yh[b,p]| > thr
+ * on the [h,w] grid of yh [3,h,w]; specs[i].out = dilation of the (nearest-upsampled) base mask exactly as
+ * wmd_mask_dilate_multi would produce it; a spec (up 1, radius 0) yields the base mask itself.  Bit-identical to the
+ * three separate calls (min/max are order-independent, the threshold is the same fp32 expression).          */
+int wmd_mask_level(const float* yl, size_t n_yl, const float* yh, float thresh_ratio, int h, int w,
+                   const wmd_dilate_spec* specs, int n, void* stream);
+
 typedef struct {
     const uint8_t* mask;   /* [npix]                                                               */
     int npix;

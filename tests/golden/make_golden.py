@@ -104,7 +104,7 @@ def gen_kitti():
     sp = SparseDepthWaveProgressiveDecoder(num_ch_enc)
     sp.load_state_dict(dec.state_dict())
     feats1 = [f[:1] for f in feats]
-    for thr in (-1.0, 0.01, 0.05, 0.1):
+    for thr in (-1.0, 0.01, 0.05, 0.1, 2.0):   # 2.0: every wavelet mask empty (nnz = 0 on all levels)
         with torch.no_grad():
             out = quiet(sp, feats1, thr)
         np.savez_compressed(os.path.join(HERE, "kitti_sparse_r18_64x64_thr%g.npz" % thr), **outputs_to_np(out))

@@ -42,6 +42,27 @@ def test_minmax_threshold_dilate_compact_bit_exact(dev):
             assert torch.equal(c[:n].cpu().long(), ref_idx)          # raster order, like mask2idxmap
 
 
+def test_fused_mask_level_equals_the_three_primitives_and_the_oracle(dev):
+    """wmd_mask_level (min/max + threshold + all dilations, one launch) against the separate entry points (bit-exact) and
+    against the oracle's max-pool dilations of the oracle's threshold mask."""
+    from wavelet_monodepth_amd import sparse_ops as S
+    specs = [(1, 0), (1, 1), (1, 2), (2, 2), (2, 1), (2, 0), (2, 3), (1, 3)]
+    for (h, w) in [(1, 1), (3, 5), (7, 9), (12, 40), (48, 160)]:
+        yl = t(synth.normal((1, 1, h, w), "fyl", 6))
+        yh = t(synth.normal((1, 1, 3, h, w), "fyh", 6))
+        for ratio in (0.02, 0.3, 0.6, -1.0, 5.0):
+            fused = S.mask_level(yl.to(dev), yh.to(dev), ratio, specs)
+            mask = S.mask_threshold(yh.to(dev), S.minmax(yl.to(dev)), ratio)
+            sep = S.dilate_multi(mask, specs)
+            assert torch.equal(fused[0], mask)
+            for f, o in zip(fused, sep):
+                assert torch.equal(f, o)
+            ref = (yh.abs().max(2)[0] > (yl.max() - yl.min()) * ratio).float()
+            assert torch.equal(fused[0].cpu().float(), ref[0, 0])
+            assert torch.equal(fused[3].cpu().float(), R.dilate(R.up2(ref), 5)[0, 0])
+            assert torch.equal(fused[2].cpu().float(), R.dilate(ref, 5)[0, 0])
+
+
 def test_sparse_conv_matches_reference_primitive_golden(dev):
     """sparse_conv3x3 of the reference (KITTI/layers.py:409-480) on a hand-made mask pair, both index paddings."""
     from wavelet_monodepth_amd import ops, sparse_ops as S
@@ -97,6 +118,19 @@ def test_sparse_decoder_vs_reference_golden_with_reference_masks(dev, name, hw, 
     feats = kitti_feats(2 if name == "64x64" else 1, hw[0], hw[1], seed=seed)
     force = {i: t(gold["wavelet_mask|%d" % (i - 1)])[0, 0, ::2, ::2] for i in (3, 2, 1)}
     out = _decoder(dev)([f[:1].to(dev) for f in feats], thr, _force_masks=force)
+    _check(out, gold)
+
+
+def test_sparse_decoder_empty_masks_vs_reference_golden(dev):
+    """thresh_ratio above 1: no coefficient passes, every compacted list has nnz = 0 (the reference then runs its
+    gather-GEMMs on empty tensors); masks, op count and maps must still match, eagerly and from the replayed graph."""
+    gold = load_golden("kitti_sparse_r18_64x64_thr2.npz")
+    sp = _decoder(dev)
+    feats = [f[:1].to(dev) for f in kitti_feats(2, 64, 64)]
+    _check(sp(feats, 2.0), gold)
+    sp.enable_graph(True)
+    for _ in range(2):
+        out = sp(feats, 2.0)
     _check(out, gold)
 
 

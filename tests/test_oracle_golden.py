@@ -114,7 +114,7 @@ def test_kitti_dense_decoder_grads():
     assert n == len([k for k in g if k.startswith("d|")])
 
 
-@pytest.mark.parametrize("thr", [-1.0, 0.01, 0.05, 0.1])
+@pytest.mark.parametrize("thr", [-1.0, 0.01, 0.05, 0.1, 2.0])   # 2.0: all masks empty
 def test_kitti_sparse_decoder(thr):
     sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
     feats = [f[:1] for f in kitti_feats(2, 64, 64)]

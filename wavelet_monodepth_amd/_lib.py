@@ -141,6 +141,8 @@ SIGNATURES = {
     "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),
+    "wmd_mask_level": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int,
+                       C.c_void_p]),
     "wmd_mask_compact_multi": (C.c_int, [C.POINTER(CompactSpec), C.c_int, C.c_void_p]),
     "wmd_sparse_conv": (C.c_int, [C.POINTER(SparseConvArgs), C.c_void_p]),
     "wmd_upsample_bilinear_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),

@@ -81,36 +81,141 @@ __global__ void mask_dilate_multi_kernel(const uint8_t* __restrict__ mask, int h
     }
 }
 
+// minmax + threshold + every dilated variant of one level in ONE launch (the three steps above are a dependent chain of
+// tiny kernels at batch 1).  No grid synchronisation is needed: yl has only h*w values, so every block reduces min/max
+// itself (exact whatever the order), and a dilated pixel is the OR of the thresholded coefficients of the COARSE cells
+// its window covers -- the base mask is never read back.  Spec (1, 0) is the base mask itself.
+struct MaskLevelKArgs {
+    const float* yl;
+    const float* yh;
+    float ratio;
+    int n_yl, h, w;
+    wmd_dilate_spec s[8];
+};
+
+// NC = compile-time bound on the coarse cells one window spans per dimension (2r+1 without upsampling, r+1 with): the
+// loads of all NC*NC cells are unconditional (indices clamped into the window, which leaves the OR unchanged) and
+// independent, so they go out back to back instead of one memory round trip per cell.
+template <int NC>
+__device__ __forceinline__ void mask_level_body(const MaskLevelKArgs& a, const wmd_dilate_spec& sp, float thr) {
+    const int h = a.h, w = a.w, npix = h * w;
+    const int H = h * sp.up, W = w * sp.up, r = sp.radius;
+    const int sh = sp.up == 2 ? 1 : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+        const int y = i / W, x = i % W;
+        // out-of-range taps never win (MaxPool2d pads with -inf): clamp the window, then map it to coarse cells
+        const int cy0 = max(y - r, 0) >> sh, cy1 = min(y + r, H - 1) >> sh;
+        const int cx0 = max(x - r, 0) >> sh, cx1 = min(x + r, W - 1) >> sh;
+        float m[NC * NC];
+#pragma unroll
+        for (int p = 0; p < NC; ++p)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = min(cy0 + p, cy1) * w + min(cx0 + q, cx1);
+                m[p * NC + q] = fmaxf(fmaxf(fabsf(a.yh[c]), fabsf(a.yh[npix + c])), fabsf(a.yh[2 * npix + c]));
+            }
+        uint8_t v = 0;
+#pragma unroll
+        for (int p = 0; p < NC * NC; ++p) v |= m[p] > thr ? 1 : 0;
+        sp.out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a) {
+    float lo = INFINITY, hi = -INFINITY;
+    // eight independent loads per round (clamped index, the duplicate of the last element changes neither min nor max):
+    // a rolled one-load-per-iteration loop would be one memory round trip per 256 values
+    for (int i = threadIdx.x; i < a.n_yl; i += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a.yl[min(i + k * 256, a.n_yl - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            lo = fminf(lo, v[k]);
+            hi = fmaxf(hi, v[k]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    __shared__ float slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+    hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+    const float thr = (hi - lo) * a.ratio;   // same fp32 expression as mask_threshold_kernel
+
+    const wmd_dilate_spec sp = a.s[blockIdx.y];
+    switch (sp.up == 2 ? sp.radius + 1 : 2 * sp.radius + 1) {
+        case 1: mask_level_body<1>(a, sp, thr); break;
+        case 2: mask_level_body<2>(a, sp, thr); break;
+        case 3: mask_level_body<3>(a, sp, thr); break;
+        case 4: mask_level_body<4>(a, sp, thr); break;
+        case 5: mask_level_body<5>(a, sp, thr); break;
+        default: mask_level_body<7>(a, sp, thr); break;
+    }
+}
+
 struct CompactKArgs {
     wmd_compact_spec s[8];
 };
 
-// One workgroup (16 wavefronts) per mask.  Per 1024-pixel chunk: every wavefront takes a 64-bit __ballot of its
-// flags; a lane's slot is popcount(ballot & lanes-below); wavefront totals are scanned through LDS.
+// One workgroup (16 wavefronts) per mask.  A thread takes 16 consecutive flags (one 16-byte load), packs them into a
+// bit field and counts them; counts are scanned inside the wavefront by shuffles and across the 16 wavefronts through
+// LDS (two barriers per 16 384 pixels); a thread then writes its own pixels in ascending order => raster order.
 __global__ __launch_bounds__(1024) void mask_compact_multi_kernel(const CompactKArgs a) {
     const wmd_compact_spec sp = a.s[blockIdx.x];
     __shared__ int wave_tot[16];
-    __shared__ int running;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (int base = 0; base < sp.npix; base += 1024) {
-        const int i = base + threadIdx.x;
-        const bool flag = i < sp.npix && sp.mask[i] != 0;
-        const unsigned long long bal = __ballot(flag);
-        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wave] = __popcll(bal);
-        __syncthreads();
-        int off = running;
-        for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
-        if (flag) sp.coords[off + prefix] = i;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int wv = 0; wv < 16; ++wv) tot += wave_tot[wv];
-            running += tot;
+    const bool vec = (reinterpret_cast<uintptr_t>(sp.mask) & 15) == 0;
+    int running = 0;   // identical in every thread
+    for (int base = 0; base < sp.npix; base += 1024 * 16) {
+        const int i0 = base + threadIdx.x * 16;
+        unsigned bits = 0;
+        if (vec && i0 + 16 <= sp.npix) {
+            const uint4 v = *reinterpret_cast<const uint4*>(sp.mask + i0);
+            const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned t = wd[k];
+                t |= t >> 4;
+                t |= t >> 2;
+                t |= t >> 1;   // bit 0 of every byte = (byte != 0)
+                bits |= ((t & 1u) | ((t >> 7) & 2u) | ((t >> 14) & 4u) | ((t >> 21) & 8u)) << (4 * k);
+            }
+        } else {
+            for (int k = 0; k < 16; ++k)
+                if (i0 + k < sp.npix && sp.mask[i0 + k] != 0) bits |= 1u << k;
         }
+        const int cnt = __popc(bits);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int wv = 0; wv < 16; ++wv) {
+            const int c = wave_tot[wv];
+            before += wv < wave ? c : 0;
+            tot += c;
+        }
+        int off = running + before + incl - cnt;
+        while (bits) {
+            const int k = __ffs(bits) - 1;
+            sp.coords[off++] = i0 + k;
+            bits &= bits - 1;
+        }
+        running += tot;
+        __syncthreads();   // wave_tot is rewritten by the next round
     }
     if (threadIdx.x == 0) *sp.nnz = running;
 }
@@ -122,26 +227,56 @@ struct SparseKArgs {
     size_t plane, plane1;
 };
 
-// WK wavefronts share one (16-pixel tile, MR out-channel tiles) task and split the input-channel loop between
-// them (the chain is latency-bound: a single wave would walk all Cin*9 gathers serially); partial accumulators
-// are combined through LDS by wave 0.
-template <int MR, int TAPS, bool DUAL, int WK>
+// WK wavefronts share one (16-pixel tile, MR out-channel tiles) task and split the input-channel loop between them;
+// partial accumulators are combined through LDS by wave 0.  At batch 1 a launch has a few dozen to a few hundred
+// active tiles, far fewer than the GPU has SIMDs, so the kernel is a dependent chain of memory round trips, not a
+// throughput problem.  The chain is kept at two trips: (1) count + pixel-list entry, (2) everything else at once --
+// the input-mask bytes, the gathers of UN K-steps x TAPS (addresses are clamped coordinates and never wait for the
+// mask: liveness is applied to the loaded value) and the weight fragments -- then MFMAs, the LDS reduction and the
+// store (bias requested up front).
+//
+// ROWS (3x3 only, W >= 3 and W1 >= 3): the three taps of a kernel row are neighbours in memory, so a lane fetches them
+// with ONE 12-byte load of a 3-wide window (base column clamped so that the window stays inside the row and still
+// covers the padded tap columns; for the 2x-upsampled source the three taps fall on <= 2 adjacent coarse columns) and
+// picks each tap by a 2-bit index -- a third of the gather instructions, which is what a CU runs out of first
+// (every scattered 64-lane dword gather costs the texture path some tens of cycles).
+struct __attribute__((packed, aligned(4))) Window3 {
+    float v[3];
+};
+
+template <int MR, int TAPS, bool DUAL, int WK, int UN, bool ROWS>
 __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs a) {
+    static_assert(!ROWS || TAPS == 9, "row windows are a 3x3 feature");
     const wmd_sparse_conv_args& g = a.g;
-    const int nnz = min(*g.out_nnz, g.max_out);
     const int tile = blockIdx.x;
-    if (tile * 16 >= nnz) return;
     const int lane = threadIdx.x & 63;
     const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kq = lane >> 4;
     const int pidx = tile * 16 + j;
+    // the pixel-list entry is requested together with the count, not after it; entries past the count are stale,
+    // so dead lanes borrow a live pixel of the tile
+    const int praw = g.out_coords[min(pidx, g.max_out - 1)];
+    const int nnz = min(*g.out_nnz, g.max_out);
+    if (tile * 16 >= nnz) return;
     const bool px_ok = pidx < nnz;
-    const int p = g.out_coords[min(pidx, nnz - 1)];
+    const int p = px_ok ? praw : __shfl(praw, lane & 48);   // lane 16k holds pixel tile*16 < nnz
     const int oy = p / g.W, ox = p % g.W;
     const int Cin = g.C1 + g.C2;
+    const int cot0 = blockIdx.y * MR;
 
-    // neighbour offsets through the coordinate padding + input-mask test (layers.py:439-453)
+    float bias_v[MR][4], bias2_v[DUAL ? MR : 1][4];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = (cot0 + m) * 16 + kq * 4 + r;
+            bias_v[m][r] = (g.bias && co < g.Cout) ? g.bias[co] : 0.f;
+            if (DUAL) bias2_v[m][r] = (g.bias2 && co < g.Cout) ? g.bias2[co] : 0.f;
+        }
+
+    // neighbour coordinates through the coordinate padding (layers.py:439-453); the input-mask test only gates the value
     int o1[TAPS], o2[TAPS];
+    bool live[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
         int gy = oy + (TAPS == 9 ? t / 3 - 1 : 0), gx = ox + (TAPS == 9 ? t % 3 - 1 : 0);
@@ -152,9 +287,29 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
         }
         gy = min(max(gy, 0), g.H - 1);
         gx = min(max(gx, 0), g.W - 1);
-        if (g.in_mask) ok = ok && g.in_mask[gy * g.W + gx] != 0;
-        o2[t] = ok ? gy * g.W + gx : -1;
-        o1[t] = ok ? (gy / g.up1) * a.W1 + gx / g.up1 : -1;
+        o2[t] = gy * g.W + gx;
+        o1[t] = (gy / g.up1) * a.W1 + gx / g.up1;
+        live[t] = ok;
+    }
+    uint8_t mk[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) mk[t] = g.in_mask ? g.in_mask[o2[t]] : (uint8_t)1;
+    // ROWS: window origin per kernel row for both sources + the column index of each tap inside the window
+    int w1off[3], w2off[3];
+    unsigned ix1 = 0, ix2 = 0;
+    if constexpr (ROWS) {
+        const int cx0 = o2[0] % g.W, cx1 = o2[1] % g.W, cx2 = o2[2] % g.W;   // padded + clamped tap columns
+        const int base2 = min(min(cx0, min(cx1, cx2)), g.W - 3);
+        const int dx0 = cx0 / g.up1, dx1 = cx1 / g.up1, dx2 = cx2 / g.up1;
+        const int base1 = min(min(dx0, min(dx1, dx2)), a.W1 - 3);
+        ix2 = (unsigned)(cx0 - base2) | (unsigned)(cx1 - base2) << 2 | (unsigned)(cx2 - base2) << 4;
+        ix1 = (unsigned)(dx0 - base1) | (unsigned)(dx1 - base1) << 2 | (unsigned)(dx2 - base1) << 4;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int cy = o2[3 * r] / g.W;
+            w2off[r] = cy * g.W + base2;
+            w1off[r] = (cy / g.up1) * a.W1 + base1;
+        }
     }
 
     f32x4 acc[MR], acc2[DUAL ? MR : 1];
@@ -164,7 +319,6 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int cot0 = blockIdx.y * MR;
     const float* wa[MR];
     const float* wa2[MR];
 #pragma unroll
@@ -175,38 +329,66 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
     }
 
     const int nci4 = (Cin + 3) / 4;
-#pragma unroll 2
-    for (int ci4 = wk; ci4 < nci4; ci4 += WK) {
-        const int ci = ci4 * 4 + kq;
-        const bool from1 = ci < g.C1;
-        const bool ch_ok = ci < Cin;
-        const int c1 = min(ci, g.C1 - 1), c2 = min(max(ci - g.C1, 0), max(g.C2 - 1, 0));
-        const float* s1 = g.x1 + (size_t)(g.c1_off + c1) * a.plane1;
-        const float* s1b = DUAL ? g.x1 + (size_t)(g.c1_off2 + c1) * a.plane1 : nullptr;
-        const float* s2 = g.x2 ? g.x2 + (size_t)c2 * a.plane : s1;
+    for (int cb = wk; cb < nci4; cb += WK * UN) {
+        float bv[UN][TAPS], bv2[DUAL ? UN : 1][TAPS];
+        float av[UN][TAPS][MR], av2[DUAL ? UN : 1][TAPS][DUAL ? MR : 1];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            // unconditional loads from clamped offsets, zeroing by select afterwards
-            const int q1 = max(o1[t], 0), q2 = max(o2[t], 0);
-            const float v1 = s1[q1];
-            const float v2 = g.x2 ? s2[q2] : 0.f;
-            const bool live = ch_ok && o2[t] >= 0;
-            const float b = live ? (from1 ? v1 : v2) : 0.f;
-            float b2 = 0.f;
-            if (DUAL) {
-                const float v1b = s1b[q1];
-                b2 = (live && from1) ? v1b : 0.f;
-            }
+        for (int u = 0; u < UN; ++u) {
+            const int ci4 = min(cb + u * WK, nci4 - 1);           // past the end: recomputed with a zeroed operand
+            const bool step_ok = cb + u * WK < nci4;
+            const int ci = ci4 * 4 + kq;
+            const bool from1 = ci < g.C1;
+            const bool ch_ok = step_ok && ci < Cin;
+            const int c1 = min(ci, g.C1 - 1), c2 = min(max(ci - g.C1, 0), max(g.C2 - 1, 0));
+            const float* s1 = g.x1 + (size_t)(g.c1_off + c1) * a.plane1;
+            const float* s1b = DUAL ? g.x1 + (size_t)(g.c1_off2 + c1) * a.plane1 : nullptr;
+            const float* s2 = g.x2 ? g.x2 + (size_t)c2 * a.plane : s1;
+            const bool use1 = from1 || !g.x2;
+            if constexpr (ROWS) {
+                const unsigned ix = use1 ? ix1 : ix2;
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                const float af = wa[m][(size_t)(ci4 * TAPS + t) * 64];
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b, acc[m], 0, 0, 0);
-                if (DUAL) {
-                    const float af2 = wa2[m][(size_t)(ci4 * TAPS + t) * 64];
-                    acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2, b2, acc2[m], 0, 0, 0);
+                for (int r = 0; r < 3; ++r) {
+                    const Window3 wv = *reinterpret_cast<const Window3*>(use1 ? s1 + w1off[r] : s2 + w2off[r]);
+                    Window3 wv2;
+                    if (DUAL) wv2 = *reinterpret_cast<const Window3*>(s1b + w1off[r]);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const unsigned sel = (ix >> (2 * d)) & 3u;
+                        bv[u][3 * r + d] = sel == 0 ? wv.v[0] : (sel == 1 ? wv.v[1] : wv.v[2]);
+                        if (DUAL) bv2[u][3 * r + d] = sel == 0 ? wv2.v[0] : (sel == 1 ? wv2.v[1] : wv2.v[2]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const float* src = use1 ? s1 + o1[t] : s2 + o2[t];   // one load per tap whichever the source
+                    bv[u][t] = *src;
+                    if (DUAL) bv2[u][t] = s1b[o1[t]];
                 }
             }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    av[u][t][m] = wa[m][(size_t)(ci4 * TAPS + t) * 64];
+                    if (DUAL) av2[u][t][m] = wa2[m][(size_t)(ci4 * TAPS + t) * 64];
+                }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const bool on = ch_ok && live[t] && mk[t] != 0 && (from1 || g.x2 != nullptr);
+                bv[u][t] = on ? bv[u][t] : 0.f;
+                if (DUAL) bv2[u][t] = (on && from1) ? bv2[u][t] : 0.f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t][m], bv[u][t], acc[m], 0, 0, 0);
+                    if (DUAL) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[u][t][m], bv2[u][t], acc2[m], 0, 0, 0);
+                }
     }
 
     if (WK > 1) {
@@ -235,10 +417,10 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
         for (int r = 0; r < 4; ++r) {
             const int co = (cot0 + m) * 16 + kq * 4 + r;
             if (co < g.Cout) {
-                float v = acc[m][r] + (g.bias ? g.bias[co] : 0.f);
+                float v = acc[m][r] + bias_v[m][r];
                 v = g.out_scale * act_apply(v, g.act, g.slope);
                 if (DUAL) {
-                    float u = acc2[m][r] + (g.bias2 ? g.bias2[co] : 0.f);
+                    float u = acc2[m][r] + bias2_v[m][r];
                     v = v - g.out_scale * act_apply(u, g.act, g.slope);
                 }
                 g.y[(size_t)co * a.plane + p] = v;
@@ -286,6 +468,30 @@ extern "C" int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wm
     return check_launch("mask_dilate_multi_kernel");
 }
 
+extern "C" int wmd_mask_level(const float* yl, size_t n_yl, const float* yh, float thresh_ratio, int h, int w,
+                              const wmd_dilate_spec* specs, int n, void* stream) {
+    if (!yl || !yh || !specs) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level: null pointer");
+    if (n_yl == 0 || n_yl > (size_t)1 << 24) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: n_yl=%zu", n_yl);
+    if (h <= 0 || w <= 0 || n <= 0 || n > 8) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: h=%d w=%d n=%d", h, w, n);
+    MaskLevelKArgs a;
+    a.yl = yl;
+    a.yh = yh;
+    a.ratio = thresh_ratio;
+    a.n_yl = (int)n_yl;
+    a.h = h;
+    a.w = w;
+    int maxpix = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!specs[i].out || (specs[i].up != 1 && specs[i].up != 2) || specs[i].radius < 0 || specs[i].radius > 3)
+            return fail(WMD_ERR_BAD_ARG, "wmd_mask_level: spec %d (up=%d radius=%d)", i, specs[i].up, specs[i].radius);
+        a.s[i] = specs[i];
+        maxpix = std::max(maxpix, h * specs[i].up * w * specs[i].up);
+    }
+    ProfScope prof("mask_level_kernel", 25.0 * maxpix * n, 2.0 * maxpix * n + 16.0 * h * w, (hipStream_t)stream);
+    hipLaunchKernelGGL(mask_level_kernel, dim3(std::min((maxpix + 255) / 256, 1024), n), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("mask_level_kernel");
+}
+
 extern "C" int wmd_mask_compact_multi(const wmd_compact_spec* specs, int n, void* stream) {
     if (!specs) return fail(WMD_ERR_BAD_ARG, "wmd_mask_compact_multi: null pointer");
     if (n <= 0 || n > 8) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_compact_multi: n=%d", n);
@@ -328,22 +534,34 @@ extern "C" int wmd_sparse_conv(const wmd_sparse_conv_args* g, void* stream) {
     const int tiles = (g->max_out + 15) / 16;
     const int taps = g->ksize == 3 ? 9 : 1;
     ProfScope prof("sparse_conv_kernel", 0.0, 0.0, s);
-    constexpr int WK = 8;  // waves per task for 3x3 (Cin*9 gathers per pixel); 1x1 chains are 9x shorter
-    if (g->wp2) {
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<1, 9, true, WK>), dim3(tiles, 1), dim3(64 * WK), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<1, 1, true, 2>), dim3(tiles, 1), dim3(128), 0, s, a);
-    } else if (a.ncot >= 4) {
-        const dim3 grid(tiles, (a.ncot + 3) / 4);
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<4, 9, false, WK>), grid, dim3(64 * WK), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<4, 1, false, 2>), grid, dim3(128), 0, s, a);
-    } else if (a.ncot >= 2) {
-        const dim3 grid(tiles, (a.ncot + 1) / 2);
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<2, 9, false, WK>), grid, dim3(64 * WK), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<2, 1, false, 2>), grid, dim3(128), 0, s, a);
+    // MR out-channel tiles per block: as few as keeps the grid near the machine size -- a sparse launch has far fewer
+    // pixel tiles than the GPU has SIMDs, so out-channel tiles go to separate blocks (each re-gathers the same few
+    // pixels out of L2) until the capacity grid reaches ~512 blocks (measured: tools/sparse_microbench.py); a full-density fine level keeps MR large and
+    // gathers once.  UN K-steps per wave are in flight together: the whole K-slice of a wave when registers allow.
+    static const int mr_force = [] { const char* e = getenv("WMD_SPARSE_MR"); return e ? atoi(e) : 0; }();
+    int MR = 1;
+    while (MR < 4 && MR < a.ncot && (long)tiles * ((a.ncot + MR - 1) / MR) > 512) MR *= 2;
+    if (mr_force == 1 || mr_force == 2 || mr_force == 4) MR = std::min(mr_force, a.ncot >= 4 ? 4 : a.ncot >= 2 ? 2 : 1);
+#define WMD_SPARSE_LAUNCH(MR_, TAPS_, DUAL_, WK_, UN_, ROWS_)                                                          \
+    hipLaunchKernelGGL((sparse_conv_kernel<MR_, TAPS_, DUAL_, WK_, UN_, ROWS_>), dim3(tiles, (a.ncot + MR_ - 1) / MR_), \
+                       dim3(64 * WK_), 0, s, a)
+    static const int rows_off = [] { const char* e = getenv("WMD_SPARSE_ROWS"); return e && atoi(e) == 0; }();
+    if (taps == 9 && g->W >= 3 && a.W1 >= 3 && !rows_off) {
+        if (g->wp2) WMD_SPARSE_LAUNCH(1, 9, true, 8, 2, true);
+        else if (MR == 4) WMD_SPARSE_LAUNCH(4, 9, false, 8, 2, true);
+        else if (MR == 2) WMD_SPARSE_LAUNCH(2, 9, false, 8, 2, true);
+        else WMD_SPARSE_LAUNCH(1, 9, false, 8, 2, true);
+    } else if (taps == 9) {   // maps narrower than a window
+        if (g->wp2) WMD_SPARSE_LAUNCH(1, 9, true, 8, 2, false);
+        else if (MR == 4) WMD_SPARSE_LAUNCH(4, 9, false, 8, 2, false);
+        else if (MR == 2) WMD_SPARSE_LAUNCH(2, 9, false, 8, 2, false);
+        else WMD_SPARSE_LAUNCH(1, 9, false, 8, 2, false);
     } else {
-        const dim3 grid(tiles, 1);
-        if (taps == 9) hipLaunchKernelGGL((sparse_conv_kernel<1, 9, false, WK>), grid, dim3(64 * WK), 0, s, a);
-        else hipLaunchKernelGGL((sparse_conv_kernel<1, 1, false, 2>), grid, dim3(128), 0, s, a);
+        if (g->wp2) WMD_SPARSE_LAUNCH(1, 1, true, 4, 8, false);
+        else if (MR == 4) WMD_SPARSE_LAUNCH(4, 1, false, 4, 8, false);
+        else if (MR == 2) WMD_SPARSE_LAUNCH(2, 1, false, 4, 8, false);
+        else WMD_SPARSE_LAUNCH(1, 1, false, 4, 8, false);
     }
+#undef WMD_SPARSE_LAUNCH
     return check_launch("sparse_conv_kernel");
 }

@@ -8,6 +8,8 @@ Differences that are not observable in the outputs: activations stay dense and z
 being compacted (see include/wmd.h), there is ONE host synchronisation per forward (to turn the device-side
 pixel counts into the python-int `total_ops`), and nothing is printed (the reference prints 'sparse: i').
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -21,6 +23,10 @@ from .depth_decoder import _build_wave_convs
 def _conv_ops(cin, cout, npix, k):
     # dense layers: (1 + k*k*cin*npix) * cout — the "1 +" sits inside the pixel product (reference :386-398)
     return (1 + k * k * cin * npix) * cout
+
+
+def _round64(n):
+    return (int(n) + 63) // 64 * 64
 
 
 def _sparse_conv_ops(cin, cout, nnz_out, mid=None):
@@ -100,18 +106,46 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         yl = yh = None
         xbuf = None            # dense [C,h,w] activations carried between sparse levels
         x = x.contiguous()
+        # every zero-initialised activation plane of the sparse levels comes out of ONE pooled buffer (one fill per
+        # forward instead of four per level; at batch 1 the chain is launch-latency bound)
+        pool_floats = 0
+        for i in sparse_scales:
+            if 1 <= i <= 3:
+                hh, ww = input_features[i].shape[-2:]
+                c0w, c1w = self.convs[("upconv", i, 0)].conv.conv.weight, self.convs[("upconv", i, 1)].conv.conv.weight
+                cm = self.convs[("waveconv", i, 1)][0].conv.weight.shape[0]
+                pool_floats += sum(_round64(c * n) for c, n in ((c0w.shape[0], hh * ww), (c1w.shape[0], 4 * hh * ww),
+                                                                (2 * cm, 4 * hh * ww), (3, 4 * hh * ww)))
+        pool = torch.zeros(pool_floats, device=dev) if pool_floats else None
+        pool_used = [0]
+
+        def zeros(*shape):
+            n = int(np.prod(shape))
+            v = pool[pool_used[0]:pool_used[0] + n].view(*shape)
+            pool_used[0] += _round64(n)          # every plane set starts 256-byte aligned
+            return v
+
+        SPECS = [(1, 1), (1, 2), (2, 2), (2, 1), (2, 0)]   # lowres, upconv0, upsample, upconv1, wavelet (:311-319)
         for i in range(4, -1, -1):
             scale_ops = 0
             h, w = x.shape[-2:] if xbuf is None else xbuf.shape[-2:]
-            if i == 4:
-                mask = torch.ones((h, w), device=dev, dtype=torch.uint8)
-            else:
-                mm = S.minmax(yl)
-                mask = S.mask_threshold(yh, mm, thresh_ratio)
-                scale_ops += 3 * h * w
-            if _force_masks is not None and i in _force_masks:
+            forced = _force_masks is not None and i in _force_masks
+            if i == 4 and not forced:
+                # all-ones mask: every dilation of it is all ones too (MaxPool2d pads with -inf) -- one fill, five views
+                ones = torch.ones(2 * h * w + 3 * 4 * h * w, device=dev, dtype=torch.uint8)
+                lowres, upconv0 = ones[:h * w].view(h, w), ones[h * w:2 * h * w].view(h, w)
+                upsample_m, upconv1, wavelet = (ones[2 * h * w + k * 4 * h * w:2 * h * w + (k + 1) * 4 * h * w].view(2 * h, 2 * w)
+                                                for k in range(3))
+            elif forced:
                 mask = _force_masks[i].to(dev).reshape(h, w).to(torch.uint8).contiguous()
-            lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask, [(1, 1), (1, 2), (2, 2), (2, 1), (2, 0)])
+                lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask, SPECS)
+            elif os.environ.get("WMD_SPARSE_UNFUSED_MASKS", "0") == "1":   # the three-launch form (parity tests)
+                mask = S.mask_threshold(yh, S.minmax(yl), thresh_ratio)
+                lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask, SPECS)
+            else:
+                lowres, upconv0, upsample_m, upconv1, wavelet = S.mask_level(yl, yh, thresh_ratio, SPECS)
+            if i != 4:
+                scale_ops += 3 * h * w
             scale_ops += 25 * h * w + 100 * h * w
             H2, W2 = 2 * h, 2 * w
             b = lambda m: m.view(torch.bool).reshape(1, 1, *m.shape)
@@ -129,20 +163,20 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 (co0, co1, cow), nnz = S.compact_multi([upconv0, upconv1, wavelet])
                 src = xbuf if xbuf is not None else x[0]
                 C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
-                x0 = torch.zeros((C0, h, w), device=dev)
+                x0 = zeros(C0, h, w)
                 S.sparse_conv(x0, src, ops.pack_weights(c0.weight), c0.bias, C0, 3, co0, nnz.data_ptr(), h * w,
                               in_mask=lowres, pad="reflect", act="elu")
                 skip = input_features[i - 1][0].contiguous()
-                x1 = torch.zeros((C1_, H2, W2), device=dev)
+                x1 = zeros(C1_, H2, W2)
                 S.sparse_conv(x1, x0, ops.pack_weights(c1.weight), c1.bias, C1_, 3, co1, nnz.data_ptr() + 4, H2 * W2,
                               x2=skip, up1=2, in_mask=upsample_m, pad="reflect", act="elu")
                 # heads: stacked 1x1 + LeakyReLU on the upconv1 support, dual 3x3 + sigmoid on the wavelet mask
                 hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
                 wstack, bstack = ops.stacked_pack([hp[0].conv.weight, hn[0].conv.weight], [hp[0].conv.bias, hn[0].conv.bias])
                 Cm = hp[0].conv.weight.shape[0]
-                mid = torch.zeros((2 * Cm, H2, W2), device=dev)
+                mid = zeros(2 * Cm, H2, W2)
                 S.sparse_conv(mid, x1, wstack, bstack, 2 * Cm, 1, co1, nnz.data_ptr() + 4, H2 * W2, act="leaky", slope=0.1)
-                yh_d = torch.zeros((1, 3, H2, W2), device=dev)
+                yh_d = zeros(1, 3, H2, W2)
                 S.sparse_conv(yh_d[0], mid, ops.pack_weights(hp[2].conv.weight), hp[2].conv.bias, 3, 3, cow,
                               nnz.data_ptr() + 8, H2 * W2, in_mask=upconv1, pad="reflect", act="sigmoid",
                               out_scale=2.0 ** (i - 1), c1=Cm, c1_off=0, wp2=ops.pack_weights(hn[2].conv.weight),

@@ -240,11 +240,13 @@ class SparseDecoderWave(DecoderWave):
         pending = []
         for level, (up, wave, skip, scale) in enumerate(((self.up2, self.wave2, xb[-3], 2.0), (self.up3, self.wave3, xb[-4], 1.0))):
             mh, mw = src.shape[-2:]
-            mask = S.mask_threshold(h, S.minmax(ll), thresh_ratio)
+            specs = [(1, 2), (2, 2), (2, 1), (2, 0)]
             if _force_masks is not None and level in _force_masks:
                 mask = _force_masks[level].to(dev).reshape(mh, mw).to(torch.uint8).contiguous()
+                up_mask, conva_mask, wave_mask, wavelet_mask = S.dilate_multi(mask, specs)
+            else:   # min/max + threshold + the four dilations in one launch
+                up_mask, conva_mask, wave_mask, wavelet_mask = S.mask_level(ll, h, thresh_ratio, specs)
             total_ops += 3 * mh * mw
-            up_mask, conva_mask, wave_mask, wavelet_mask = S.dilate_multi(mask, [(1, 2), (2, 2), (2, 1), (2, 0)])
             total_ops += 25 * mh * mw + 100 * mh * mw
             # mask2idxmap calls: wavelet, conva, wave (fine) + up (coarse) (+ a repeated `wave` at the 2nd level, :374-375)
             total_ops += 3 * 4 * mh * mw + mh * mw + (4 * mh * mw if level == 1 else 0)

@@ -37,6 +37,18 @@ def dilate_multi(mask, specs):
     return outs
 
 
+def mask_level(yl, yh, thresh_ratio, specs):
+    """minmax(yl) -> threshold(yh) -> every dilated variant, one launch (depth_decoder.py:308-319).
+    specs = [(up, radius), ...]; (1, 0) is the thresholded mask itself.  Bit-identical to the three separate calls."""
+    h, w = yh.shape[-2:]
+    yl, yh = yl.contiguous(), yh.contiguous()
+    outs = [torch.empty((h * up, w * up), device=yh.device, dtype=torch.uint8) for up, _ in specs]
+    arr = (_lib.DilateSpec * len(specs))(*[_lib.DilateSpec(up, r, ptr(o)) for (up, r), o in zip(specs, outs)])
+    check(_lib.lib().wmd_mask_level(ptr(yl), yl.numel(), ptr(yh), float(thresh_ratio), h, w, arr, len(specs),
+                                    current_stream()), "wmd_mask_level")
+    return outs
+
+
 def compact_multi(masks):
     """uint8 masks -> (list of int32 coordinate lists [npix capacity], int32 tensor of counts [n]) in one launch;
     raster order, counts stay on the device."""
