@@ -63,6 +63,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self.fuse_heads = True   # inference: fused 1x1 -> 3x3 -> IDWT head kernels where the width allows (32/64/128)
         self.overlap_heads = os.environ.get("WMD_OVERLAP_HEADS", "0") == "1"   # opt-in (graph mode): heads on a second stream; measured no gain
         self._side_stream = None
+        self.two_stream_graphs = os.environ.get("WMD_TWO_STREAM_GRAPHS", "1") == "1"   # graph mode: heads replay on a second stream
+        self._segments = {}
 
     # -- pieces ------------------------------------------------------------------------------
     def _head_mid(self, x, key):
@@ -110,15 +112,78 @@ class DepthWaveProgressiveDecoder(nn.Module):
 
     def forward(self, input_features):
         if self._graph_mode and not torch.is_grad_enabled():
-            self.outputs = self._graphs.run(self._forward_impl, input_features, self.parameters())
+            if self.two_stream_graphs:
+                self.outputs = self._forward_two_streams(input_features)
+            else:
+                self.outputs = self._graphs.run(self._forward_impl, input_features, self.parameters())
             return self.outputs
         return self._forward_impl(input_features)
+
+    # -- two-stream replay ---------------------------------------------------------------------
+    # A replayed hipGraph executes its nodes one after the other even when the capture forked onto a second stream
+    # (tools/graph_concurrency_probe.py: two independent 32 us convolutions take 61 us forked inside one graph, 47 us as
+    # two graphs replayed on two streams).  The forward has two dependency chains -- trunk T4 > T3 > T2 > T1 and heads
+    # H4 > H3 > H2 > H1 with H_i after T_i -- and the coarse heads / coarse trunk layers are launches of 46-360 workgroups
+    # on 256 CUs.  So the forward is captured as 8 graph segments: trunk segments (and H1, which has nothing left to
+    # overlap with) replay on the caller's stream, H4..H2 on a side stream behind an event per level.  Segments of one
+    # stream share a memory pool (they replay in capture order); the two streams use different pools, so a buffer freed
+    # during one capture can never be handed to a segment that runs concurrently; tensors that cross streams stay alive.
+    def _forward_two_streams(self, input_features):
+        key = tuple((t.data_ptr(), tuple(t.shape)) for t in input_features) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        ent = self._segments.get(key)
+        if ent is None:
+            if len(self._segments) >= 4:
+                self._segments.clear()
+            ent = self._capture_two_streams(list(input_features))
+            self._segments[key] = ent
+        trunk, heads, events, side, done, outputs, _keep = ent
+        main = torch.cuda.current_stream()
+        for i in (4, 3, 2):
+            trunk[i].replay()
+            events[i].record(main)
+            side.wait_event(events[i])
+            with torch.cuda.stream(side):
+                heads[i].replay()
+        done.record(side)
+        trunk[1].replay()
+        main.wait_event(done)
+        heads[1].replay()
+        return dict(outputs)
+
+    def _capture_two_streams(self, feats):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):          # eager warm-up (autotuning, packed-weight caches)
+            self._forward_impl(feats)
+            self._forward_impl(feats)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        pool_main, pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        trunk, heads, keep = {}, {}, [feats]
+        self.outputs = {}
+        x, yl = feats[-1], None
+        for i in range(4, 0, -1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool_main):
+                x = self.convs[("upconv", i, 0)](x)
+                skip = feats[i - 1] if self.use_skips else None
+                x = self.convs[("upconv", i, 1)](x, skip=skip, up=2)
+            trunk[i] = g
+            keep.append(x)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool_main if i == 1 else pool_side):
+                yl = self._level_heads(i, x, yl)
+            heads[i] = g
+            keep.append(yl)
+        events = {i: torch.cuda.Event() for i in (4, 3, 2)}
+        return trunk, heads, events, torch.cuda.Stream(), torch.cuda.Event(), dict(self.outputs), keep
 
     def enable_graph(self, on=True):
         """Inference only: capture the whole forward (≈45 kernel launches) into one hipGraph per input
         signature and replay it.  Outputs then live in static buffers that the next call overwrites."""
         self._graph_mode = bool(on)
         self._graphs.clear()
+        self._segments.clear()
         return self
 
     def _forward_impl(self, input_features):
