@@ -13,7 +13,10 @@ export WMD_TUNE_CACHE=$OUT/tune_cache.json
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
 # 2. kernel trace of the same command (no CPU leg)
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $OLDPWD/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1)
+#    (two-stream replay off: co-running kernels stretch each other's durations, the summary is compared with bench.py's
+#     serial per-launch hipEvents; the overlapped trace is kept next to it)
+(cd /tmp && WMD_TWO_STREAM_GRAPHS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $OLDPWD/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_two_stream -- python $OLDPWD/bench.py --no-cpu-baseline > $OUT/stats_two_stream.log 2>&1)
 # 3. PMC passes, separate runs, eager launches so every kernel is a dispatch of its own
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     set -- $pass

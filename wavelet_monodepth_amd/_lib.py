@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwmd_hip.so")
+LIB_PATH = os.environ.get("WMD_LIB_PATH") or os.path.join(_HERE, "libwmd_hip.so")   # WMD_LIB_PATH: A/B builds (development)
 
 PAD = {"zero": 0, "constant": 0, "reflect": 1, "reflection": 1, "replicate": 2}
 ACT = {"none": 0, None: 0, "elu": 1, "leaky": 2, "sigmoid": 3}
