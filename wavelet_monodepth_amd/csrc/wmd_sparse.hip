@@ -224,6 +224,7 @@ __global__ __launch_bounds__(1024) void mask_compact_multi_kernel(const CompactK
 struct SparseKArgs {
     wmd_sparse_conv_args g;
     int nci4, ncot, W1;
+    int split_waves;   // (tiles x K-slices) that must stay in flight before a wave takes a longer K range
     size_t plane, plane1;
 };
 
@@ -248,18 +249,39 @@ template <int MR, int TAPS, bool DUAL, int WK, int UN, bool ROWS>
 __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs a) {
     static_assert(!ROWS || TAPS == 9, "row windows are a 3x3 feature");
     const wmd_sparse_conv_args& g = a.g;
-    const int tile = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kq = lane >> 4;
-    const int pidx = tile * 16 + j;
-    // the pixel-list entry is requested together with the count, not after it; entries past the count are stale,
-    // so dead lanes borrow a live pixel of the tile
-    const int praw = g.out_coords[min(pidx, g.max_out - 1)];
+    // How the WK wavefronts of a block are used depends on the pixel count, which only the device knows: with few tiles
+    // all WK waves share one tile and split K (S = WK, latency-bound chain as short as possible); with many tiles the
+    // machine is full anyway and a wave that walks a longer K range for its own tile amortises the fixed trips and skips
+    // the LDS reduction (S = 1: WK tiles per block).  The pixel-list entry of every candidate mapping is requested
+    // together with the count, not after it; entries past the count are stale, so dead lanes borrow a live pixel.
+    constexpr int NS = WK == 8 ? 4 : (WK == 4 ? 3 : 1);   // S in {WK, WK/2, ..., 1}
+    int praw_s[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const int S_ = WK >> q;
+        praw_s[q] = g.out_coords[min(((int)blockIdx.x * (WK / S_) + wk / S_) * 16 + j, g.max_out - 1)];
+    }
     const int nnz = min(*g.out_nnz, g.max_out);
-    if (tile * 16 >= nnz) return;
+    const int ntile = (nnz + 15) >> 4;
+    int sq = 0;   // S = WK >> sq
+#pragma unroll
+    for (int q = 1; q < NS; ++q)
+        if (ntile * (WK >> q) >= a.split_waves) sq = q;   // merge K slices only while enough wavefronts stay busy
+    const int S = WK >> sq;
+    const int tpb = WK / S;
+    if ((int)blockIdx.x * tpb * 16 >= nnz) return;      // whole block idle
+    const int tile = (int)blockIdx.x * tpb + wk / S;
+    const int ks = wk % S;                               // this wave's K slice
+    const bool tile_ok = tile * 16 < nnz;                // wave-uniform; an idle wave still joins the barrier below
+    int praw = praw_s[0];
+#pragma unroll
+    for (int q = 1; q < NS; ++q) praw = sq == q ? praw_s[q] : praw;
+    const int pidx = tile * 16 + j;
     const bool px_ok = pidx < nnz;
-    const int p = px_ok ? praw : __shfl(praw, lane & 48);   // lane 16k holds pixel tile*16 < nnz
+    const int p = tile_ok ? (px_ok ? praw : __shfl(praw, lane & 48)) : 0;   // lane 16k holds pixel tile*16 < nnz
     const int oy = p / g.W, ox = p % g.W;
     const int Cin = g.C1 + g.C2;
     const int cot0 = blockIdx.y * MR;
@@ -329,13 +351,13 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
     }
 
     const int nci4 = (Cin + 3) / 4;
-    for (int cb = wk; cb < nci4; cb += WK * UN) {
+    for (int cb = ks; cb < (tile_ok ? nci4 : 0); cb += S * UN) {
         float bv[UN][TAPS], bv2[DUAL ? UN : 1][TAPS];
         float av[UN][TAPS][MR], av2[DUAL ? UN : 1][TAPS][DUAL ? MR : 1];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int ci4 = min(cb + u * WK, nci4 - 1);           // past the end: recomputed with a zeroed operand
-            const bool step_ok = cb + u * WK < nci4;
+            const int ci4 = min(cb + u * S, nci4 - 1);           // past the end: recomputed with a zeroed operand
+            const bool step_ok = cb + u * S < nci4;
             const int ci = ci4 * 4 + kq;
             const bool from1 = ci < g.C1;
             const bool ch_ok = step_ok && ci < Cin;
@@ -391,25 +413,25 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
                 }
     }
 
-    if (WK > 1) {
-        __shared__ f32x4 red[WK > 1 ? WK - 1 : 1][DUAL ? 2 * MR : MR][64];
-        if (wk > 0) {
+    if (WK > 1 && S > 1) {   // S is block-uniform
+        __shared__ f32x4 red[WK][DUAL ? 2 * MR : MR][64];
+        if (ks > 0) {
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                red[wk - 1][m][lane] = acc[m];
-                if (DUAL) red[wk - 1][MR + m][lane] = acc2[m];
+                red[wk][m][lane] = acc[m];
+                if (DUAL) red[wk][MR + m][lane] = acc2[m];
             }
         }
         __syncthreads();
-        if (wk > 0) return;
-#pragma unroll
-        for (int w = 0; w < WK - 1; ++w)
+        if (ks > 0) return;
+        for (int w = 1; w < S; ++w)
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                acc[m] += red[w][m][lane];
-                if (DUAL) acc2[m] += red[w][MR + m][lane];
+                acc[m] += red[wk + w][m][lane];
+                if (DUAL) acc2[m] += red[wk + w][MR + m][lane];
             }
     }
+    if (!tile_ok) return;
     if (!px_ok) return;
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -530,6 +552,8 @@ extern "C" int wmd_sparse_conv(const wmd_sparse_conv_args* g, void* stream) {
     a.W1 = g->W / g->up1;
     a.plane = (size_t)g->H * g->W;
     a.plane1 = (size_t)(g->H / g->up1) * a.W1;
+    static const int split_waves = [] { const char* e = getenv("WMD_SPARSE_SPLIT_WAVES"); return e ? atoi(e) : 2048; }();
+    a.split_waves = split_waves;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (g->max_out + 15) / 16;
     const int taps = g->ksize == 3 ? 9 : 1;
