@@ -162,6 +162,32 @@ def test_sparse_decoder_graph_replay_matches_eager(dev):
                 assert_close(out[k], v, 2e-6, key_str(k))
 
 
+def test_sparse_decoder_graph_replay_with_injected_masks(dev):
+    """Injected (device-resident) masks are live inputs of the captured graph: replay == eager, and new mask values
+    written in place flow through."""
+    sp = _decoder(dev, seed=3)
+    feats = [f.to(dev) for f in kitti_feats(1, 96, 160, seed=2)]
+    shapes = {3: (6, 10), 2: (12, 20), 1: (24, 40)}
+    gen = torch.Generator().manual_seed(5)
+    force = {i: (torch.rand(hw, generator=gen) < 0.3).to(torch.uint8).to(dev) for i, hw in shapes.items()}
+    ref = sp(feats, 0.05, _force_masks={i: m.clone() for i, m in force.items()})
+    sp.enable_graph(True)
+    for _ in range(2):
+        out = sp(feats, 0.05, _force_masks=force)
+    assert out["total_ops"] == ref["total_ops"]
+    for s_ in range(4):
+        assert_close(out[("disp", s_)], ref[("disp", s_)], 2e-6, "disp%d" % s_)
+    sp.enable_graph(False)
+    for i in force:
+        force[i].copy_((torch.rand(shapes[i], generator=gen) < 0.6).to(torch.uint8))
+    ref2 = sp(feats, 0.05, _force_masks={i: m.clone() for i, m in force.items()})
+    sp.enable_graph(True)
+    out2 = sp(feats, 0.05, _force_masks=force)
+    assert out2["total_ops"] == ref2["total_ops"] and out2["total_ops"] != ref["total_ops"]
+    for s_ in range(4):
+        assert_close(out2[("disp", s_)], ref2[("disp", s_)], 2e-6, "disp%d after in-place mask update" % s_)
+
+
 def test_sparse_equals_dense_at_negative_threshold(dev):
     """Reference invariant: thresh_ratio <= 0 reproduces the dense decoder with the same weights."""
     from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder

@@ -54,7 +54,7 @@ if "sparse" in which:
     for p in (0.05, 0.10, 0.20, 0.50):
         force = {}
         for i, (h, w) in zip((3, 2, 1), ((12, 40), (24, 80), (48, 160))):
-            m = (torch.from_numpy(synth.uniform((h, w), "dens%d" % i, 3, 0.0, 1.0)) < p).to(torch.uint8)
+            m = (torch.from_numpy(synth.uniform((h, w), "dens%d" % i, 3, 0.0, 1.0)) < p).to(torch.uint8).to(dev)
             force[i] = m
         out = sp(feats, 0.05, _force_masks=force)
         dens = [float(out[("wavelet_mask", s)].float().mean()) for s in (2, 1, 0)]

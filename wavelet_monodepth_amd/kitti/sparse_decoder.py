@@ -86,10 +86,14 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
     @torch.no_grad()
     def forward(self, input_features, thresh_ratio=0.05, sparse_scales=[0, 1, 2, 3], _force_masks=None):
         assert input_features[-1].shape[0] == 1, "works with single input only"
-        if self._graph_mode and _force_masks is None:
+        forced_on_device = _force_masks is None or all(m.is_cuda for m in _force_masks.values())
+        if self._graph_mode and forced_on_device:
             thr, scales = float(thresh_ratio), tuple(sparse_scales)
-            res = self._graphs.run(lambda f: self._device_chain(f, thr, scales, None), list(input_features),
-                                   self.parameters(), extra_key=(thr, scales))
+            lv = sorted(_force_masks) if _force_masks else []      # injected masks are live inputs of the graph too
+            nf = len(input_features)
+            res = self._graphs.run(lambda f: self._device_chain(f[:nf], thr, scales, dict(zip(lv, f[nf:])) if lv else None),
+                                   list(input_features) + [_force_masks[i] for i in lv], self.parameters(),
+                                   extra_key=(thr, scales, tuple(lv)))
             out, counters, static_ops = dict(res[0]), res[1], res[2]
         else:
             out, counters, static_ops = self._device_chain(input_features, thresh_ratio, sparse_scales, _force_masks)
