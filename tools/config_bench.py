@@ -72,6 +72,11 @@ if "nyu" in which:
         t = timeit(lambda: dec(feats), n=10)
     gmac = 33.325
     print("nyu: DecoderWave 640x480 batch %d forward: %.3f ms  %.1f frames/s  %.1f TFLOP/s" % (B, t * 1e3, B / t, 2 * gmac * B / t / 1e3))
+    dec.enable_graph(True)
+    with torch.no_grad():
+        t = timeit(lambda: dec(feats), n=20)
+    dec.enable_graph(False)
+    print("nyu: DecoderWave 640x480 batch %d forward, hipGraph replay: %.3f ms  %.1f frames/s  %.1f TFLOP/s" % (B, t * 1e3, B / t, 2 * gmac * B / t / 1e3))
     fg = [f.clone().requires_grad_(True) for f in feats]
 
     def step():
@@ -89,3 +94,11 @@ if "r50" in which:
     with torch.no_grad():
         t = timeit(lambda: dec(feats), n=10)
     print("r50: dense decoder 1024x320 batch %d forward: %.3f ms  %.1f frames/s  %.1f TFLOP/s" % (B, t * 1e3, B / t, 2 * 17.19 * B / t / 1e3))
+    for two in (False, True):
+        dec.two_stream_graphs = two
+        dec.enable_graph(True)
+        with torch.no_grad():
+            t = timeit(lambda: dec(feats), n=20)
+        print("r50: dense decoder 1024x320 batch %d forward, hipGraph replay (%s): %.3f ms  %.1f frames/s  %.1f TFLOP/s" % (
+            B, "trunk/heads on two streams" if two else "one graph", t * 1e3, B / t, 2 * 17.19 * B / t / 1e3))
+    dec.enable_graph(False)
