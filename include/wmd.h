@@ -353,6 +353,10 @@ typedef struct {
     int c1_off2;
     float out_scale;             /* y = out_scale * act(conv + bias)                              */
     float* y;                    /* dense [Cout,H,W]; written at the active pixels only            */
+    int split_waves;             /* 0 = default (2048).  The wavefronts of a block split the input channels of one
+                                  * 16-pixel tile while (tiles x slices) stays below this count, and take longer
+                                  * channel ranges of separate tiles beyond it (decided on the device from *out_nnz);
+                                  * 1 = never split, INT_MAX = always split.  Results agree to fp32 rounding.      */
 } wmd_sparse_conv_args;
 
 /* Gather-GEMM convolution on the active pixels (sparse_conv3x3 / sparse_conv1x1 / sparse_upsample /

@@ -63,6 +63,54 @@ def test_fused_mask_level_equals_the_three_primitives_and_the_oracle(dev):
             assert torch.equal(fused[2].cpu().float(), R.dilate(ref, 5)[0, 0])
 
 
+@pytest.mark.parametrize("ksize,dual", [(3, False), (1, False), (3, True)])
+def test_sparse_conv_every_k_split_mode_vs_dense_reference(dev, ksize, dual):
+    """The wavefronts of a block either split K for one tile or take whole K ranges of separate tiles, decided on the
+    device from the pixel count (args.split_waves moves the switch point): every mode, with fused upsample + concat,
+    reflect index padding, channel counts that are not multiples of 4/16, against a masked dense convolution."""
+    import torch.nn.functional as F
+    from wavelet_monodepth_amd import ops, sparse_ops as S
+    H, W = 40, 56
+    c1, c2, cout = (37, 21, 19) if not dual else (24, 0, 3)
+    up = 2 if c2 else 1
+    gen = torch.Generator().manual_seed(11)
+    x1 = torch.randn(2 * c1 if dual else c1, H // up, W // up, generator=gen)
+    x2 = torch.randn(c2, H, W, generator=gen) if c2 else None
+    in_mask = (torch.rand(H, W, generator=gen) < 0.7)
+    omask = (torch.rand(H, W, generator=gen) < 0.5)
+    cin = c1 + c2
+    w = torch.randn(cout, cin, ksize, ksize, generator=gen) / np.sqrt(cin * ksize * ksize)
+    b = torch.randn(cout, generator=gen) * 0.1
+    w2 = torch.randn(cout, cin, ksize, ksize, generator=gen) / np.sqrt(cin * ksize * ksize)
+    b2 = torch.randn(cout, generator=gen) * 0.1
+
+    def dense(xa, ww, bb):
+        xin = xa if up == 1 else F.interpolate(xa[None], scale_factor=2, mode="nearest")[0]
+        if x2 is not None:
+            xin = torch.cat([xin, x2], 0)
+        xin = (xin * (in_mask if ksize == 3 else torch.ones_like(in_mask)))[None]
+        if ksize == 3:
+            xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
+        return F.elu(F.conv2d(xin, ww, bb))[0]
+
+    ref = dense(x1[:c1], w, b) - dense(x1[c1:], w2, b2) if dual else dense(x1, w, b)
+    (coords,), cnt = S.compact_multi([omask.to(dev).to(torch.uint8)])
+    ntile = (int(omask.sum()) + 15) // 16
+    outs = []
+    for sw in (1, ntile + 1, 2 * ntile + 1, 4 * ntile + 1, 2 ** 30):      # -> 1, 2, 4, 8 (and 8) K slices per tile
+        y = torch.zeros((cout, H, W), device=dev)
+        S.sparse_conv(y, x1.to(dev), ops.pack_weights(w.to(dev)), b.to(dev), cout, ksize, coords, cnt.data_ptr(), H * W,
+                      x2=None if x2 is None else x2.to(dev), up1=up, in_mask=in_mask.to(dev).to(torch.uint8) if ksize == 3 else None,
+                      pad="reflect", act="elu", split_waves=sw,
+                      **(dict(c1=c1, c1_off=0, wp2=ops.pack_weights(w2.to(dev)), bias2=b2.to(dev), c1_off2=c1) if dual else {}))
+        y = y.cpu()
+        assert float(y[:, ~omask].abs().max()) == 0.0, "wrote outside the output mask"
+        assert_close(y[:, omask], ref[:, omask], 2e-5, "split_waves=%d" % sw)
+        outs.append(y)
+    for y in outs[1:]:
+        assert_close(y, outs[0], 2e-6, "K-split modes agree")
+
+
 def test_sparse_conv_matches_reference_primitive_golden(dev):
     """sparse_conv3x3 of the reference (KITTI/layers.py:409-480) on a hand-made mask pair, both index paddings."""
     from wavelet_monodepth_amd import ops, sparse_ops as S

@@ -103,7 +103,7 @@ class SparseConvArgs(C.Structure):
                 ("slope", C.c_float), ("x1", C.c_void_p), ("x2", C.c_void_p), ("in_mask", C.c_void_p),
                 ("out_coords", C.c_void_p), ("out_nnz", C.c_void_p), ("max_out", C.c_int),
                 ("wp", C.c_void_p), ("bias", C.c_void_p), ("wp2", C.c_void_p), ("bias2", C.c_void_p),
-                ("c1_off2", C.c_int), ("out_scale", C.c_float), ("y", C.c_void_p)]
+                ("c1_off2", C.c_int), ("out_scale", C.c_float), ("y", C.c_void_p), ("split_waves", C.c_int)]
 
 
 _lib = None

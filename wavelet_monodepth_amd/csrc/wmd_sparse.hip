@@ -553,7 +553,8 @@ extern "C" int wmd_sparse_conv(const wmd_sparse_conv_args* g, void* stream) {
     a.plane = (size_t)g->H * g->W;
     a.plane1 = (size_t)(g->H / g->up1) * a.W1;
     static const int split_waves = [] { const char* e = getenv("WMD_SPARSE_SPLIT_WAVES"); return e ? atoi(e) : 2048; }();
-    a.split_waves = split_waves;
+    if (g->split_waves < 0) return fail(WMD_ERR_BAD_ARG, "wmd_sparse_conv: split_waves=%d", g->split_waves);
+    a.split_waves = g->split_waves > 0 ? g->split_waves : split_waves;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (g->max_out + 15) / 16;
     const int taps = g->ksize == 3 ? 9 : 1;

@@ -63,7 +63,7 @@ def compact_multi(masks):
 
 def sparse_conv(y, x1, wp, bias, cout, ksize, out_coords, out_nnz, max_out, x2=None, up1=1, in_mask=None,
                 pad="reflect", act="none", slope=0.0, out_scale=1.0, c1=None, c1_off=0, wp2=None, bias2=None,
-                c1_off2=0):
+                c1_off2=0, split_waves=0):
     """Gather-GEMM convolution on the active pixels; writes y [Cout,H,W] in place at those pixels."""
     Cout_, H, W = y.shape
     assert Cout_ == cout
@@ -73,6 +73,7 @@ def sparse_conv(y, x1, wp, bias, cout, ksize, out_coords, out_nnz, max_out, x2=N
                             Cout=cout, ksize=ksize, pad_mode=PAD[pad], act=ACT[act], slope=float(slope),
                             x1=ptr(x1), x2=ptr(x2), in_mask=ptr(in_mask), out_coords=ptr(out_coords),
                             out_nnz=out_nnz, max_out=int(max_out), wp=ptr(wp), bias=ptr(bias), wp2=ptr(wp2),
-                            bias2=ptr(bias2), c1_off2=c1_off2, out_scale=float(out_scale), y=ptr(y))
+                            bias2=ptr(bias2), c1_off2=c1_off2, out_scale=float(out_scale), y=ptr(y),
+                            split_waves=int(split_waves))
     check(_lib.lib().wmd_sparse_conv(C.byref(a), current_stream()), "wmd_sparse_conv")
     return y
