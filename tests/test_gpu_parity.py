@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
 Tolerance: north_star asks for <= 1e-4 relative on depth maps; single operators are held to 2e-5
 (fp32 accumulation-order noise only)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -145,6 +147,8 @@ def test_conv_every_tile_configuration_and_split(dev):
         l = _lib.lib()
         tested = 0
         for i, name in enumerate(names):
+            if name.startswith("conv_wino_kernel") and ww is None:   # family switched off (WMD_WINOGRAD=0)
+                continue
             if not (name.endswith(",%d>" % (9 if k == 3 else 1)) or (k == 3 and name.startswith("conv_wino_kernel"))):
                 continue
             for ks in (1, 2, 3):
@@ -165,6 +169,7 @@ def test_conv_every_tile_configuration_and_split(dev):
         assert tested >= (12 if k == 3 else 4)
 
 
+@pytest.mark.skipif(os.environ.get("WMD_WINOGRAD", "1") == "0", reason="Winograd family switched off (WMD_WINOGRAD=0)")
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[7] == 3], ids=lambda c: "x".join(str(v) for v in c))
 def test_conv_winograd_configurations(dev, case):
     """Every Winograd F(2x2,3x3) configuration, forced, on every 3x3 case (pads, upsample + concat, odd sizes, ragged
