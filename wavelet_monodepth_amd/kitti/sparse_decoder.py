@@ -39,6 +39,45 @@ def _sparse_conv_ops(cin, cout, nnz_out, mid=None):
     return ops_
 
 
+def level_static_ops(i, h, w, sparse, trunk=None, heads=()):
+    """Pixel-count independent part of the reference's op model for decoder level i working on an h x w coarse grid
+    (depth_decoder.py:296-417): threshold + dilation arithmetic, the four mask2idxmap calls of a sparse level or the
+    dense layers of a dense one, and the IDWT.  trunk = ((Cin0, Cout0), (Cin1, Cout1)), heads = [(Cin, Cmid, Cin3,
+    Cout3), ...] are only read for a dense level."""
+    H2, W2 = 2 * h, 2 * w
+    n = 0
+    if i != 4:
+        n += 3 * h * w                                # max |yh| over three bands + compare (:308-309)
+    n += 25 * h * w + 100 * h * w                     # MaxPool 5x5 on the coarse grid, 5x5 on the fine grid (:313-319)
+    if sparse:
+        n += 2 * h * w + 2 * H2 * W2                  # four mask2idxmap calls (layers.py:388)
+    else:
+        (ci0, co0), (ci1, co1) = trunk
+        n += _conv_ops(ci0, co0, h * w, 3) + _conv_ops(ci1, co1, H2 * W2, 3)
+        for cin, cmid, cin3, cout3 in heads:
+            n += _conv_ops(cin, cmid, H2 * W2, 1) + _conv_ops(cin3, cout3, H2 * W2, 3)
+    n += 4 * (2 * H2) * (2 * W2)                      # IDWT output pixels x 4 (:373,417)
+    return n
+
+
+def resolve_total_ops(static_ops, counters, counts):
+    """The reference's per-scale and total op counts from the static parts, the layer widths of every sparse level
+    (counters: (level, _, (Cin0, Cout0), (Cin1, Cout1), (Cin_1x1, Cmid), (Cin3, Cout3))) and that level's pixel
+    counts (counts[level] = (upconv0, upconv1, wavelet) mask sums).  -> ({scale: ops}, total)."""
+    per_scale, total = {}, 0
+    for i in sorted(static_ops, reverse=True):
+        n = static_ops[i]
+        for (lvl, _nnz, (ci0, co0_), (ci1, co1_), (cim, cm), (ci3, co3)) in counters:
+            if lvl != i:
+                continue
+            n0, n1, nw = counts[lvl]
+            n += _sparse_conv_ops(ci0, co0_, n0) + _sparse_conv_ops(ci1, co1_, n1)
+            n += 2 * _sparse_conv_ops(ci3, co3, nw, mid=(cim, cm, n1))
+        per_scale[i - 1] = n
+        total += n
+    return per_scale, total
+
+
 class SparseDepthWaveProgressiveDecoder(nn.Module):
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
         super().__init__()
@@ -148,9 +187,6 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask, SPECS)
             else:
                 lowres, upconv0, upsample_m, upconv1, wavelet = S.mask_level(yl, yh, thresh_ratio, SPECS)
-            if i != 4:
-                scale_ops += 3 * h * w
-            scale_ops += 25 * h * w + 100 * h * w
             H2, W2 = 2 * h, 2 * w
             b = lambda m: m.view(torch.bool).reshape(1, 1, *m.shape)
             out[("lowres_mask", i - 1)] = b(lowres)
@@ -163,7 +199,7 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
 
             if i in sparse_scales:
                 assert self.use_skips and i > 0 and yl is not None
-                scale_ops += 2 * h * w + 2 * H2 * W2          # four mask2idxmap calls (layers.py:388)
+                scale_ops = level_static_ops(i, h, w, True)
                 (co0, co1, cow), nnz = S.compact_multi([upconv0, upconv1, wavelet])
                 src = xbuf if xbuf is not None else x[0]
                 C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
@@ -191,16 +227,15 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 xbuf = x1
             else:
                 src = xbuf.unsqueeze(0) if xbuf is not None else x
-                scale_ops += _conv_ops(src.shape[1], c0.weight.shape[0], h * w, 3)
                 xd = ops.conv2d_fused(src, c0.weight, c0.bias, pad="reflect", act="elu")
                 skip = input_features[i - 1] if (self.use_skips and i > 0) else None
                 cin1 = xd.shape[1] + (0 if skip is None else skip.shape[1])
-                scale_ops += _conv_ops(cin1, c1.weight.shape[0], H2 * W2, 3)
                 ux = ops.conv2d_fused(xd, c1.weight, c1.bias, x2=skip, up1=2, pad="reflect", act="elu")
-                for j in ([0] if i == 4 else []) + [-1, 1]:
-                    hd = self.convs[("waveconv", i, j)]
-                    scale_ops += _conv_ops(hd[0].conv.weight.shape[1], hd[0].conv.weight.shape[0], H2 * W2, 1)
-                    scale_ops += _conv_ops(hd[2].conv.weight.shape[1], hd[2].conv.weight.shape[0], H2 * W2, 3)
+                hds = [self.convs[("waveconv", i, j)] for j in ([0] if i == 4 else []) + [-1, 1]]
+                scale_ops = level_static_ops(
+                    i, h, w, False, ((src.shape[1], c0.weight.shape[0]), (cin1, c1.weight.shape[0])),
+                    [(hd[0].conv.weight.shape[1], hd[0].conv.weight.shape[0], hd[2].conv.weight.shape[1],
+                      hd[2].conv.weight.shape[0]) for hd in hds])
                 ll_new, yh = self._dense_coefficients(ux, i, with_ll=(i == 4))
                 if i == 4:
                     yl = ll_new
@@ -213,7 +248,6 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             out[("wavelets", i - 1, "HL")] = yh[:, :, 1]
             out[("wavelets", i - 1, "HH")] = yh[:, :, 2]
             yl, disp = ops.idwt_haar(yl, yh, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
-            scale_ops += 4 * yl.shape[2] * yl.shape[3]
             out[("disp", i - 1)] = disp
             static_ops[i] = scale_ops
             if i == 1:
@@ -223,17 +257,9 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
     @staticmethod
     def _host_op_model(out, counters, static_ops):
         # ---- the reference's op model needs the pixel counts as python ints: one sync for the whole forward
-        total_ops = 0
         resolved = {lvl: [int(v) for v in nnz.tolist()] for (lvl, nnz, *_rest) in counters}
-        for i in sorted(static_ops, reverse=True):
-            scale_ops = static_ops[i]
-            for (lvl, _nnz, (ci0, co0_), (ci1, co1_), (cim, cm), (ci3, co3)) in counters:
-                if lvl != i:
-                    continue
-                n0, n1, nw = resolved[lvl]
-                scale_ops += _sparse_conv_ops(ci0, co0_, n0) + _sparse_conv_ops(ci1, co1_, n1)
-                scale_ops += 2 * _sparse_conv_ops(ci3, co3, nw, mid=(cim, cm, n1))
-            out[("total_ops", i - 1)] = scale_ops
-            total_ops += scale_ops
-        out["total_ops"] = total_ops
+        per_scale, total = resolve_total_ops(static_ops, counters, resolved)
+        for sc, n in per_scale.items():
+            out[("total_ops", sc)] = n
+        out["total_ops"] = total
         return out
