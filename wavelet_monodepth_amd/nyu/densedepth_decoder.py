@@ -203,6 +203,28 @@ def _sparse_conv_ops(cin, cout, nnz_out):
     return cin * 9 * nnz_out + (1 + 9 * cin) * nnz_out * cout
 
 
+def nyu_sparse_total_ops(c_in, hw_in, c_d0, c_skip1, c_d1, hw1, levels, counts):
+    """The reference's op model of SparseDecoderWave.forward (densedepth_decoder.py:296-409) as a host function:
+    c_in/hw_in = channels and (h, w) of the deepest encoder block, c_d0 = conv2 width, c_skip1 = channels of the first
+    skip, c_d1 / hw1 = width and (h, w) of up1's output, levels = [(Cin_convA, Cout_convA, Cin_wave), ...] of the two sparse levels,
+    counts = [(n_wave, n_wavelet), ...] their pixel counts.  Returns the python int `total_ops`."""
+    (h0, w0), (h1, w1) = hw_in, hw1
+    n = (1 + 9 * c_in) * h0 * w0 * c_d0                       # conv2 (counted with 9 taps by the reference, :301)
+    n += (1 + 9 * (c_d0 + c_skip1)) * h1 * w1 * c_d1          # up1
+    n += (1 + 9 * c_d1) * h1 * w1 * 4                         # wave1_ll + wave1
+    n += (2 * h1) * (2 * w1)                                  # IDWT
+    mh, mw = h1, w1
+    for level, ((cin_a, ca, cin_w), (n_wave, n_wl)) in enumerate(zip(levels, counts)):
+        n += 3 * mh * mw                                      # threshold
+        n += 25 * mh * mw + 100 * mh * mw                     # dilations
+        # mask2idxmap calls: wavelet, conva, wave (fine) + up (coarse) (+ a repeated `wave` at the 2nd level, :374-375)
+        n += 3 * 4 * mh * mw + mh * mw + (4 * mh * mw if level == 1 else 0)
+        n += (4 * mh) * (4 * mw)                              # IDWT of the level
+        n += _sparse_conv_ops(cin_a, ca, n_wave) + _sparse_conv_ops(cin_w, 3, n_wl)
+        mh, mw = 2 * mh, 2 * mw
+    return n
+
+
 class SparseDecoderWave(DecoderWave):
     """SparseDecoderWave (reference densedepth_decoder.py:224-409): dense down to scale 2, then two
     threshold-gated levels that only use up{2,3}.convA and wave{2,3}.  `forward(x_blocks, thresh_ratio=0.1)`,
@@ -218,22 +240,16 @@ class SparseDecoderWave(DecoderWave):
         xb = x_blocks
         assert xb[-1].shape[0] == 1, "works with single input only"
         dev = xb[-1].device
-        total_ops = 0
         w2 = self.conv2.conv.weight
-        total_ops += (1 + 9 * xb[-1].shape[1]) * xb[-1].shape[2] * xb[-1].shape[3] * w2.shape[0]
         x_d0 = self.conv2(xb[-1])
         x_d1 = self.up1(x_d0, xb[-2])
-        chn = x_d0.shape[1] + xb[-2].shape[1]
-        total_ops += (1 + 9 * chn) * x_d1.shape[2] * x_d1.shape[3] * x_d1.shape[1]
         ll = self._wave(self.wave1_ll, x_d1, 2.0 ** 3)
         out[("disp", 3)] = ll / (2 ** 3)
         h = self._wave(self.wave1, x_d1, 2.0 ** 2).unsqueeze(1)
-        total_ops += (1 + 9 * x_d1.shape[1]) * x_d1.shape[2] * x_d1.shape[3] * 4
         out[("wavelet_mask", 2)] = torch.ones_like(h[:, 0])
         out[("wavelets", 2, "LL")] = ll
         out[("wavelets", 2, "LH")], out[("wavelets", 2, "HL")], out[("wavelets", 2, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
         ll, disp = ops.idwt_haar(ll, h, disp_scale=0.25, clamp01=False)
-        total_ops += ll.shape[2] * ll.shape[3]
         out[("disp", 2)] = disp
 
         src = x_d1[0].contiguous()       # dense [C,h,w]; later: the previous level's convA output buffer
@@ -246,10 +262,6 @@ class SparseDecoderWave(DecoderWave):
                 up_mask, conva_mask, wave_mask, wavelet_mask = S.dilate_multi(mask, specs)
             else:   # min/max + threshold + the four dilations in one launch
                 up_mask, conva_mask, wave_mask, wavelet_mask = S.mask_level(ll, h, thresh_ratio, specs)
-            total_ops += 3 * mh * mw
-            total_ops += 25 * mh * mw + 100 * mh * mw
-            # mask2idxmap calls: wavelet, conva, wave (fine) + up (coarse) (+ a repeated `wave` at the 2nd level, :374-375)
-            total_ops += 3 * 4 * mh * mw + mh * mw + (4 * mh * mw if level == 1 else 0)
             H2, W2 = 2 * mh, 2 * mw
             s = 1 - level
             out[("wavelet_mask", s)] = wavelet_mask.to(torch.float32).reshape(1, 1, H2, W2)
@@ -268,12 +280,11 @@ class SparseDecoderWave(DecoderWave):
             h = hd.unsqueeze(1)
             out[("wavelets", s, "LH")], out[("wavelets", s, "HL")], out[("wavelets", s, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
             ll, disp = ops.idwt_haar(ll, h, disp_scale=0.5 if level == 0 else 1.0, clamp01=False)
-            total_ops += ll.shape[2] * ll.shape[3]
             out[("disp", s)] = disp if level == 0 else ll
             pending.append((nnz, ca.weight.shape[1], Ca, cw.weight.shape[1]))
             src = xa
-        for nnz, cin_a, ca_, cin_w in pending:           # one host sync for the python-int op model
-            n_wave, n_wl = [int(v) for v in nnz.tolist()]
-            total_ops += _sparse_conv_ops(cin_a, ca_, n_wave) + _sparse_conv_ops(cin_w, 3, n_wl)
-        out["total_ops"] = total_ops
+        counts = [tuple(int(v) for v in nnz.tolist()) for nnz, *_ in pending]   # one host sync for the python-int op model
+        out["total_ops"] = nyu_sparse_total_ops(xb[-1].shape[1], tuple(xb[-1].shape[2:]), w2.shape[0], xb[-2].shape[1],
+                                                x_d1.shape[1], tuple(x_d1.shape[2:]),
+                                                [(cin_a, ca_, cin_w) for _nnz, cin_a, ca_, cin_w in pending], counts)
         return out
