@@ -80,3 +80,65 @@ def test_nyu_sparse_op_model_full_size_known_answer():
         want = json.load(f)["nyu_densenet161_640x480"]["total_ops"]
     counts = [(60 * 80, 60 * 80), (120 * 160, 120 * 160)]
     assert _nyu_total_ops([96, 96, 192, 384, 2208], (15, 20), counts) == want
+
+
+# ---- autotuner (host logic; the configuration table comes from the library, no GPU needed) ---------------------------------
+def test_committed_tune_cache_names_exist_in_the_library_table():
+    """bench.py preloads profiles/r01_tune_cache_config2.json; an entry whose kernel name left the table would be
+    ignored silently (and the shape re-tuned inside the warm-up)."""
+    import json, os
+    from wavelet_monodepth_amd import tuner
+    names = tuner.config_names()
+    assert len(names) >= 10 and len(set(names)) == len(names)
+    path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "r01_tune_cache_config2.json")
+    with open(path) as f:
+        cache = json.load(f)
+    assert len(cache) >= 8
+    for key, (name, ks) in cache.items():
+        assert name in names, "%s -> %s is not a kernel configuration of this build" % (key, name)
+        assert ks in tuner.KSPLITS
+
+
+def test_tuner_picks_the_fastest_valid_candidate(monkeypatch):
+    import torch
+    from wavelet_monodepth_amd import tuner
+    names = tuner.config_names()
+    cands = [i + 1 for i, n in enumerate(names) if n.endswith(",9>") or n.startswith("conv_wino_kernel")]
+    fast, refused, hopeless = cands[3], cands[1], cands[5]
+    calls = []
+
+    def launch(cfg, ks):
+        calls.append((cfg, ks))
+        return -3 if cfg == refused or ks > 4 else 0           # planner refuses: not a candidate
+
+    def fake_time(launch_, cfg, ks, reps, e0, e1):
+        if cfg == fast:
+            return 1.0 if ks == 2 else 1.5
+        return 100.0 if cfg == hopeless else 3.0 + 0.01 * cfg + 0.1 * ks
+
+    class _Ev:
+        def __init__(self, enable_timing=True):
+            pass
+
+    monkeypatch.setattr(tuner, "_time", fake_time)
+    monkeypatch.setattr(torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(tuner, "_cache_file", None)
+    key = "conv|test|host-logic"
+    try:
+        cfg, ks = tuner.tune(key, 9, launch)
+        assert (cfg, ks) == (fast, 2)
+        assert tuner.lookup(key) == (fast, 2)                  # remembered by NAME, resolved back to the index
+        assert not any(c == hopeless and k > 1 for c, k in calls), "a hopeless tile shape had its splits swept"
+        # a name that is not in the table (stale cache) is ignored, not mis-resolved
+        tuner._cache["conv|stale"] = ("conv_fwd_kernel<0,0,0,0,0,0,0,9>", 1)
+        assert tuner.lookup("conv|stale") is None
+        # preload never overrides what this process measured
+        import json, tempfile, os
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump({key: [names[cands[0] - 1], 1], "conv|other": [names[cands[0] - 1], 4]}, f)
+        tuner.preload(f.name)
+        os.unlink(f.name)
+        assert tuner.lookup(key) == (fast, 2) and tuner.lookup("conv|other") == (cands[0], 4)
+    finally:
+        for k in (key, "conv|stale", "conv|other"):
+            tuner._cache.pop(k, None)
