@@ -281,7 +281,8 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
     for (int q = 1; q < NS; ++q) praw = sq == q ? praw_s[q] : praw;
     const int pidx = tile * 16 + j;
     const bool px_ok = pidx < nnz;
-    const int p = tile_ok ? (px_ok ? praw : __shfl(praw, lane & 48)) : 0;   // lane 16k holds pixel tile*16 < nnz
+    const int plive = __shfl(praw, lane & 48);           // executed by every lane; lane 16k holds pixel tile*16 (< nnz)
+    const int p = tile_ok ? (px_ok ? praw : plive) : 0;
     const int oy = p / g.W, ox = p % g.W;
     const int Cin = g.C1 + g.C2;
     const int cot0 = blockIdx.y * MR;
