@@ -167,11 +167,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    # WMD_BENCH_BACKEND=gloo + WMD_BENCH_SHARE_DEVICES=1: rehearsal of the N>1 launch contract on a box with fewer GPUs
+    # than ranks (ranks share devices, the barrier / max-over-ranks reduction goes through gloo) -- not a measurement
+    backend = os.environ.get("WMD_BENCH_BACKEND", "nccl")
+    if os.environ.get("WMD_BENCH_SHARE_DEVICES", "0") == "1":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from wavelet_monodepth_amd import _lib, tuner
     _lib.lib()  # fail loudly if the HIP library is missing
@@ -207,7 +216,7 @@ def main():
         elapsed = time.perf_counter() - t0
         step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert all(torch.isfinite(v).all() for v in out.values())
