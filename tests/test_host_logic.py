@@ -204,3 +204,69 @@ def test_reference_format_checkpoint_roundtrip(tmp_path):
         dst2.load_state_dict(torch.load(path), strict=True)
         for k, v in src.state_dict().items():
             assert torch.equal(dst.state_dict()[k], v) and torch.equal(dst2.state_dict()[k], v), k
+
+
+# ---- no CPU fallback anywhere in the product ----------------------------------------------------------------------------
+def test_every_module_refuses_cpu_tensors():
+    """The product path must fail loudly instead of computing on the host: decoders, wavelet modules, loss and
+    evaluation operators all raise WmdError on CPU tensors (this box has no GPU)."""
+    import torch
+    from wavelet_monodepth_amd import _lib, evaluation as ev, ops, photometric as ph, sparse_ops as S
+    from wavelet_monodepth_amd.kitti import DepthDecoder, DepthWaveProgressiveDecoder, SparseDepthWaveProgressiveDecoder
+    from wavelet_monodepth_amd.nyu import DecoderWave, SparseDecoderWave
+    from wavelet_monodepth_amd.wavelets import DWT, IDWT
+    kf = [torch.zeros(1, c, 64 >> (k + 1), 64 >> (k + 1)) for k, c in enumerate(R18)]
+    enc = [8, 8, 16, 32, 64]
+    nf = [torch.zeros(1, c, 64 >> (k + 1), 96 >> (k + 1)) for k, c in enumerate(enc)]
+    calls = [
+        lambda: DepthWaveProgressiveDecoder(np.array(R18))(kf),
+        lambda: DepthDecoder(np.array(R18))(kf),
+        lambda: SparseDepthWaveProgressiveDecoder(np.array(R18))(kf, 0.05),
+        lambda: DecoderWave(enc_features=enc)(nf),
+        lambda: SparseDecoderWave(enc_features=enc)(nf, 0.1),
+        lambda: IDWT()((torch.zeros(1, 1, 4, 4), [torch.zeros(1, 1, 3, 4, 4)])),
+        lambda: DWT(J=2)(torch.zeros(1, 1, 8, 8)),
+        lambda: ph.SSIM()(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8)),
+        lambda: ph.get_smooth_loss(torch.zeros(1, 1, 8, 8), torch.zeros(1, 3, 8, 8)),
+        lambda: ev.compute_errors(torch.ones(16), torch.ones(16)),
+        lambda: S.minmax(torch.zeros(8)),
+        lambda: S.mask_threshold(torch.zeros(1, 1, 3, 4, 4), torch.zeros(2), 0.1),
+        lambda: S.dilate_multi(torch.zeros(4, 4, dtype=torch.uint8), [(1, 1)]),
+        lambda: S.mask_level(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 3, 4, 4), 0.1, [(1, 0)]),
+        lambda: S.compact_multi([torch.zeros(4, 4, dtype=torch.uint8)]),
+        lambda: S.sparse_conv(torch.zeros(4, 4, 4), torch.zeros(4, 4, 4), torch.zeros(2304), None, 4, 3,
+                              torch.zeros(16, dtype=torch.int32), 0, 16),
+        lambda: ops.upsample_bilinear(torch.zeros(1, 1, 4, 4), (8, 8)),
+        lambda: ops.dwt_haar(torch.zeros(1, 1, 8, 8), 1),
+        lambda: ops.conv2d_fused(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3), None),
+        lambda: ops.dwconv3x3_relu(torch.zeros(1, 4, 4, 4), torch.zeros(4, 1, 3, 3)),
+        lambda: ev.flip_postprocess(torch.zeros(1, 4, 4), torch.zeros(1, 4, 4)),
+        lambda: ev.compute_errors_nyu(torch.ones(1, 16), torch.ones(1, 16)),
+        lambda: ph.warp_frame(torch.zeros(1, 3, 8, 8), torch.ones(1, 1, 8, 8), torch.eye(4)[None], torch.eye(4)[None],
+                              torch.eye(4)[None]),
+    ]
+    for i, call in enumerate(calls):
+        with pytest.raises((_lib.WmdError, AssertionError)) as e:
+            with torch.no_grad():
+                call()
+        assert isinstance(e.value, _lib.WmdError), "call %d: %r" % (i, e.value)
+
+
+def test_sparse_entry_points_validate_arguments_without_gpu():
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib
+    lib = _lib.lib()
+    spec = (_lib.DilateSpec * 1)(_lib.DilateSpec(1, 0, 1))
+    assert lib.wmd_mask_level(None, 4, None, 0.1, 2, 2, spec, 1, None) == -1                      # null planes
+    assert lib.wmd_mask_level(1, 0, 1, 0.1, 2, 2, spec, 1, None) == -2                            # empty yl (torch.max raises too)
+    assert lib.wmd_mask_level(1, 4, 1, 0.1, 2, 2, spec, 9, None) == -2                            # more than 8 variants
+    bad = (_lib.DilateSpec * 1)(_lib.DilateSpec(3, 0, 1))
+    assert lib.wmd_mask_level(1, 4, 1, 0.1, 2, 2, bad, 1, None) == -1                             # up must be 1 or 2
+    a = _lib.SparseConvArgs(H=4, W=4, C1=4, up1=1, C1tot=4, c1_off=0, C2=0, Cout=4, ksize=3, pad_mode=1, act=0, slope=0.0,
+                            x1=1, x2=None, in_mask=None, out_coords=1, out_nnz=1, max_out=16, wp=1, bias=None, wp2=None,
+                            bias2=None, c1_off2=0, out_scale=1.0, y=1, split_waves=-1)
+    assert lib.wmd_sparse_conv(C.byref(a), None) == -1 and b"split_waves" in lib.wmd_last_error()
+    a.split_waves, a.ksize = 0, 5
+    assert lib.wmd_sparse_conv(C.byref(a), None) == -3                                            # unsupported kernel size
+    a.ksize, a.max_out = 3, 0
+    assert lib.wmd_sparse_conv(C.byref(a), None) == 0                                             # nothing to do: no launch
