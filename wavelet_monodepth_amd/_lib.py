@@ -197,6 +197,8 @@ def ptr(t):
     """Device pointer of a tensor (None -> NULL). The tensor must be fp32/int and contiguous."""
     if t is None:
         return None
+    if not t.is_cuda:   # last line of defence: a host pointer must never reach a kernel (there is no CPU path)
+        raise WmdError("libwmd_hip expects device tensors, got a %s tensor" % t.device)
     assert t.is_contiguous(), "libwmd_hip expects contiguous tensors"
     return t.data_ptr()
 
