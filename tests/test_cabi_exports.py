@@ -57,3 +57,39 @@ def test_ops_refuse_cpu_tensors():
     from wavelet_monodepth_amd import ops
     with pytest.raises(_lib.WmdError):
         ops.idwt_haar(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 3, 2, 2))
+
+
+def test_ctypes_structs_mirror_the_header_layout(tmp_path):
+    """Every argument struct of include/wmd.h against its ctypes mirror: size and the offset of every field, as laid out
+    by the C compiler (gcc on the header itself) -- a silent layout drift would corrupt arguments, not raise."""
+    import re
+    import subprocess
+    import sys
+
+    pairs = {"wmd_conv_args": _lib.ConvArgs, "wmd_conv_dgrad_args": _lib.ConvDgradArgs, "wmd_conv_wgrad_args": _lib.ConvWgradArgs,
+             "wmd_dwconv_args": _lib.DwConvArgs, "wmd_head_args": _lib.HeadArgs, "wmd_head_fused_args": _lib.HeadFusedArgs,
+             "wmd_head_shiftsum_args": _lib.HeadShiftsumArgs, "wmd_head_level_args": _lib.HeadLevelArgs,
+             "wmd_dilate_spec": _lib.DilateSpec, "wmd_compact_spec": _lib.CompactSpec, "wmd_sparse_conv_args": _lib.SparseConvArgs,
+             "wmd_eval_kitti_args": _lib.EvalKittiArgs, "wmd_warp_args": _lib.WarpArgs}
+    header = os.path.join(ROOT, "include", "wmd.h")
+    declared = set(re.findall(r"^\} (wmd_\w+);", open(header).read(), flags=re.M)) - {"wmd_status"}
+    assert declared == set(pairs), declared ^ set(pairs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wmd.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src)])
+    got = {}
+    for ln in subprocess.check_output([exe]).decode().split("\n"):
+        if ln:
+            c, f, v = ln.split()
+            got[(c, f)] = int(v)
+    for cname, cls in pairs.items():
+        assert got[(cname, "sizeof")] == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, "%s.%s" % (cname, fname)
