@@ -93,3 +93,38 @@ def test_ctypes_structs_mirror_the_header_layout(tmp_path):
         assert got[(cname, "sizeof")] == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, "%s.%s" % (cname, fname)
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Return type and every parameter of every prototype in include/wmd.h against _lib.SIGNATURES: count and kind
+    (pointer / int / float / size_t).  A float passed where the C side reads an int would not raise anywhere."""
+    src = open(os.path.join(ROOT, "include", "wmd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+;", "", src, flags=re.S)
+    protos = re.findall(r"^\s*([\w ]+?[\s\*]+)(wmd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.M | re.S)
+    assert len(protos) == len(_lib.SIGNATURES), (len(protos), len(_lib.SIGNATURES))
+
+    def kind_c(decl):
+        decl = decl.strip()
+        if decl == "void" or not decl:
+            return None
+        if "*" in decl:
+            return "ptr"
+        base = decl.replace("const", " ").split()
+        ty = " ".join(base[:-1]) if len(base) > 1 else base[0]
+        return {"int": "int", "float": "float", "double": "double", "size_t": "size_t", "unsigned": "int"}[ty]
+
+    def kind_py(t):
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int: "int", C.c_long: "long", C.c_float: "float", C.c_double: "double", C.c_size_t: "size_t"}[t]
+
+    for ret, name, params in protos:
+        restype, argtypes = _lib.SIGNATURES[name]
+        want = [k for k in (kind_c(p) for p in params.split(",")) if k]
+        got = [kind_py(t) for t in argtypes]
+        assert got == want, "%s: header %s, ctypes %s" % (name, want, got)
+        r = ret.strip()
+        want_r = "ptr" if "*" in r else {"int": "int", "long": "long", "size_t": "size_t", "double": "double", "float": "float", "void": None}[r.replace("const", "").strip()]
+        got_r = None if restype is None else kind_py(restype)
+        assert got_r == want_r, "%s returns %s, ctypes says %s" % (name, want_r, got_r)
