@@ -511,3 +511,34 @@ def test_upsample_bilinear_and_disp_to_depth(dev, shape, size, ac):
     assert_close(xg.grad, x.grad, 2e-5, "dx")
     y2 = ops.upsample_bilinear(xg.detach(), size, align_corners=ac)
     assert torch.equal(y2, y.detach())
+
+
+def test_nyu_model_forward_is_encoder_then_decoder(dev):
+    """NYUv2/model.py:66-71: Model(opts)(x, threshold) == decoder(encoder(x)[, threshold]) for the dense and the sparse
+    decoder; the decoder half runs on the HIP kernels (checked against the CPU oracle on the same features)."""
+    from types import SimpleNamespace as NS
+    from wavelet_monodepth_amd import nyu
+    torch.manual_seed(3)
+    base = dict(encoder_type="resnet", num_layers=18, pretrained_encoder=False, normalize_input=False, use_wavelets=True,
+                use_224=False, dw_waveconv=False, dw_upconv=False)
+    x = torch.rand(1, 3, 64, 96, device=dev)
+    for sparse in (False, True):
+        m = nyu.Model(NS(use_sparse=sparse, **base)).to(dev).eval()
+        synth.fill_state_dict(m.decoder, seed=8)
+        with torch.no_grad():
+            m.encoder(x)                       # MIOpen settles on its algorithms in the first call
+            out = m(x, 0.1)
+            feats = m.encoder(x)
+            want = m.decoder(feats, 0.1) if sparse else m.decoder(feats)
+            sd = {k: v.cpu() for k, v in m.decoder.state_dict().items()}
+            cf = [f.cpu() for f in feats]
+            ref = R.nyu_sparse_wave_decoder(cf, sd, 0.1) if sparse else R.nyu_wave_decoder(cf, sd)
+        assert set(out) == set(want)
+        for k, v in want.items():
+            if torch.is_tensor(v) and v.dtype.is_floating_point:
+                assert_close(out[k], v, 1e-5, key_str(k))      # the PyTorch encoder is not bit-reproducible run to run
+            elif not torch.is_tensor(v) and not sparse:
+                assert out[k] == v
+        if not sparse:                                          # (a threshold pixel may flip between CPU and GPU features)
+            for s in range(4):
+                assert_close(out[("disp", s)].cpu(), ref[("disp", s)], 1e-4, "disp%d vs oracle" % s)

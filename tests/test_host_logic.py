@@ -270,3 +270,61 @@ def test_sparse_entry_points_validate_arguments_without_gpu():
     assert lib.wmd_sparse_conv(C.byref(a), None) == -3                                            # unsupported kernel size
     a.ksize, a.max_out = 3, 0
     assert lib.wmd_sparse_conv(C.byref(a), None) == 0                                             # nothing to do: no launch
+
+
+# ---- NYUv2 Model(opts) (NYUv2/model.py:12-71) ------------------------------------------------------------------------------
+def test_nyu_model_picks_encoder_and_decoder_like_the_reference():
+    from types import SimpleNamespace as NS
+    import torch
+    from wavelet_monodepth_amd import _lib, nyu
+
+    def opts(**kw):
+        base = dict(encoder_type="resnet", num_layers=18, pretrained_encoder=False, normalize_input=True, use_wavelets=True,
+                    use_sparse=False, use_224=False, dw_waveconv=False, dw_upconv=False)
+        base.update(kw)
+        return NS(**base)
+
+    def depthwise(dec):
+        return any(".conv.0.0.weight" in k or k.startswith("conv.0.0") or ".0.0.weight" in k for k in dec.state_dict())
+
+    cases = [(dict(), nyu.DecoderWave, False), (dict(use_224=True), nyu.DecoderWave224, False),
+             (dict(use_sparse=True), nyu.SparseDecoderWave, False), (dict(use_wavelets=False), nyu.Decoder, False),
+             (dict(use_wavelets=False, use_224=True), nyu.Decoder224, False),
+             (dict(use_wavelets=False, dw_upconv=True), nyu.Decoder, True),
+             (dict(dw_waveconv=True, dw_upconv=True), nyu.DecoderWave, True)]
+    for kw, cls, dw in cases:
+        m = nyu.Model(opts(**kw))
+        assert type(m.decoder) is cls and m.use_sparse == bool(kw.get("use_sparse")), kw
+        assert depthwise(m.decoder) == dw, kw
+        assert list(m.encoder.num_ch_enc) == [64, 64, 128, 256, 512]
+    assert list(nyu.Model(opts(num_layers=50)).encoder.num_ch_enc) == [64, 256, 512, 1024, 2048]
+    # a namespace that predates --use_sparse (model.py:44-46) means dense, and gets the attribute
+    o = opts()
+    del o.use_sparse
+    m = nyu.Model(o)
+    assert type(m.decoder) is nyu.DecoderWave and o.use_sparse is False
+    with pytest.raises(NotImplementedError):
+        nyu.Model(opts(use_sparse=True, use_224=True))                     # model.py:41-42
+    with pytest.raises(NotImplementedError):
+        nyu.Model(opts(encoder_type="densenet"))                           # torchvision encoders are passed in instead
+    with pytest.raises(NotImplementedError):
+        nyu.Model(opts(encoder_type="vgg"))
+
+    class Enc(torch.nn.Module):                                             # what the reference's DenseEncoder exposes
+        num_ch_enc = [96, 96, 192, 384, 2208]
+
+        def forward(self, x):
+            return [torch.zeros(1, c, 64 >> (k + 1), 96 >> (k + 1)) for k, c in enumerate(self.num_ch_enc)]
+
+    m = nyu.Model(opts(encoder_type="densenet", use_sparse=True), encoder=Enc())
+    assert m.decoder.conv2.conv.weight.shape == (1104, 2208, 3, 3) and m.use_sparse
+    with pytest.raises(_lib.WmdError):                                      # encoder on the host, decoder refuses: no CPU fallback
+        m(torch.zeros(1, 3, 64, 96), 0.1)
+    # the ResNet encoder itself is ordinary PyTorch and does NOT normalise (the reference's loop discards its result)
+    enc = nyu.NyuResnetEncoder(18, normalize_input=True).eval()
+    x = torch.rand(1, 3, 64, 96)
+    with torch.no_grad():
+        feats = enc(x)
+        e = enc.encoder
+        assert torch.equal(feats[0], e.relu(e.bn1(e.conv1(x))))
+    assert [tuple(f.shape[1:]) for f in feats] == [(64, 32, 48), (64, 16, 24), (128, 8, 12), (256, 4, 6), (512, 2, 3)]
