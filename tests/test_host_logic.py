@@ -353,3 +353,26 @@ def test_convs_attribute_satisfies_the_trainers_parameter_group_rule():
         assert seen == {id(p) for p in dec.parameters()}, cls.__name__
         # keys are the reference's tuples: ("upconv", i, j), ("waveconv", i, j) / ("dispconv", s)
         assert all(isinstance(k, tuple) and k[0] in ("upconv", "waveconv", "dispconv") for k in dec.convs)
+
+
+def test_kitti_factories_follow_the_reference_signatures():
+    """network_constructors.py:12-40: make_depth_encoder(opts), make_depth_decoder(encoder, opts)."""
+    from types import SimpleNamespace as NS
+    from wavelet_monodepth_amd import kitti
+    opts = NS(encoder_type="resnet", num_layers=18, weights_init="scratch", use_wavelets=True, use_sparse=False, scales=[0, 1, 2, 3])
+    enc = kitti.make_depth_encoder(opts)
+    assert list(enc.num_ch_enc) == [64, 64, 128, 256, 512]
+    assert type(kitti.make_depth_decoder(enc, opts)) is kitti.DepthWaveProgressiveDecoder
+    opts.use_sparse = True
+    assert type(kitti.make_depth_decoder(enc, opts)) is kitti.SparseDepthWaveProgressiveDecoder
+    opts.use_wavelets = False
+    base = kitti.make_depth_decoder(enc, opts)
+    assert type(base) is kitti.DepthDecoder and list(base.scales) == [0, 1, 2, 3]
+    with pytest.raises(NotImplementedError):
+        kitti.make_depth_encoder(NS(encoder_type="mobilenet", num_layers=18, weights_init="scratch"))
+    with pytest.raises(RuntimeError):                     # "pretrained" needs a download: refused loudly
+        kitti.make_depth_encoder(NS(encoder_type="resnet", num_layers=18, weights_init="pretrained"))
+    # explicit form used by tools/test_simple.py
+    assert type(kitti.make_depth_decoder(enc.num_ch_enc, range(4), use_wavelets=True, use_sparse=True)) \
+        is kitti.SparseDepthWaveProgressiveDecoder
+    assert type(kitti.make_depth_decoder(enc.num_ch_enc, range(4))) is kitti.DepthDecoder
