@@ -1,4 +1,4 @@
-"""hipGraph capture/replay of a whole decoder forward (launch-bound: ~45 kernels of 5-250 us each).
+"""hipGraph capture/replay of a whole decoder forward (launch-bound: 25-35 kernels of 3-120 us each).
 
 One graph per input signature (pointers, shapes) and parameter version; replay re-executes every
 kernel on the live input buffers — nothing is cached but the launch sequence.  Capture uses PyTorch's

@@ -179,7 +179,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
         return trunk, heads, events, torch.cuda.Stream(), torch.cuda.Event(), dict(self.outputs), keep
 
     def enable_graph(self, on=True):
-        """Inference only: capture the whole forward (≈45 kernel launches) into one hipGraph per input
+        """Inference only: capture the whole forward (≈25 kernel launches) into hipGraph(s) per input
         signature and replay it.  Outputs then live in static buffers that the next call overwrites."""
         self._graph_mode = bool(on)
         self._graphs.clear()

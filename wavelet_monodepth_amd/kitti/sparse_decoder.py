@@ -116,7 +116,7 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         return yl, yh.unsqueeze(1)
 
     def enable_graph(self, on=True):
-        """Capture the whole device-side chain (≈45 launches, all pixel counts stay on the device) into one hipGraph
+        """Capture the whole device-side chain (≈35 launches, all pixel counts stay on the device) into one hipGraph
         per (inputs, threshold, scales) and replay it; only the python-int op model is computed on the host after."""
         self._graph_mode = bool(on)
         self._graphs.clear()
