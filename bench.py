@@ -6,10 +6,14 @@ encoder features already resident in HBM: 8 fused 3x3 MFMA convolutions, 9 wavel
 -> 4 disparity maps + 16 coefficient planes.  N GPUs = N independent shards of the batch dimension
 (weak scaling; the forward path has no exchange step, so no collective is issued).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`, plus `train`: the
+data-parallel TRAINING step of BASELINE.json configs[2] (KITTI ResNet50 1024x320, batch 8 per GPU) through the RCCL
+gradient exchange -- frames/s, gradient bytes, exposed all-reduce time, RCCL world size (skipped with --no-train).
+Other workloads for the record: --workload train (configs[2] alone), --workload train-nyu (configs[4]: NYUv2
+DenseNet161 640x480 batch 4 per GPU).
 """
 import argparse
 import json
@@ -27,6 +31,7 @@ R18 = [64, 64, 128, 256, 512]
 HEIGHT, WIDTH, BATCH = 192, 640, 12
 FLOP_PER_FRAME = 6.947e9     # conv MACs x2, SURVEY.md §8(d) / BASELINE.md §2
 PEAK_F32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+TUNE_CACHE = "r01_tune_cache_config2.json"   # committed tile / split-K choices (profiles/)
 
 
 def build_model(dev):
@@ -83,70 +88,147 @@ def cpu_baseline(dec, feats, budget_s=20.0):
                       % (len(times), med, torch.__version__, best, cands, avail)}
 
 
-def train_main(args, rank, local_rank, world, dev):
-    """Secondary workload (BASELINE.json configs[2]): KITTI ResNet50 1024x320 training step, batch 8 per GPU —
-    torch encoder + HIP decoder forward/backward, gradient all-reduce through RCCL (decoder bucket first, on a
-    side stream), Adam.  Reported for scaling studies; the headline metric stays the forward workload."""
-    import torch.distributed as dist
-    from wavelet_monodepth_amd import synth
-    from wavelet_monodepth_amd.ddp import GradientExchange, monodepth_groups
-    from wavelet_monodepth_amd.encoders import ResnetEncoder
-    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+def _train_setup(kind, args, rank, world, dev):
+    """-> (step, gx, describe) for one data-parallel training workload.
 
-    H, W, B = args.height, args.width, args.batch
+    kitti: BASELINE.json configs[2] -- ResNet encoder (PyTorch/MIOpen) + HIP wavelet decoder forward/backward, loss =
+           sum_s mean|disp_s - target_s|, Adam (trainer.py:96-98,208-212).
+    nyu:   BASELINE.json configs[4] -- DenseNet161 encoder + HIP DecoderWave at 640x480, the reference's supervised loss
+           (NYUv2/train.py:258,289-314): 0.1 * L1(bilinear-upsampled disp_s, depth) over the four scales + L1(LL3,
+           DWT_J4(depth).yl)/16, Adam.
+    One process per GPU; for world > 1 the gradients go through GradientExchange (RCCL: ~25 MB buckets, decoder first, on a
+    side stream while the encoder backward still runs)."""
+    from wavelet_monodepth_amd import ops, synth
+    from wavelet_monodepth_amd.ddp import GradientExchange, bucket_groups
+
     torch.manual_seed(0)
-    enc = ResnetEncoder(args.num_layers).to(dev)
-    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(enc.num_ch_enc), seed=1).to(dev)
+    if kind == "kitti":
+        from wavelet_monodepth_amd.encoders import ResnetEncoder
+        from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+        H, W, B = args.height, args.width, args.batch
+        enc = ResnetEncoder(args.num_layers).to(dev)
+        dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(enc.num_ch_enc), seed=1).to(dev)
+        img = torch.from_numpy(synth.uniform((B, 3, H, W), "img%d" % rank, 0, 0.0, 1.0)).to(dev)
+        target = [torch.from_numpy(synth.uniform((B, 1, H >> s, W >> s), "tgt%d" % s, rank, 0.05, 0.95)).to(dev) for s in range(4)]
+
+        def loss_fn():
+            out = dec(enc(img))
+            return sum((out[("disp", s)] - target[s]).abs().mean() for s in range(4))
+        what = "KITTI ResNet%d %dx%d training step, batch %d per GPU, loss = sum_s mean|disp_s - target_s| (BASELINE.json configs[2])" \
+            % (args.num_layers, W, H, B)
+    else:
+        from wavelet_monodepth_amd.encoders import DenseEncoder
+        from wavelet_monodepth_amd.nyu import DecoderWave
+        H, W, B = 480, 640, args.nyu_batch
+        enc = DenseEncoder().to(dev)
+        dec = synth.fill_state_dict(DecoderWave(enc_features=enc.num_ch_enc), seed=9).to(dev)
+        img = torch.from_numpy(synth.uniform((B, 3, H, W), "nimg%d" % rank, 0, 0.0, 1.0)).to(dev)
+        depth = torch.from_numpy(synth.uniform((B, 1, H // 2, W // 2), "ndepth", rank, 0.1, 1.0)).to(dev)
+        with torch.no_grad():
+            yl_gt, _ = ops.dwt_haar(depth, J=4)
+
+        def loss_fn():
+            out = dec(enc(img))
+            total = 0.0
+            for s in range(4):
+                pred = ops.upsample_bilinear(out[("disp", s)], (H // 2, W // 2), align_corners=True)
+                total = total + 0.1 * (pred - depth).abs().mean()
+            return total + (out[("wavelets", 3, "LL")] - yl_gt).abs().mean() / 16
+        what = "NYUv2 DenseNet161 %dx%d training step, batch %d per GPU, L1 on upsampled disparities + LL3 vs DWT(J=4) of the " \
+               "ground truth (BASELINE.json configs[4])" % (W, H, B)
     params = list(enc.parameters()) + list(dec.parameters())
-    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-5)
-    gx = GradientExchange(monodepth_groups(enc, dec), world=world, rank=rank, backend="rccl" if world > 1 else "torch") \
-        if world > 1 else None
-    img = torch.from_numpy(synth.uniform((B, 3, H, W), "img%d" % rank, 0, 0.0, 1.0)).to(dev)
-    target = [torch.from_numpy(synth.uniform((B, 1, H >> s, W >> s), "tgt%d" % s, rank, 0.05, 0.95)).to(dev) for s in range(4)]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    gx = None
+    if world > 1:
+        gx = GradientExchange(bucket_groups(enc, dec), world=world, rank=rank, backend=args.exchange_backend, modules=[enc, dec])
 
     def step():
         if gx is not None:
             gx.zero_grad()
         else:
             opt.zero_grad(set_to_none=True)
-        out = dec(enc(img))
-        loss = sum((out[("disp", s)] - target[s]).abs().mean() for s in range(4))
+        loss = loss_fn()
         loss.backward()
         if gx is not None:
             gx.finish()
         opt.step()
         return loss
+    return step, gx, {"workload": what, "batch_per_gpu": B, "global_batch": B * world,
+                      "parallelism": "dp%d, %s bucketed all-reduce overlapped with the encoder backward" % (world, args.exchange_backend)}
+
+
+def _timed(step, steps, warmup, world, red_dev):
+    import torch.distributed as dist
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for _ in range(steps):
+        last = step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    return elapsed, last
+
+
+def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup):
+    """Time the data-parallel training step with the gradient exchange on, then (world > 1) with the all-reduces switched
+    off: the difference is the all-reduce time the overlap did NOT hide.  -> dict (same on every rank)."""
+    step, gx, cfg = _train_setup(kind, args, rank, world, dev)
+    elapsed, loss = _timed(step, steps, warmup, world, red_dev)
     assert torch.isfinite(loss)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "training frames/sec (encoder + wavelet decoder fwd+bwd + Adam) @%dx%d bs%d/GPU" % (W, H, B),
-            "value": round(B * args.steps * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "KITTI ResNet%d %dx%d training step, batch %d per GPU, loss = sum_s mean|disp_s - target_s| "
-                                   "(BASELINE.json configs[2])" % (args.num_layers, W, H, B),
-                       "global_batch": B * world, "parallelism": "dp%d, RCCL bucketed all-reduce" % world},
-            "gradient_bytes": None if gx is None else gx.message_bytes()}))
+    B = cfg["batch_per_gpu"]
+    res = {"frames_per_s": round(B * steps * world / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "n_gpus": world, "config": cfg}
     if gx is not None:
+        sizes = gx.message_bytes()
+        gx.enabled = False            # local gradients only from here on (timing only; nothing after this needs the replicas in sync)
+        local, _ = _timed(step, steps, 2, world, red_dev)
+        gx.enabled = True
+        res.update({"gradient_bytes": sum(sizes.values()), "gradient_buckets": sizes,
+                    "ms_per_step_without_exchange": round(local / steps * 1e3, 3),
+                    "exposed_allreduce_ms_per_step": round((elapsed - local) / steps * 1e3, 3),
+                    "exchange_backend": args.exchange_backend, "exchange_world_size": gx.world})
         gx.close()
+    return res
+
+
+def train_main(kind, args, rank, world, dev, red_dev):
+    """--workload train / train-nyu: the training step alone, as the one JSON line."""
+    st = train_stats(kind, args, rank, world, dev, red_dev, args.steps, args.warmup)
+    if rank == 0:
+        cfg = st.pop("config")
+        line = {"metric": "training frames/sec (encoder + wavelet decoder fwd+bwd + Adam)", "value": st.pop("frames_per_s"),
+                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": st.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic", "config": cfg}
+        line.update({k: v for k, v in st.items() if k not in ("steps", "warmup", "n_gpus")})
+        print(json.dumps(line))
+
+
+def respawn(args):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1) and pass its output through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -155,26 +237,33 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fwd", "train"], default="fwd")
+    ap.add_argument("--no-train", action="store_true", help="skip the data-parallel training extras of the fwd workload")
+    ap.add_argument("--workload", choices=["fwd", "train", "train-nyu"], default="fwd")
     ap.add_argument("--num-layers", type=int, default=50)
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--nyu-batch", type=int, default=4)
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--exchange-backend", choices=["rccl", "torch"], default=os.environ.get("WMD_BENCH_EXCHANGE", "rccl"))
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn(args)                  # does not return
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    # WMD_BENCH_BACKEND=gloo + WMD_BENCH_SHARE_DEVICES=1: rehearsal of the N>1 launch contract on a box with fewer GPUs
-    # than ranks (ranks share devices, the barrier / max-over-ranks reduction goes through gloo) -- not a measurement
+    # WMD_BENCH_BACKEND=gloo + WMD_BENCH_SHARE_DEVICES=1 (+ --exchange-backend torch): rehearsal of the N>1 launch contract on
+    # a box with fewer GPUs than ranks (ranks share devices, every collective goes through gloo) -- not a measurement
     backend = os.environ.get("WMD_BENCH_BACKEND", "nccl")
     if os.environ.get("WMD_BENCH_SHARE_DEVICES", "0") == "1":
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -184,13 +273,13 @@ def main():
 
     from wavelet_monodepth_amd import _lib, tuner
     _lib.lib()  # fail loudly if the HIP library is missing
-    # tile/split-K choices measured for this workload in an earlier run (any missing key is tuned in the warm-up)
+    # tile/split-K choices measured for these workloads in an earlier run (any missing key is tuned in the warm-up)
     # (WMD_BENCH_RETUNE=1 ignores the committed choices: used to regenerate that file after kernel changes)
     if os.environ.get("WMD_BENCH_RETUNE", "0") != "1":
-        tuner.preload(os.path.join(ROOT, "profiles", "r01_tune_cache_config2.json"))
+        tuner.preload(os.path.join(ROOT, "profiles", TUNE_CACHE))
 
-    if args.workload == "train":
-        train_main(args, rank, local_rank, world, dev)
+    if args.workload != "fwd":
+        train_main("kitti" if args.workload == "train" else "nyu", args, rank, world, dev, red_dev)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -224,46 +313,16 @@ def main():
     # kernel-level roofline: the same K steps again with hipEvent pairs around every launch
     roof = None
     if rank == 0:
-        with torch.no_grad():
-            dec.enable_graph(False)   # per-launch hipEvents need eager launches
-            dec(feats)
-            _lib.profile_begin()
-            for _ in range(args.steps):
-                dec(feats)
-            recs = _lib.profile_end()
-        # trunk convolutions: the direct kernels and the Winograd F(2x2,3x3) ones (the fused-head GEMM chain is listed apart)
-        is_wino = lambda r: r["kernel"].startswith("conv_wino_kernel")
-        convs = [r for r in recs if (r["kernel"].startswith("conv_fwd_kernel<") and "fused" not in r["kernel"]) or is_wino(r)]
-        dom = max(convs, key=lambda r: r["ms"])
-        tot_ms = sum(r["ms"] for r in recs)
-        conv_ms = sum(r["ms"] for r in convs)
-        conv_fl = sum(r["flops"] for r in convs)
-        # `flops` are ALGORITHMIC (2*Cin*9*Cout per output pixel); a Winograd kernel executes 2.25x fewer on the matrix pipe
-        executed = lambda r: r["flops"] / (2.25 if is_wino(r) else 1.0)
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        ach_exec = executed(dom) / (dom["ms"] * 1e-3) / 1e12
-        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same kernel only
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"].get(dom["kernel"], {}).get("traffic_bytes_per_launch")
-        except OSError:
-            pass
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic,
-                "algorithm": "winograd F(2x2,3x3): achieved counts algorithmic (direct-convolution) FLOPs, the matrix pipe "
-                             "executes 1/2.25 of them" if is_wino(dom) else "direct implicit GEMM",
-                "executed_mfma_tflops": round(ach_exec, 2), "frac_executed": round(ach_exec / PEAK_F32_MFMA, 4),
-                "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],
-                "kernel": dom["kernel"], "launches_per_step": dom["calls"] // args.steps,
-                "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
-                "flop_per_launch": dom["flops"] / dom["calls"],
-                "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                                     "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
-                                     "executed_mfma_tflops": round(sum(executed(r) for r in convs) / (conv_ms * 1e-3) / 1e12, 2),
-                                     "share_of_gpu_time": round(conv_ms / tot_ms, 3)},
-                "whole_step": {"achieved": round(FLOP_PER_FRAME * BATCH * args.steps / (tot_ms * 1e-3) / 1e12, 2),
-                               "gpu_ms_per_step": round(tot_ms / args.steps, 4)},
-                "kernels_ms_per_step": {r["kernel"]: round(r["ms"] / args.steps, 4) for r in recs}}
+        roof = roofline(dec, feats, args.steps)
+    if world > 1:
+        barrier()   # rank 0's per-launch pass ends before the collective part starts
+
+    # data-parallel training step (BASELINE.json configs[2]) through the gradient exchange: every rank takes part
+    train = None
+    if not args.no_train:
+        del out
+        dec.enable_graph(False)
+        train = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 3)
 
     if rank == 0:
         frames = BATCH * args.steps * world
@@ -286,11 +345,66 @@ def main():
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d (independent shards)" % world},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dec, feats),   # rank 0, N=1 only
+            "train": train,
         }
         print(json.dumps(res))
     if world > 1:
-        barrier()   # rank 0's per-launch roofline pass ends before any rank tears the communicator down
+        barrier()
         dist.destroy_process_group()
+
+
+def roofline(dec, feats, steps):
+    """Per-kernel hipEvent pass over `steps` eager forwards -> the `roofline` object of the JSON line.
+
+    The dominant kernel is a Winograd F(2x2,3x3) convolution: the matrix pipe executes 1/2.25 of the algorithmic
+    (direct-convolution) FLOPs.  `achieved` / `frac` are what the MFMA pipe EXECUTES against its dense fp32 peak (a true
+    fraction of a hardware limit); the algorithmic rate (SURVEY.md §8(d)'s per-unit figure x units per launch / duration)
+    is kept beside it as `achieved_algorithmic` / `frac_algorithmic` and can exceed 1."""
+    from wavelet_monodepth_amd import _lib
+    with torch.no_grad():
+        dec.enable_graph(False)   # per-launch hipEvents need eager launches
+        dec(feats)
+        _lib.profile_begin()
+        for _ in range(steps):
+            dec(feats)
+        recs = _lib.profile_end()
+    # trunk convolutions: the direct kernels and the Winograd ones (the fused-head GEMM chains are listed apart)
+    is_wino = lambda r: r["kernel"].startswith("conv_wino")
+    convs = [r for r in recs if (r["kernel"].startswith("conv_fwd_kernel<") and "fused" not in r["kernel"]) or is_wino(r)]
+    dom = max(convs, key=lambda r: r["ms"])
+    tot_ms = sum(r["ms"] for r in recs)
+    conv_ms = sum(r["ms"] for r in convs)
+    conv_fl = sum(r["flops"] for r in convs)
+    executed = lambda r: r["flops"] / (2.25 if is_wino(r) else 1.0)
+    alg = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    ach = executed(dom) / (dom["ms"] * 1e-3) / 1e12
+    traffic, traffic_src = None, None   # HBM bytes per launch: rocprofv3 --pmc passes of this same command (tools/profile_session.sh)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pm = json.load(f)
+        traffic = pm["kernels"].get(dom["kernel"], {}).get("traffic_bytes_per_launch")
+        traffic_src = "imported: profiles/pmc_traffic.json (%s)" % pm.get("source", "rocprofv3 --pmc passes of bench.py")
+    except OSError:
+        pass
+    heads = [r for r in recs if r not in convs and not r["kernel"].startswith("conv_splitk")]
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithm": "winograd F(2x2,3x3): achieved/frac = FLOPs the matrix pipe executes (algorithmic / 2.25)"
+                         if is_wino(dom) else "direct implicit GEMM (executed = algorithmic FLOPs)",
+            "achieved_algorithmic": round(alg, 2), "frac_algorithmic": round(alg / PEAK_F32_MFMA, 4),
+            "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],
+            "kernel": dom["kernel"], "launches_per_step": dom["calls"] // steps,
+            "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
+            "flop_per_launch": dom["flops"] / dom["calls"],
+            "all_conv_kernels": {"achieved": round(sum(executed(r) for r in convs) / (conv_ms * 1e-3) / 1e12, 2),
+                                 "frac": round(sum(executed(r) for r in convs) / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
+                                 "achieved_algorithmic": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                 "ms_per_step": round(conv_ms / steps, 4),
+                                 "share_of_gpu_time": round(conv_ms / tot_ms, 3)},
+            "heads_and_idwt": {"ms_per_step": round(sum(r["ms"] for r in heads) / steps, 4)},
+            "whole_step": {"achieved_algorithmic": round(FLOP_PER_FRAME * BATCH * steps / (tot_ms * 1e-3) / 1e12, 2),
+                           "gpu_ms_per_step": round(tot_ms / steps, 4)},
+            "kernels_ms_per_step": {r["kernel"]: round(r["ms"] / steps, 4) for r in recs}}
 
 
 if __name__ == "__main__":

@@ -85,6 +85,10 @@ int wmd_idwt_haar_bwd(const float* d_out, const float* d_disp, const float* out,
  * NYUv2/train.py:258 on 240x320 depth): x [N,2h,2w] -> yl [N,h,w], yh [N,3,h,w].
  * Call J times for a J-level transform (yh list is fine -> coarse).                    */
 int wmd_dwt_haar_fwd(const float* x, float* yl, float* yh, int N, int h, int w, void* stream);
+/* The same analysis step for ANY input size H x W (mode="reflect" of pytorch_wavelets' DWTForward, NYUv2/train.py:258):
+ * an odd axis is extended by one reflected sample on the right / bottom (x[N] = x[N-2]) before the stride-2 filter
+ * pair, so yl [N,ceil(H/2),ceil(W/2)], yh [N,3,ceil(H/2),ceil(W/2)].  An odd axis needs >= 2 samples.                */
+int wmd_dwt_haar_reflect_fwd(const float* x, float* yl, float* yh, int N, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Dense convolutions of the decoders (implicit GEMM on fp32 MFMA)
@@ -386,6 +390,8 @@ int wmd_comm_unique_id(void* unique_id_128);
 int wmd_comm_init(wmd_comm** comm, const void* unique_id_128, int world, int rank);
 /* in-place sum all-reduce of `n` floats then scale by `scale` (1/world), on `stream` */
 int wmd_comm_allreduce(wmd_comm* comm, float* buf, size_t n, float scale, void* stream);
+/* in-place broadcast of n floats from rank `root` (initial parameter / BatchNorm-buffer synchronisation of the replicas) */
+int wmd_comm_broadcast(wmd_comm* comm, float* buf, size_t n, int root, void* stream);
 int wmd_comm_destroy(wmd_comm* comm);
 
 /* ------------------------------------------------------------------ *

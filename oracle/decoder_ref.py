@@ -39,11 +39,16 @@ def haar_idwt(yl, yh):
 
 
 def haar_dwt(x, J=1):
-    """DWT(J, wave='haar', mode='reflect') on even sizes (NYUv2/train.py:258,289).
+    """DWT(J, wave='haar', mode='reflect') (NYUv2/train.py:258,289).  Odd axes: pytorch_wavelets (lowlevel.afb1d, mode
+    'reflect') pads p = 2*(ceil(N/2)-1) - N + 2 = 1 sample as (p//2, (p+1)//2) = (0, 1) with F.pad(..., 'reflect'), i.e. one
+    reflected sample on the right / bottom; pinned by PyWavelets' dwt2(mode='reflect') on odd sizes (tests/golden/pywt_haar.npz).
     Returns (yl, [yh_fine, ..., yh_coarse]) with yh[k] of shape [B,C,3,h,w]."""
     yh = []
     ll = x
     for _ in range(J):
+        ph, pw = ll.shape[-2] % 2, ll.shape[-1] % 2
+        if ph or pw:
+            ll = torch.nn.functional.pad(ll, (0, pw, 0, ph), mode="reflect")
         a = ll[:, :, 0::2, 0::2]
         b = ll[:, :, 0::2, 1::2]
         c = ll[:, :, 1::2, 0::2]

@@ -3,6 +3,8 @@
 Run in the build container only (needs /root/reference):
     python tests/golden/make_golden.py kitti
     python tests/golden/make_golden.py nyu
+    python tests/golden/make_golden.py nyu_variants
+    python tests/golden/make_golden.py kitti_round2
 (two processes because both reference projects call their package `networks`).
 The outputs are data (inputs are regenerated from wavelet_monodepth_amd.synth); no reference source
 is copied.  See refshim/pytorch_wavelets/__init__.py for how the absent third-party IDWT is handled.
@@ -265,6 +267,51 @@ def gen_nyu():
     print("nyu goldens written")
 
 
+def pack_outputs(out, limit=4096):
+    """Full-size outputs as small fixtures: float maps -> strided sample (util.sample's rule), boolean masks -> packbits
+    (+ shape), integers as they are."""
+    res = {}
+    for k, v in out.items():
+        ks = key_str(k)
+        if torch.is_tensor(v) and v.dtype.is_floating_point:
+            res["s|" + ks] = sample(v.detach().cpu().numpy().astype(np.float32), limit)
+        elif torch.is_tensor(v):
+            a = v.detach().cpu().numpy().astype(np.uint8)
+            res["m|" + ks] = np.packbits(a.reshape(-1))
+            res["mshape|" + ks] = np.asarray(a.shape, dtype=np.int64)
+        else:
+            res["i|" + ks] = np.asarray(int(v), dtype=np.int64)
+    return res
+
+
+def gen_kitti_round2():
+    """Round 2: (a) BASELINE config 4 at FULL size -- the reference's sparse decoder on R18 640x192 features for the
+    thresholds of the sweep (sampled maps, bit-packed masks, op-count integers); (b) non-default `sparse_scales`
+    (depth_decoder.py:292,331: levels outside the list run densely inside the sparse decoder)."""
+    sys.path.insert(0, "/root/reference/KITTI")
+    from networks.decoders import SparseDepthWaveProgressiveDecoder
+
+    num_ch_enc = np.array([64, 64, 128, 256, 512])
+    sp = synth.fill_state_dict(SparseDepthWaveProgressiveDecoder(num_ch_enc), seed=1)
+    feats = [t(f) for f in synth.encoder_features(1, 192, 640, num_ch_enc, seed=1)]
+    for thr in (0.01, 0.05, 0.1):
+        with torch.no_grad():
+            out = quiet(sp, feats, thr)
+        dens = [float(out[("wavelet_mask", s)].float().mean()) for s in (2, 1, 0)]
+        print("640x192 thr", thr, "wavelet mask density", dens, "total_ops", int(out["total_ops"]))
+        np.savez_compressed(os.path.join(HERE, "kitti_sparse_r18_640x192_thr%g.npz" % thr), **pack_outputs(out))
+    feats_b = [t(f) for f in synth.encoder_features(1, 96, 160, num_ch_enc, seed=2)]
+    # (a dense level BELOW a sparse one crashes in the reference -- its dense branch keeps reading the stale `x` -- so the
+    # usable lists are the ones whose sparse levels are the finest ones: i = 1; i = 2, 1; none)
+    for scales in ([0, 1], [1, 2], [0]):
+        with torch.no_grad():
+            out = quiet(sp, feats_b, 0.15, scales)
+        np.savez_compressed(os.path.join(HERE, "kitti_sparse_r18_96x160_thr0.15_scales%s.npz" % "".join(map(str, scales))),
+                            **outputs_to_np(out))
+        print("sparse_scales", scales, "total_ops", int(out["total_ops"]))
+    print("round-2 kitti goldens written")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "kitti"
-    {"kitti": gen_kitti, "nyu": gen_nyu, "nyu_variants": gen_nyu_variants}[which]()
+    {"kitti": gen_kitti, "nyu": gen_nyu, "nyu_variants": gen_nyu_variants, "kitti_round2": gen_kitti_round2}[which]()

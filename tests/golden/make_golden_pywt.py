@@ -19,7 +19,8 @@ for name, (h, w) in {"a": (4, 6), "b": (12, 40), "c": (7, 5), "d": (24, 80)}.ite
     yh = synth.normal((3, h, w), "pywt_yh_" + name, 11).astype(np.float64)
     rec = pywt.idwt2((yl, (yh[0], yh[1], yh[2])), "haar", mode="zero")
     out["idwt_" + name] = rec
-for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4)}.items():
+# "o*": odd sizes -- mode="reflect" extends an odd axis by one reflected sample (round 2)
+for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4), "o1": (7, 9, 1), "o2": (15, 22, 3), "o3": (30, 45, 4)}.items():
     x = synth.normal((h, w), "pywt_x_" + name, 12).astype(np.float64)
     ll = x
     for j in range(J):

@@ -36,18 +36,37 @@ class TinyNet(nn.Module):
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from wavelet_monodepth_amd.ddp import GradientExchange, monodepth_groups
+    from wavelet_monodepth_amd.ddp import GradientExchange, bucket_groups
     net = TinyNet()
-    gx = GradientExchange(monodepth_groups(net.encoder, net.decoder), backend="torch")
-    assert [b["name"] for b in gx.buckets][0] == "decoder"
+    if rank == 1:                                        # replicas start different: construction broadcasts rank 0's values
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    gx = GradientExchange(bucket_groups(net.encoder, net.decoder, bucket_bytes=1200), backend="torch", modules=[net])
+    assert [b["name"] for b in gx.buckets][0] == "decoder" and len(gx.buckets) >= 3
+    ref = TinyNet()
+    assert all(torch.equal(a, b) for a, b in zip(net.parameters(), ref.parameters()))
     torch.manual_seed(1)
     full = torch.randn(4, 3, 8, 8)
     shard = full[rank * 2:(rank + 1) * 2]
-    for step in range(2):                                # second step exercises zero_grad / bucket reuse
-        gx.zero_grad()
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    for step in range(3):                                # later steps exercise bucket re-arming with every zero_grad flavour
+        if step == 1:
+            opt.zero_grad(set_to_none=False)             # keeps the bucket views (used to skip the exchange silently)
+        else:
+            gx.zero_grad()
         loss = net(shard).pow(2).mean()
         loss.backward()
         gx.finish()
+        if step == 0:                                    # the bucket holding the unused `fc` learned not to wait for it
+            assert all(b["arm"] <= len(b["params"]) for b in gx.buckets)
+            assert sum(b["arm"] for b in gx.buckets) == sum(len(b["params"]) for b in gx.buckets) - 2
+    # gradient accumulation: two local backward passes, one exchange
+    gx.zero_grad()
+    with gx.no_sync():
+        net(shard[:1]).pow(2).mean().mul(0.5).backward()
+    net(shard[1:]).pow(2).mean().mul(0.5).backward()
+    gx.finish()
     grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
     torch.save(grads, os.path.join(out_dir, "g%d.pt" % rank))
     gx.close()

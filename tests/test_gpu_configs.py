@@ -1,0 +1,262 @@
+"""GPU parity at the REAL sizes of BASELINE.json's configurations (round-1 verdict: configs 3, 4 and 5 were only timed or
+only run at toy sizes): forward AND gradients through the C ABI against the CPU oracle / the reference's own outputs.
+
+  config 3  KITTI ResNet50 channels [64,256,512,1024,2048] @1024x320: 10x32 coarse tiles, Cin = 2048 split-K plans, every
+            wgrad / dgrad plan at those shapes; batch-8 properties
+  config 4  KITTI R18 640x192 sparse decoder, thresholds 0.01 / 0.05 / 0.1 against the reference's packed full-size outputs,
+            non-default `sparse_scales`
+  config 5  NYUv2 DenseNet161 widths [96,96,192,384,2208] @640x480 backward (ragged 2208 -> 1104 -> 552 ... channel tails)
+  +         MobileNetV2 widths [32,24,32,64,1280] / [..,160] (24-channel skips, K tails), tools/test_simple.py smoke
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as R
+from wavelet_monodepth_amd import synth
+from util import R18, R50, assert_close, check_packed, key_str, kitti_feats, load_golden, nyu_feats, sample, t, unpack_mask
+
+pytestmark = pytest.mark.gpu
+NET_TOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _sq_loss(out):
+    # squared: the plain mean of an IDWT output does not depend on the high-frequency heads at all
+    return sum((out[("disp", s)] ** 2).mean() for s in range(4))
+
+
+def _compare_grads(dec, feats_gpu, sd_cpu, feats_cpu, tol=NET_TOL, skip_feats=()):
+    for k, (a, b) in enumerate(zip(feats_gpu, feats_cpu)):
+        if b.grad is None or k in skip_feats:
+            continue
+        assert a.grad is not None, "feature %d got no gradient" % k
+        assert_close(a.grad, b.grad, tol, "dfeat%d" % k)
+    n = 0
+    for name, p in dec.named_parameters():
+        g = sd_cpu[name].grad
+        assert g is not None and p.grad is not None, name
+        assert_close(p.grad, g, tol, "d " + name)
+        n += 1
+    return n
+
+
+def _kitti_wave_fwd_bwd_vs_oracle(dev, chans, B, H, W, seed):
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=seed).to(dev)
+    feats = kitti_feats(B, H, W, chans, seed=seed)
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in dec.state_dict().items()}
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    ref = R.kitti_wave_decoder(fc, sd)
+    _sq_loss(ref).backward()
+    # inference path (fused heads, Winograd trunk, tuned tiles)
+    with torch.no_grad():
+        out = dec([f.to(dev) for f in feats])
+    for k in ref:
+        assert_close(out[k], ref[k].detach(), NET_TOL, "no_grad " + key_str(k))
+    # training path (per-head operators with saved activations) + backward kernels
+    fg = [f.to(dev).requires_grad_(True) for f in feats]
+    og = dec(fg)
+    for k in ref:
+        assert_close(og[k], ref[k].detach(), NET_TOL, "grad-mode " + key_str(k))
+    loss = _sq_loss(og)
+    loss.backward()
+    assert abs(float(loss) - float(_sq_loss(ref))) < 1e-5 * max(1.0, abs(float(_sq_loss(ref))))
+    n = _compare_grads(dec, fg, sd, fc)
+    assert n == 52
+    return dec
+
+
+def test_config3_r50_1024x320_forward_and_gradients_vs_oracle(dev):
+    """One full-size frame: every trunk / head / IDWT kernel and every dgrad / wgrad plan at the config-3 shapes
+    (2048 -> 256 @10x32 ... 32 @160x512) against the oracle and its autograd."""
+    _kitti_wave_fwd_bwd_vs_oracle(dev, R50, 1, 320, 1024, seed=3)
+
+
+def test_config3_r50_half_size_batch2_gradients_vs_oracle(dev):
+    """512x160 (odd coarse grid 5x16) at batch 2: batch strides of the backward kernels with R50 channel counts."""
+    _kitti_wave_fwd_bwd_vs_oracle(dev, R50, 2, 160, 512, seed=4)
+
+
+def test_config3_r50_batch8_properties(dev):
+    """The full per-GPU batch of config 3 (8 x 1024x320), beyond what the CPU oracle can afford, through size-independent
+    properties: (a) per-sample independence of the forward, (b) a batch made of 8 copies of one frame has the same
+    batch-mean loss gradient w.r.t. the weights as that frame alone (wgrad's pixel/batch split reduction at full size),
+    and 1/8 of its feature gradient per copy."""
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R50)), seed=5).to(dev)
+    feats8 = [f.to(dev) for f in kitti_feats(8, 320, 1024, R50, seed=5)]
+    with torch.no_grad():
+        out8 = {k: v.clone() for k, v in dec(feats8).items()}
+        one = dec([f[5:6] for f in feats8])
+    for s in range(4):
+        assert_close(out8[("disp", s)][5:6], one[("disp", s)], 1e-6, "batch independence disp%d" % s)
+    del out8, one
+    f1 = [f[2:3].clone().requires_grad_(True) for f in feats8]
+    _sq_loss(dec(f1)).backward()
+    g1 = {n: p.grad.clone() for n, p in dec.named_parameters()}
+    gf1 = [f.grad.clone() for f in f1]
+    for p in dec.parameters():
+        p.grad = None
+    rep = [f[2:3].expand(8, -1, -1, -1).contiguous().requires_grad_(True) for f in feats8]
+    _sq_loss(dec(rep)).backward()
+    for n, p in dec.named_parameters():
+        assert_close(p.grad, g1[n], 2e-5, "replicated-batch dW " + n)
+    for k, f in enumerate(rep):
+        assert_close(f.grad[3:4] * 8, gf1[k], 2e-5, "replicated-batch dfeat%d" % k)
+
+
+def test_config5_densenet161_640x480_backward_vs_oracle(dev):
+    """NYUv2 DecoderWave at DenseNet161 widths, one 640x480 frame: gradients of every feature map and every parameter
+    against autograd through the oracle (2208 -> 1104 conv2, 1488 -> 552 ... 330 -> 138: wgrad with ragged K tails)."""
+    from wavelet_monodepth_amd.nyu import DecoderWave
+    enc = [96, 96, 192, 384, 2208]
+    dec = synth.fill_state_dict(DecoderWave(enc_features=enc), seed=9).to(dev)
+    feats = nyu_feats(1, 480, 640, enc, seed=9, prefix="nyu_big")
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in dec.state_dict().items()}
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    ref = R.nyu_wave_decoder(fc, sd)
+    _sq_loss(ref).backward()
+    fg = [f.to(dev).requires_grad_(True) for f in feats]
+    og = dec(fg)
+    for k in ref:
+        assert_close(og[k], ref[k].detach(), NET_TOL, key_str(k))
+    _sq_loss(og).backward()
+    n = _compare_grads(dec, fg, sd, fc)
+    assert n == len(list(dec.parameters())) and n >= 20
+
+
+def test_config5_densenet161_batch4_properties(dev):
+    """Config 5's per-GPU batch (4 x 640x480): batch independence of the forward and the replicated-batch gradient identity."""
+    from wavelet_monodepth_amd.nyu import DecoderWave
+    enc = [96, 96, 192, 384, 2208]
+    dec = synth.fill_state_dict(DecoderWave(enc_features=enc), seed=10).to(dev)
+    feats4 = [f.to(dev) for f in nyu_feats(4, 480, 640, enc, seed=10, prefix="nyu_b4")]
+    with torch.no_grad():
+        out4 = {k: v.clone() for k, v in dec(feats4).items()}
+        one = dec([f[3:4] for f in feats4])
+    for s in range(4):
+        assert_close(out4[("disp", s)][3:4], one[("disp", s)], 1e-6, "batch independence disp%d" % s)
+    f1 = [f[1:2].clone().requires_grad_(True) for f in feats4]
+    _sq_loss(dec(f1)).backward()
+    g1 = {n: p.grad.clone() for n, p in dec.named_parameters()}
+    for p in dec.parameters():
+        p.grad = None
+    rep = [f[1:2].expand(4, -1, -1, -1).contiguous().requires_grad_(True) for f in feats4]
+    _sq_loss(dec(rep)).backward()
+    for n, p in dec.named_parameters():
+        assert_close(p.grad, g1[n], 2e-5, "replicated-batch dW " + n)
+
+
+@pytest.mark.parametrize("last", [1280, 160])
+def test_mobilenetv2_channel_contract_forward_and_gradients(dev, last):
+    """KITTI/networks/encoders/mobilenetv2_encoder.py:142: num_ch_enc = [32, 24, 32, 64, 1280] (or 160 without the last
+    layer): Cin = 1280, 24-channel skips -> K-tail paths of every kernel family, forward + backward vs the oracle."""
+    _kitti_wave_fwd_bwd_vs_oracle(dev, [32, 24, 32, 64, last], 2, 64, 96, seed=6)
+
+
+def test_mobilenetv2_baseline_decoder_vs_oracle(dev):
+    from wavelet_monodepth_amd.kitti import DepthDecoder
+    chans = [32, 24, 32, 64, 1280]
+    dec = synth.fill_state_dict(DepthDecoder(np.array(chans)), seed=7).to(dev)
+    feats = kitti_feats(2, 64, 96, chans, seed=7)
+    sd = {k: v.cpu() for k, v in dec.state_dict().items()}
+    with torch.no_grad():
+        ref = R.kitti_baseline_decoder(feats, sd)
+        out = dec([f.to(dev) for f in feats])
+    for k in ref:
+        assert_close(out[k], ref[k], NET_TOL, key_str(k))
+
+
+# ---- config 4: sparse decoder at 640x192 -----------------------------------------------------------------------------------
+def _sparse(dev, seed=1):
+    from wavelet_monodepth_amd.kitti import SparseDepthWaveProgressiveDecoder
+    return synth.fill_state_dict(SparseDepthWaveProgressiveDecoder(np.array(R18)), seed=seed).to(dev)
+
+
+@pytest.mark.parametrize("thr", [0.01, 0.05, 0.1])
+def test_config4_sparse_640x192_vs_reference_with_reference_masks(dev, thr):
+    """The reference's own full-size outputs (tests/golden/kitti_sparse_r18_640x192_thr*.npz: sampled maps, bit-packed
+    masks, op integers).  The reference's threshold masks are injected (a coefficient sitting exactly at the threshold may
+    flip with fp32 rounding); dilations, compaction, gather-GEMMs, heads, IDWT, all five mask families and the integer op
+    model must then match exactly / to 1e-4.  Eager and hipGraph replay."""
+    gold = load_golden("kitti_sparse_r18_640x192_thr%g.npz" % thr)
+    force = {i: t(unpack_mask(gold, "wavelet_mask|%d" % (i - 1)))[0, 0, ::2, ::2].contiguous().to(dev) for i in (3, 2, 1)}
+    sp = _sparse(dev)
+    feats = [f.to(dev) for f in kitti_feats(1, 192, 640, seed=1)]
+    check_packed(sp(feats, thr, _force_masks=force), gold, NET_TOL)
+    sp.enable_graph(True)
+    for _ in range(2):
+        out = sp(feats, thr, _force_masks=force)
+    check_packed(out, gold, NET_TOL)
+
+
+@pytest.mark.parametrize("thr", [0.01, 0.05, 0.1])
+def test_config4_sparse_640x192_free_running_vs_oracle(dev, thr):
+    """No injected masks: the GPU's own thresholding.  A coefficient within rounding distance of the threshold may flip, so
+    masks are allowed to differ in at most 1e-4 of the pixels (none observed), and where a run produced identical masks
+    everything else must match the oracle to 1e-4 and the op count exactly."""
+    sp = _sparse(dev)
+    feats = kitti_feats(1, 192, 640, seed=1)
+    sd = {k: v.cpu() for k, v in sp.state_dict().items()}
+    with torch.no_grad():
+        ref = R.kitti_sparse_decoder(feats, sd, thr)
+    out = sp([f.to(dev) for f in feats], thr)
+    flips = 0
+    for s in range(3):
+        a, b = out[("wavelet_mask", s)].cpu(), ref[("wavelet_mask", s)]
+        flips += int((a != b).sum())
+        assert float((a != b).float().mean()) <= 1e-4, "scale %d: %d mask pixels differ" % (s, int((a != b).sum()))
+    if flips == 0:
+        assert out["total_ops"] == ref["total_ops"]
+        for s in range(4):
+            assert_close(out[("disp", s)], ref[("disp", s)], NET_TOL, "disp%d" % s)
+
+
+@pytest.mark.parametrize("scales", [[0, 1], [1, 2], [0]])
+def test_sparse_decoder_non_default_sparse_scales_vs_reference(dev, scales):
+    """depth_decoder.py:292,331: levels outside `sparse_scales` run densely inside the sparse decoder.  Fixtures from the
+    reference (it only survives lists whose sparse levels are the finest ones); its masks are injected as above."""
+    gold = load_golden("kitti_sparse_r18_96x160_thr0.15_scales%s.npz" % "".join(map(str, scales)))
+    force = {i: t(gold["wavelet_mask|%d" % (i - 1)])[0, 0, ::2, ::2] for i in (3, 2, 1)}
+    out = _sparse(dev)([f.to(dev) for f in kitti_feats(1, 96, 160, seed=2)], 0.15, scales, _force_masks=force)
+    assert set(key_str(k) for k in out) == set(gold)
+    for k, v in out.items():
+        ks = key_str(k)
+        if torch.is_tensor(v) and v.dtype == torch.bool:
+            assert np.array_equal(v.cpu().numpy().astype(np.uint8), gold[ks]), ks
+        elif torch.is_tensor(v):
+            assert_close(v, gold[ks], NET_TOL, ks)
+        else:
+            assert int(v) == int(gold[ks]), "%s: %d vs %d" % (ks, int(v), int(gold[ks]))
+
+
+# ---- config 1: tools/test_simple.py -------------------------------------------------------------------------------------------
+def test_config1_test_simple_script_writes_its_outputs(dev, tmp_path):
+    """BASELINE config 1 (the reference runs KITTI/test_simple.py on the CPU; this package has no CPU path by design, so the
+    plumbing check runs on the GPU): the script must run end to end and write the files it announces."""
+    script = os.path.join(ROOT, "tools", "test_simple.py")
+    for extra, sub in (([], "dense"), (["--sparse", "--threshold", "0.05"], "sparse")):
+        out_dir = os.path.join(str(tmp_path), sub)
+        r = subprocess.run([sys.executable, script, "--out", out_dir] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = sorted(os.listdir(out_dir))
+        assert len(files) == 17, files                           # the scaled disparity + 4 scales x (LL, LH, HL, HH)
+        disp = np.load(os.path.join(out_dir, "image_disp.npy"))
+        assert disp.shape == (1, 1, 192, 640) and np.isfinite(disp).all()
+        assert 0.01 - 1e-6 <= disp.min() and disp.max() <= 10.0 + 1e-4   # disp_to_depth(., 0.1, 100): [1/100, 1/0.1]
+        for s_ in range(4):
+            ll = np.load(os.path.join(out_dir, "image_wavelets_%d_LL.npy" % s_))
+            assert ll.shape == (1, 1, 96 >> s_, 320 >> s_) and np.isfinite(ll).all()
+        if sub == "sparse":
+            assert "total_ops" in r.stdout

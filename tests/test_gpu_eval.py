@@ -40,7 +40,10 @@ def test_compute_errors_nyu_vs_reference_golden(dev):
         gt = u("nyu_gt%d" % i, shape, 0.5, 9.5)
         pred = np.clip(gt * u("nyu_ratio%d" % i, shape, 0.6, 1.6), 0.4, 10.0).astype(np.float32)
         # the reference pools all images of the call into one mean: do the same by flattening
-        out = ev.compute_errors_nyu(g(pred.reshape(1, -1), dev), g(gt.reshape(1, -1), dev))[0].cpu().numpy()
+        out = ev.compute_errors_nyu(g(pred, dev), g(gt, dev)).cpu().numpy()          # reference semantics: one global reduction
+        rows = ev.compute_errors_nyu(g(pred, dev), g(gt, dev), per_image=True)
+        assert rows.shape == (pred.shape[0], 6)
+        np.testing.assert_allclose(rows[:, 0].mean().item(), out[0], rtol=1e-5)      # abs_rel is a plain mean: rows average to it
         np.testing.assert_allclose(out, gold["compute_errors_nyu_%d" % i], rtol=1e-5)
 
 

@@ -55,7 +55,9 @@ def test_idwt_vs_pywavelets_golden(dev):
 def test_dwt_vs_pywavelets_golden_and_roundtrip(dev):
     from wavelet_monodepth_amd import ops
     g = load_golden("pywt_haar.npz")
-    for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4)}.items():
+    # o1..o3: odd sizes (an odd axis gets one reflected sample: mode="reflect" of DWTForward / pywt.dwt2)
+    for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4), "o1": (7, 9, 1), "o2": (15, 22, 3),
+                            "o3": (30, 45, 4)}.items():
         x = t(synth.normal((h, w), "pywt_x_" + name, 12)).reshape(1, 1, h, w).to(dev)
         yl, yh = ops.dwt_haar(x, J)
         assert_close(yl[0, 0], g["dwt_%s_yl" % name], 2e-6, "yl")
@@ -66,6 +68,8 @@ def test_dwt_vs_pywavelets_golden_and_roundtrip(dev):
         rec = yl
         for j in reversed(range(J)):
             rec, _ = ops.idwt_haar(rec, yh[j])
+            fh, fw = (yh[j - 1].shape[-2:] if j else (h, w))      # crop the reflected sample of an odd level again
+            rec = rec[:, :, :fh, :fw].contiguous()
         assert_close(rec, x, 2e-6, "idwt(dwt(x))")
 
 

@@ -298,17 +298,24 @@ def test_nyu_model_picks_encoder_and_decoder_like_the_reference():
         assert depthwise(m.decoder) == dw, kw
         assert list(m.encoder.num_ch_enc) == [64, 64, 128, 256, 512]
     assert list(nyu.Model(opts(num_layers=50)).encoder.num_ch_enc) == [64, 256, 512, 1024, 2048]
-    # a namespace that predates --use_sparse (model.py:44-46) means dense, and gets the attribute
+    # a namespace that predates --use_sparse (model.py:44-46) means dense; the caller's namespace is only read
     o = opts()
     del o.use_sparse
     m = nyu.Model(o)
-    assert type(m.decoder) is nyu.DecoderWave and o.use_sparse is False
+    assert type(m.decoder) is nyu.DecoderWave and m.use_sparse is False and not hasattr(o, "use_sparse")
     with pytest.raises(NotImplementedError):
         nyu.Model(opts(use_sparse=True, use_224=True))                     # model.py:41-42
     with pytest.raises(NotImplementedError):
-        nyu.Model(opts(encoder_type="densenet"))                           # torchvision encoders are passed in instead
-    with pytest.raises(NotImplementedError):
         nyu.Model(opts(encoder_type="vgg"))
+    # config 5: DenseNet161 (densenet_encoder.py:13-33) and the two MobileNetV2 flavours (model.py:25-30)
+    from wavelet_monodepth_amd import encoders
+    m = nyu.Model(opts(encoder_type="densenet"))
+    assert type(m.encoder) is encoders.DenseEncoder and list(m.encoder.num_ch_enc) == [96, 96, 192, 384, 2208]
+    assert m.decoder.conv2.conv.weight.shape == (1104, 2208, 3, 3)
+    assert sum(p.numel() for p in m.encoder.parameters()) == 28681000      # torchvision densenet161
+    for kind, last in (("mobilenet", 1280), ("mobilenet_light", 160)):
+        m = nyu.Model(opts(encoder_type=kind))
+        assert list(m.encoder.num_ch_enc) == [32, 24, 32, 64, last]
 
     class Enc(torch.nn.Module):                                             # what the reference's DenseEncoder exposes
         num_ch_enc = [96, 96, 192, 384, 2208]
@@ -368,8 +375,11 @@ def test_kitti_factories_follow_the_reference_signatures():
     opts.use_wavelets = False
     base = kitti.make_depth_decoder(enc, opts)
     assert type(base) is kitti.DepthDecoder and list(base.scales) == [0, 1, 2, 3]
+    mob = kitti.make_depth_encoder(NS(encoder_type="mobilenet", num_layers=18, weights_init="scratch"))
+    assert list(mob.num_ch_enc) == [32, 24, 32, 64, 1280]                  # mobilenetv2_encoder.py:142
+    assert list(kitti.make_depth_encoder(NS(encoder_type="mobilenet_light", num_layers=18, weights_init="scratch")).num_ch_enc)[-1] == 160
     with pytest.raises(NotImplementedError):
-        kitti.make_depth_encoder(NS(encoder_type="mobilenet", num_layers=18, weights_init="scratch"))
+        kitti.make_depth_encoder(NS(encoder_type="vgg", num_layers=18, weights_init="scratch"))
     with pytest.raises(RuntimeError):                     # "pretrained" needs a download: refused loudly
         kitti.make_depth_encoder(NS(encoder_type="resnet", num_layers=18, weights_init="pretrained"))
     # explicit form used by tools/test_simple.py

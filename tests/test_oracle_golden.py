@@ -43,7 +43,9 @@ def test_haar_idwt_vs_pywavelets():
 
 def test_haar_dwt_vs_pywavelets():
     g = load_golden("pywt_haar.npz")
-    for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4)}.items():
+    # o1..o3: odd sizes (an odd axis gets one reflected sample: mode="reflect" of DWTForward / pywt.dwt2)
+    for name, (h, w, J) in {"a": (8, 12, 1), "b": (48, 160, 4), "c": (240, 320, 4), "o1": (7, 9, 1), "o2": (15, 22, 3),
+                            "o3": (30, 45, 4)}.items():
         x = t(synth.normal((h, w), "pywt_x_" + name, 12)).reshape(1, 1, h, w)
         yl, yh = R.haar_dwt(x, J)
         assert_close(yl[0, 0], g["dwt_%s_yl" % name], 2e-6, "yl")
@@ -130,6 +132,27 @@ def test_kitti_sparse_decoder_96x160(thr):
     check_outputs(out, gold)
     dens = [float(gold["wavelet_mask|%d" % s].mean()) for s in range(3)]
     assert 0.01 < min(dens) and max(dens) < 0.98, "fixture should exercise a non-trivial mask: %s" % dens
+
+
+@pytest.mark.parametrize("thr", [0.01, 0.05, 0.1])
+def test_kitti_sparse_decoder_config4_full_size(thr):
+    """BASELINE config 4 at its real size (R18 640x192) against the reference's outputs for the threshold sweep: sampled
+    maps, every mask bit, the integer op model."""
+    from util import check_packed
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    with torch.no_grad():
+        out = R.kitti_sparse_decoder(kitti_feats(1, 192, 640, seed=1), sd, thr)
+    check_packed(out, load_golden("kitti_sparse_r18_640x192_thr%g.npz" % thr), 5e-6)
+
+
+@pytest.mark.parametrize("scales", [[0, 1], [1, 2], [0]])
+def test_kitti_sparse_decoder_non_default_sparse_scales(scales):
+    """depth_decoder.py:292,331: levels outside `sparse_scales` run densely inside the sparse decoder (the reference only
+    survives lists whose sparse levels are the finest ones; these are the fixtures it could produce)."""
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    with torch.no_grad():
+        out = R.kitti_sparse_decoder(kitti_feats(1, 96, 160, seed=2), sd, 0.15, scales)
+    check_outputs(out, load_golden("kitti_sparse_r18_96x160_thr0.15_scales%s.npz" % "".join(map(str, scales))))
 
 
 def test_sparse_equals_dense_at_negative_threshold():

@@ -103,3 +103,28 @@ def loss_case(B=2, H=32, W=64, seed=17, hints=False):
         inputs["depth_hint"] = synth.uniform((B, 1, H, W), "lc_hint", seed, 1.0, 40.0).astype(np.float32)
         inputs["depth_hint_mask"] = (synth.uniform((B, 1, H, W), "lc_hmask", seed, 0.0, 1.0) > 0.3).astype(np.float32)
     return inputs, outputs
+
+
+def check_packed(out, gold, tol, exact=True, limit=4096):
+    """Compare a decoder output dict with a PACKED full-size fixture (tests/golden/make_golden.py::pack_outputs): float
+    maps as strided samples ("s|key"), boolean masks bit-packed ("m|key" + "mshape|key"), integers ("i|key")."""
+    want = {k.split("|", 1)[1] for k in gold if k[:2] in ("s|", "m|", "i|")}
+    have = {key_str(k) for k in out}
+    assert want == have, want ^ have
+    for k, v in out.items():
+        ks = key_str(k)
+        if torch.is_tensor(v) and v.dtype.is_floating_point:
+            assert_close(sample(v.detach().cpu().numpy(), limit), gold["s|" + ks], tol, ks)
+        elif torch.is_tensor(v):
+            shape = tuple(int(n) for n in gold["mshape|" + ks])
+            ref = np.unpackbits(gold["m|" + ks])[:int(np.prod(shape))].reshape(shape)
+            assert tuple(v.shape) == shape, ks
+            if exact:
+                assert np.array_equal(v.cpu().numpy().astype(np.uint8), ref), ks
+        elif exact:
+            assert int(v) == int(gold["i|" + ks]), "%s: %d vs %d" % (ks, int(v), int(gold["i|" + ks]))
+
+
+def unpack_mask(gold, key):
+    shape = tuple(int(n) for n in gold["mshape|" + key])
+    return np.unpackbits(gold["m|" + key])[:int(np.prod(shape))].reshape(shape)

@@ -118,6 +118,7 @@ SIGNATURES = {
     "wmd_idwt_haar_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]),
     "wmd_idwt_haar_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]),
     "wmd_dwt_haar_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "wmd_dwt_haar_reflect_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "wmd_conv_packed_weight_floats": (C.c_size_t, [C.c_int] * 3),
     "wmd_conv_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wmd_conv_pack_weights_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -166,6 +167,7 @@ SIGNATURES = {
     "wmd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wmd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "wmd_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),
+    "wmd_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "wmd_comm_destroy": (C.c_int, [C.c_void_p]),
 }
 

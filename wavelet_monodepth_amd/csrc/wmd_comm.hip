@@ -62,6 +62,15 @@ extern "C" int wmd_comm_allreduce(wmd_comm* comm, float* buf, size_t n, float sc
     return WMD_OK;
 }
 
+extern "C" int wmd_comm_broadcast(wmd_comm* comm, float* buf, size_t n, int root, void* stream) {
+    if (!comm || !buf) return fail(WMD_ERR_BAD_ARG, "wmd_comm_broadcast: null pointer");
+    if (root < 0 || root >= comm->world) return fail(WMD_ERR_BAD_ARG, "wmd_comm_broadcast: root=%d world=%d", root, comm->world);
+    if (n == 0) return WMD_OK;
+    ncclResult_t r = ncclBroadcast(buf, buf, n, ncclFloat, root, comm->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return nccl_fail("ncclBroadcast", r);
+    return WMD_OK;
+}
+
 extern "C" int wmd_comm_destroy(wmd_comm* comm) {
     if (!comm) return WMD_OK;
     ncclResult_t r = ncclCommDestroy(comm->comm);

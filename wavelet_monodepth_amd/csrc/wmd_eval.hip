@@ -359,9 +359,21 @@ extern "C" int wmd_eval_errors(const float* pred, const float* gt, int B, size_t
     if (!pred || !gt || !out9) return fail(WMD_ERR_BAD_ARG, "wmd_eval_errors: null pointer");
     if (B <= 0 || n_per_image == 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_eval_errors: B=%d n=%zu", B, n_per_image);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof("eval_metrics_kernel", 30.0 * B * n_per_image, 8.0 * B * n_per_image, s);
-    hipLaunchKernelGGL(eval_metrics_kernel, dim3(1, B), dim3(1024), 0, s, pred, gt, (const float*)nullptr, out9, (double*)nullptr, n_per_image, 0, 0.f, 0.f, 0);
-    return check_launch("eval_metrics_kernel");
+    // up to 64 blocks per item + the deterministic finish (one block over the ~1.6e8 elements of a flattened NYUv2 test
+    // set would be one CU's worth of bandwidth); the fp64 partials live in a stream-ordered allocation
+    const int mblk = (int)std::max<size_t>(1, std::min<size_t>((n_per_image + 8191) / 8192, 64));
+    double* partial = nullptr;
+    if (mblk > 1 && hipMallocAsync((void**)&partial, sizeof(double) * 9 * (size_t)B * mblk, s) != hipSuccess)
+        return fail(WMD_ERR_HIP, "wmd_eval_errors: hipMallocAsync failed");
+    int st;
+    {
+        ProfScope prof("eval_metrics_kernel", 30.0 * B * n_per_image, 8.0 * B * n_per_image, s);
+        hipLaunchKernelGGL(eval_metrics_kernel, dim3(mblk, B), dim3(1024), 0, s, pred, gt, (const float*)nullptr, out9, partial, n_per_image, 0, 0.f, 0.f, 0);
+        if (mblk > 1) hipLaunchKernelGGL(eval_metrics_finish_kernel, dim3(B), dim3(64), 0, s, partial, out9, B, mblk);
+        st = check_launch("eval_metrics_kernel");
+    }
+    if (partial && hipFreeAsync(partial, s) != hipSuccess && !st) return fail(WMD_ERR_HIP, "wmd_eval_errors: hipFreeAsync failed");
+    return st;
 }
 
 extern "C" int wmd_flip_postprocess(const float* l_disp, const float* r_disp, float* out, int B, int h, int w, void* stream) {

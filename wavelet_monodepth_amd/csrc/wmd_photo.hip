@@ -228,17 +228,12 @@ __device__ __forceinline__ void warp_P(const float* __restrict__ K, const float*
 }
 
 __device__ __forceinline__ float clip_coord(float in, int size, float* mult) {   // ATen clip_coordinates_set_grad
-    if (in <= 0.f) {
-        *mult = 0.f;
-        return 0.f;
-    }
+    // written so that a NaN coordinate (depth 0 x inf, a degenerate pose) lands on 0 with zero gradient instead of
+    // slipping through both comparisons and being cast to an int: ATen never indexes with a NaN either
     const float mx = (float)(size - 1);
-    if (in >= mx) {
-        *mult = 0.f;
-        return mx;
-    }
-    *mult = 1.f;
-    return in;
+    const bool inside = in > 0.f && in < mx;          // false for NaN
+    *mult = inside ? 1.f : 0.f;
+    return inside ? in : (in >= mx ? mx : 0.f);       // NaN -> 0
 }
 
 __device__ __forceinline__ WarpGeom warp_geom(float depth, int x, int y, const float* __restrict__ iK, const float* P, int H, int W,

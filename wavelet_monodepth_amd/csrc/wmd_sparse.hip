@@ -540,6 +540,10 @@ extern "C" int wmd_sparse_conv(const wmd_sparse_conv_args* g, void* stream) {
         return fail(WMD_ERR_BAD_SHAPE, "wmd_sparse_conv: H=%d W=%d C1=%d C2=%d Cout=%d", g->H, g->W, g->C1, g->C2, g->Cout);
     if (g->ksize != 1 && g->ksize != 3) return fail(WMD_ERR_UNSUPPORTED, "wmd_sparse_conv: ksize=%d", g->ksize);
     if (g->up1 != 1 && g->up1 != 2) return fail(WMD_ERR_BAD_ARG, "wmd_sparse_conv: up1=%d", g->up1);
+    if (g->up1 == 2 && ((g->H | g->W) & 1))
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_sparse_conv: a 2x-upsampled source needs even H, W (got %dx%d)", g->H, g->W);
+    if (g->ksize == 3 && g->pad_mode == WMD_PAD_REFLECT && (g->H < 2 || g->W < 2))
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_sparse_conv: reflection padding needs H, W >= 2 (got %dx%d)", g->H, g->W);
     if (g->c1_off < 0 || g->c1_off + g->C1 > g->C1tot) return fail(WMD_ERR_BAD_ARG, "wmd_sparse_conv: channel slice");
     if (g->wp2 && (g->Cout > 16 || g->c1_off2 < 0 || g->c1_off2 + g->C1 > g->C1tot || g->C2 != 0))
         return fail(WMD_ERR_BAD_ARG, "wmd_sparse_conv: dual-head mode needs Cout <= 16, C2 == 0 and a valid slice");

@@ -196,6 +196,43 @@ extern "C" int wmd_dwt_haar_fwd(const float* x, float* yl, float* yh, int N, int
     return check_launch("haar_analysis_kernel");
 }
 
+// DWT(J, "haar", mode="reflect") on ANY size: pytorch_wavelets pads an odd axis by one reflected sample on the right / bottom
+// (afb1d: p = 2*(ceil(N/2) - 1) - N + 2 = 1 -> F.pad(x, (0, 1), "reflect"), i.e. x[N] = x[N-2]) before the stride-2 filter
+// pair.  Folded into the load indices here.
+__global__ void haar_analysis_reflect_kernel(const float* __restrict__ x, float* __restrict__ yl, float* __restrict__ yh,
+                                             int N, int H, int W, int h, int w) {
+    const size_t total = (size_t)N * h * w;
+    const size_t plane = (size_t)h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = i % w;
+        const size_t r = i / w;
+        const int y = r % h;
+        const size_t n = r / h;
+        const int y0 = 2 * y, x0 = 2 * xx;
+        const int y1 = y0 + 1 < H ? y0 + 1 : H - 2, x1 = x0 + 1 < W ? x0 + 1 : W - 2;
+        const float* p = x + n * (size_t)H * W;
+        const float a = p[(size_t)y0 * W + x0], b = p[(size_t)y0 * W + x1], c = p[(size_t)y1 * W + x0], d = p[(size_t)y1 * W + x1];
+        yl[i] = (a + b + c + d) * 0.5f;
+        float* hb = yh + n * 3 * plane + (size_t)y * w + xx;
+        hb[0] = (a + b - c - d) * 0.5f;
+        hb[plane] = (a - b + c - d) * 0.5f;
+        hb[2 * plane] = (a - b - c + d) * 0.5f;
+    }
+}
+
+extern "C" int wmd_dwt_haar_reflect_fwd(const float* x, float* yl, float* yh, int N, int H, int W, void* stream) {
+    if (!x || !yl || !yh) return fail(WMD_ERR_BAD_ARG, "wmd_dwt_haar_reflect_fwd: null pointer");
+    if (N < 0 || H <= 0 || W <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_dwt_haar_reflect_fwd: N=%d H=%d W=%d", N, H, W);
+    if (((H & 1) && H < 2) || ((W & 1) && W < 2))
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_dwt_haar_reflect_fwd: reflection padding of an odd axis needs >= 2 samples (%dx%d)", H, W);
+    if (N == 0) return WMD_OK;
+    const int h = (H + 1) / 2, w = (W + 1) / 2;
+    const size_t work = (size_t)N * h * w;
+    ProfScope prof("haar_analysis_reflect_kernel", 16.0 * work, 32.0 * work, (hipStream_t)stream);
+    hipLaunchKernelGGL(haar_analysis_reflect_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, x, yl, yh, N, H, W, h, w);
+    return check_launch("haar_analysis_reflect_kernel");
+}
+
 extern "C" int wmd_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, float slope, void* stream) {
     if (!dy || !y || !dz) return fail(WMD_ERR_BAD_ARG, "wmd_act_bwd: null pointer");
     if (act < 0 || act > 3) return fail(WMD_ERR_BAD_ARG, "wmd_act_bwd: act=%d", act);

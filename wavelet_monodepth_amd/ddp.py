@@ -3,24 +3,33 @@
 The reference is single-GPU (KITTI/trainer.py:45).  Here: one process per GPU, the minibatch is sharded across
 ranks, and ONE exchange step per iteration sums the gradients:
 
-  * parameters are grouped into flat fp32 buckets in REVERSE forward order — the decoder first (its gradients
-    are complete before the encoder backward has started), then encoder stages layer4 .. conv1;
+  * parameters are grouped into flat fp32 buckets of ~25 MB in REVERSE forward order — the decoder first (its
+    gradients are complete before the encoder backward has started), then the encoder's parameters from its last
+    registered module back to its stem, whatever the encoder is (ResNet stages, 160 DenseNet layers, MobileNet blocks);
   * every parameter's `.grad` is a view into its bucket, so autograd accumulates straight into the flat buffer
     (no gather copy);
   * a post-accumulate hook counts a bucket down; when it is full the bucket is all-reduced (sum, then 1/world)
     on a SIDE stream after an event recorded on the compute stream — the collective overlaps the rest of the
-    backward pass;
+    backward pass (xGMI rings are per-link bound: a handful of 25 MB messages keeps every link busy without
+    paying the per-collective latency 160 times);
   * `finish()` launches whatever is left (buckets holding unused parameters such as `encoder.fc`, whose
-    gradient stays zero) and makes the compute stream wait for the side stream before `optimizer.step()`.
+    gradient stays zero), makes the compute stream wait for the side stream before `optimizer.step()`, and re-arms
+    every bucket for the next step — whatever the caller does with `zero_grad` afterwards;
+  * construction broadcasts parameters and floating-point buffers (BatchNorm running statistics) from rank 0, so
+    the replicas start identical like under torch's DistributedDataParallel; `sync_buffers()` repeats the buffer
+    broadcast on demand (e.g. before evaluation / checkpointing).
 
-Backends: "rccl" = wmd_comm_* (libwmd_hip.so -> RCCL over xGMI); "torch" = torch.distributed.all_reduce on
+Backends: "rccl" = wmd_comm_* (libwmd_hip.so -> RCCL over xGMI); "torch" = torch.distributed collectives on
 whatever process group is initialised (gloo on CPU: used by the multi-process CPU tests).
 """
+import contextlib
 import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
+
+BUCKET_BYTES = 25 << 20
 
 
 class _RcclBackend:
@@ -35,14 +44,23 @@ class _RcclBackend:
         raw = store.get("wmd_comm_uid")
         self.comm = C.c_void_p()
         _lib.check(l.wmd_comm_init(C.byref(self.comm), raw, world, rank), "wmd_comm_init")
+        self.world = world
         self.side = torch.cuda.Stream()
 
-    def allreduce(self, buf, scale):
+    def _fork(self):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
+
+    def allreduce(self, buf, scale):
+        self._fork()
         self._lib.check(self._lib.lib().wmd_comm_allreduce(self.comm, buf.data_ptr(), buf.numel(), float(scale),
                                                            self.side.cuda_stream), "wmd_comm_allreduce")
+
+    def broadcast(self, buf, root=0):
+        self._fork()
+        self._lib.check(self._lib.lib().wmd_comm_broadcast(self.comm, buf.data_ptr(), buf.numel(), root,
+                                                           self.side.cuda_stream), "wmd_comm_broadcast")
 
     def wait(self):
         torch.cuda.current_stream().wait_stream(self.side)
@@ -62,6 +80,9 @@ class _TorchBackend:
         w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.work.append((w, buf, scale))
 
+    def broadcast(self, buf, root=0):
+        dist.broadcast(buf, src=root, group=self.group)
+
     def wait(self):
         for w, buf, scale in self.work:
             w.wait()
@@ -73,11 +94,32 @@ class _TorchBackend:
         pass
 
 
+class _NullBackend:
+    """world == 1 without a process group: nothing to exchange."""
+
+    def allreduce(self, buf, scale):
+        if scale != 1.0:
+            buf.mul_(scale)
+
+    def broadcast(self, buf, root=0):
+        pass
+
+    def wait(self):
+        pass
+
+    def close(self):
+        pass
+
+
 class GradientExchange:
     """groups: list of (name, iterable of parameters) in the order their gradients become ready
-    (decoder first).  Call `finish()` between `loss.backward()` and `optimizer.step()`."""
+    (decoder first; `bucket_groups` builds it).  Call `finish()` between `loss.backward()` and `optimizer.step()`.
 
-    def __init__(self, groups, world=None, rank=None, backend="torch", store=None, process_group=None):
+    modules: the nn.Modules whose parameters AND buffers rank 0 broadcasts at construction (default: only the
+    parameters of `groups` are broadcast)."""
+
+    def __init__(self, groups, world=None, rank=None, backend="torch", store=None, process_group=None, modules=(),
+                 broadcast_from_rank0=True):
         self.world = dist.get_world_size() if world is None else world
         self.rank = dist.get_rank() if rank is None else rank
         self.buckets = []
@@ -91,46 +133,115 @@ class GradientExchange:
             for p in params:
                 p.grad = flat[off:off + p.numel()].view_as(p)   # autograd accumulates in place into the bucket
                 off += p.numel()
-            self.buckets.append({"name": name, "params": params, "flat": flat, "pending": len(params), "sent": False})
+            # arm = how many gradient arrivals complete the bucket; learned down on the first step for buckets that hold
+            # parameters the loss never reaches (resnet.fc, densenet.norm5/classifier): see finish()
+            self.buckets.append({"name": name, "params": params, "flat": flat, "arm": len(params), "count": 0, "sent": False})
         if backend == "rccl":
             if store is None:
                 store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17,
                                       self.world, self.rank == 0)
             self.backend = _RcclBackend(self.world, self.rank, store)
+        elif self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            self.backend = _NullBackend()
         else:
             self.backend = _TorchBackend(process_group)
+        self.enabled = True        # False: the all-reduces are skipped (local gradients; used to time the exposed cost)
+        self._accumulating = False
+        self._modules = list(modules)
         self._hooks = []
         for b in self.buckets:
             for p in b["params"]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+        if broadcast_from_rank0 and self.world > 1:
+            self.sync_parameters()
+            self.sync_buffers()
 
+    # -- replica synchronisation -----------------------------------------------------------------
+    def _broadcast_tensors(self, tensors):
+        """Rank 0's values of `tensors` to every rank, packed into flat messages of <= BUCKET_BYTES."""
+        tensors = [t for t in tensors if t.numel() and t.dtype == torch.float32]
+        i = 0
+        while i < len(tensors):
+            chunk, size = [], 0
+            while i < len(tensors) and (not chunk or size + 4 * tensors[i].numel() <= BUCKET_BYTES):
+                chunk.append(tensors[i])
+                size += 4 * tensors[i].numel()
+                i += 1
+            flat = torch.cat([t.detach().reshape(-1) for t in chunk])
+            self.backend.broadcast(flat, 0)
+            self.backend.wait()
+            off = 0
+            with torch.no_grad():
+                for t in chunk:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+
+    def sync_parameters(self):
+        seen, ps = set(), []
+        for b in self.buckets:
+            ps += b["params"]
+        for m in self._modules:
+            ps += list(m.parameters())
+        uniq = [p for p in ps if not (id(p) in seen or seen.add(id(p)))]
+        self._broadcast_tensors(uniq)
+
+    def sync_buffers(self):
+        """BatchNorm running statistics (every fp32 buffer of `modules`) from rank 0."""
+        bufs = [b for m in self._modules for b in m.buffers()]
+        if bufs:
+            self._broadcast_tensors(bufs)
+
+    # -- per-step protocol -----------------------------------------------------------------------
     def _make_hook(self, bucket):
         def hook(_param):
-            bucket["pending"] -= 1
-            if bucket["pending"] == 0 and not bucket["sent"]:
+            if self._accumulating:
+                return
+            if bucket["sent"]:
+                raise RuntimeError("gradient bucket %s received a gradient after it was all-reduced: call finish() once per "
+                                   "backward pass, or wrap extra backward passes in no_sync()" % bucket["name"])
+            bucket["count"] += 1
+            if bucket["count"] == bucket["arm"]:
                 self._send(bucket)
         return hook
 
     def _send(self, bucket):
         bucket["sent"] = True
-        self.backend.allreduce(bucket["flat"], 1.0 / self.world)
+        if self.enabled:
+            self.backend.allreduce(bucket["flat"], 1.0 / self.world)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only accumulate into the buckets."""
+        self._accumulating = True
+        try:
+            yield
+        finally:
+            self._accumulating = False
 
     def zero_grad(self):
-        """Keep the bucket views alive: zero the flat buffers instead of dropping `.grad`."""
+        """Keep the bucket views alive: zero the flat buffers instead of dropping `.grad`.  (The optimizer's own
+        `zero_grad(set_to_none=False)` is equivalent; `set_to_none=True` would detach the views and is refused here.)"""
         for b in self.buckets:
             b["flat"].zero_()
-            b["pending"] = len(b["params"])
-            b["sent"] = False
+            lo, hi = b["flat"].data_ptr(), b["flat"].data_ptr() + 4 * b["flat"].numel()
             for p in b["params"]:
-                lo = b["flat"].data_ptr()
-                if p.grad is None or not (lo <= p.grad.data_ptr() < lo + 4 * b["flat"].numel()):
-                    raise RuntimeError("parameter gradient of bucket %s was re-allocated; use GradientExchange.zero_grad()" % b["name"])
+                if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                    raise RuntimeError("parameter gradient of bucket %s was re-allocated; use GradientExchange.zero_grad() "
+                                       "or optimizer.zero_grad(set_to_none=False)" % b["name"])
 
     def finish(self):
         for b in self.buckets:
-            if not b["sent"]:       # buckets with parameters that received no gradient this step
+            if not b["sent"]:
+                # some parameters of this bucket received no gradient (their slice stays zero): send it now, and from the
+                # next step on do not wait for them -- the bucket then leaves as soon as its used parameters are in
+                # (the static-graph assumption of torch DDP; a parameter that turns up later raises in the hook)
+                if 0 < b["count"] < b["arm"]:
+                    b["arm"] = b["count"]
                 self._send(b)
         self.backend.wait()
+        for b in self.buckets:      # re-arm: the next backward starts from a clean count whatever zero_grad the caller uses
+            b["count"] = 0
+            b["sent"] = False
 
     def message_bytes(self):
         return {b["name"]: 4 * b["flat"].numel() for b in self.buckets}
@@ -141,16 +252,36 @@ class GradientExchange:
         self.backend.close()
 
 
-def monodepth_groups(encoder, decoder):
-    """Bucket order for an encoder/decoder depth network: decoder, then ResNet stages in backward order."""
-    groups = [("decoder", list(decoder.parameters()))]
-    enc = getattr(encoder, "encoder", encoder)
+def _chunks(name, params, bucket_bytes):
+    """Split an ordered parameter list into consecutive buckets of <= bucket_bytes (a single larger tensor gets its own)."""
+    out, cur, size = [], [], 0
+    for p in params:
+        nb = 4 * p.numel()
+        if cur and size + nb > bucket_bytes:
+            out.append(cur)
+            cur, size = [], 0
+        cur.append(p)
+        size += nb
+    if cur:
+        out.append(cur)
+    return [(name if k == 0 else "%s.%d" % (name, k), ps) for k, ps in enumerate(out)]
+
+
+def bucket_groups(encoder, decoder, bucket_bytes=BUCKET_BYTES):
+    """Bucket order for an encoder/decoder depth network: the decoder's parameters (reverse registration order = the
+    order its backward produces them: heads and fine levels first), then the encoder's in reverse registration order —
+    torch registers modules in forward order, so this is the order the encoder backward completes them for ResNet,
+    DenseNet and MobileNet alike — cut into ~bucket_bytes messages."""
     seen = set()
-    for stage in ("layer4", "layer3", "layer2", "layer1"):
-        if hasattr(enc, stage):
-            ps = list(getattr(enc, stage).parameters())
-            seen.update(id(p) for p in ps)
-            groups.append(("encoder." + stage, ps))
-    rest = [p for p in encoder.parameters() if id(p) not in seen]
-    groups.append(("encoder.stem", rest))
+
+    def fresh(ps):
+        out = [p for p in ps if id(p) not in seen]
+        seen.update(id(p) for p in out)
+        return out
+
+    groups = _chunks("decoder", fresh(reversed(list(decoder.parameters()))), bucket_bytes)
+    groups += _chunks("encoder", fresh(reversed(list(encoder.parameters()))), bucket_bytes)
     return groups
+
+
+monodepth_groups = bucket_groups   # round-1 name

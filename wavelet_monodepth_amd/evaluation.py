@@ -69,14 +69,21 @@ def _errors9(pred, gt):
 
 
 def compute_errors(gt, pred):
-    """KITTI compute_errors per leading-dimension item: [B,7] (argument order of the reference: gt first)."""
+    """KITTI compute_errors per leading-dimension item: [B,7] (argument order of the reference: gt first).  The reference
+    calls it once per image and averages the rows afterwards (evaluate_depth.py:305-313), which is what the rows are for."""
     return _errors9(pred, gt)[:, :7]
 
 
-def compute_errors_nyu(pred, gt):
-    """NYUv2 compute_errors_nyu per leading-dimension item: [B,6] = abs_rel, rmse, log_10, a1, a2, a3."""
-    o = _errors9(pred, gt)
-    return torch.stack([o[:, 0], o[:, 2], o[:, 7], o[:, 4], o[:, 5], o[:, 6]], 1)
+def compute_errors_nyu(pred, gt, per_image=False):
+    """NYUv2/utils.py:85-98: (abs_rel, rmse, log_10, a1, a2, a3) as a [6] tensor — ONE reduction over every element of the
+    arrays handed in, as the reference computes them over its whole concatenated test set (rmse = sqrt of the GLOBAL mean
+    squared error: averaging per-image rmse values afterwards gives a different, non-comparable number).
+    per_image=True: one row per leading-dimension item, [B,6], for per-frame diagnostics."""
+    if per_image:
+        o = _errors9(pred, gt)
+        return torch.stack([o[:, 0], o[:, 2], o[:, 7], o[:, 4], o[:, 5], o[:, 6]], 1)
+    o = _errors9(pred.reshape(1, -1), gt.reshape(1, -1))[0]
+    return torch.stack([o[0], o[2], o[7], o[4], o[5], o[6]])
 
 
 def flip_postprocess(l_disp, r_disp_raw):

@@ -5,6 +5,8 @@ kernel on the live input buffers — nothing is cached but the launch sequence. 
 graph support only as the owner of the capture stream and of the private memory pool."""
 import torch
 
+from . import ops as _ops
+
 
 class GraphCache:
     def __init__(self, max_entries=8):
@@ -16,7 +18,7 @@ class GraphCache:
 
     def run(self, fn, inputs, params, extra_key=()):
         key = tuple((t.data_ptr(), tuple(t.shape)) for t in inputs) + tuple((p.data_ptr(), p._version) for p in params) \
-            + tuple(extra_key)
+            + tuple(extra_key) + (_ops.pack_generation(),)
         ent = self._entries.get(key)
         if ent is None:
             if len(self._entries) >= self._max:

@@ -129,7 +129,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
     # stream share a memory pool (they replay in capture order); the two streams use different pools, so a buffer freed
     # during one capture can never be handed to a segment that runs concurrently; tensors that cross streams stay alive.
     def _forward_two_streams(self, input_features):
-        key = tuple((t.data_ptr(), tuple(t.shape)) for t in input_features) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = tuple((t.data_ptr(), tuple(t.shape)) for t in input_features) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + (ops.pack_generation(),)
         ent = self._segments.get(key)
         if ent is None:
             if len(self._segments) >= 4:

@@ -1,7 +1,6 @@
 """Factories with the reference's names, signatures and selection logic
 (/root/reference/KITTI/networks/network_constructors.py): `make_depth_decoder(encoder, opts)` (:30-40) and
-`make_depth_encoder(opts)` (:12-27, ResNet only: the MobileNet encoders come from torchvision, which is not part of this
-package).  The pose factory of that file is out of scope.  Nothing is printed.
+`make_depth_encoder(opts)` (:12-27; the encoders are the plain torch.nn ones of `wavelet_monodepth_amd.encoders`).  The pose factory of that file is out of scope.  Nothing is printed.
 
 `make_depth_decoder` also accepts the explicit form `make_depth_decoder(num_ch_enc, scales, use_wavelets=..., use_sparse=...)`
 for callers that have no option namespace.
@@ -10,13 +9,13 @@ from .depth_decoder import DepthDecoder, DepthWaveProgressiveDecoder
 
 
 def make_depth_encoder(opts):
-    from ..encoders import ResnetEncoder
+    from ..encoders import MobileNetV2Encoder, ResnetEncoder
     if opts.encoder_type == "resnet":
         # weights_init == "pretrained" downloads ImageNet weights in the reference; there is no network here, so the
         # encoder refuses `pretrained=True` with a clear message and checkpoints are loaded explicitly instead
         return ResnetEncoder(opts.num_layers, pretrained=(opts.weights_init == "pretrained"))
     if opts.encoder_type in ("mobilenet", "mobilenet_light"):
-        raise NotImplementedError("the MobileNetV2 encoders come from torchvision, which is not part of this package")
+        return MobileNetV2Encoder(pretrained=(opts.weights_init == "pretrained"), use_last_layer=(opts.encoder_type == "mobilenet"))
     raise NotImplementedError
 
 

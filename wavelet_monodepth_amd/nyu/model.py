@@ -3,16 +3,16 @@ the option namespace, `forward(x, threshold=-1)` hands the threshold to the spar
 
 The decoders are this package's HIP-backed classes.  The encoder stays ordinary PyTorch (BASELINE.json north_star): the
 reference takes DenseNet / ResNet / MobileNetV2 from torchvision, which this image does not have, so
-  * `encoder_type == "resnet"` builds the plain-torch ResNet of `wavelet_monodepth_amd.encoders` (torchvision-compatible
-    state_dict names, five feature maps, `num_ch_enc` as resnet_encoder.py:66-91), and
-  * any other encoder is passed in ready-made (`Model(opts, encoder=DenseEncoder(...))`): a module whose forward returns
-    the five feature maps and that exposes `num_ch_enc` — exactly what the reference's encoder classes provide.
-Nothing is printed (the reference prints "Building model using ... encoder").
+`wavelet_monodepth_amd.encoders` defines them in plain torch.nn with torchvision-compatible state_dict names
+(`densenet` = DenseNet161 -> num_ch_enc [96, 96, 192, 384, 2208]; `mobilenet` / `mobilenet_light` = MobileNetV2 with / without
+the 1280-channel last layer).  A ready-made encoder can also be handed in (`Model(opts, encoder=...)`): any module whose
+forward returns the five feature maps and that exposes `num_ch_enc`.
+Nothing is printed (the reference prints "Building model using ... encoder"), and the option namespace is only read.
 """
 import numpy as np
 import torch.nn as nn
 
-from ..encoders import _ResNet, _SPECS
+from ..encoders import DenseEncoder, MobileNetV2Encoder, _ResNet, _SPECS
 from .densedepth_decoder import Decoder, Decoder224, DecoderWave, DecoderWave224, SparseDecoderWave
 
 
@@ -44,45 +44,52 @@ class NyuResnetEncoder(nn.Module):
         return [f0, f1, f2, f3, f4]
 
 
+def _build_encoder(opts):
+    kind = opts.encoder_type
+    if kind == "resnet":
+        return NyuResnetEncoder(num_layers=opts.num_layers, pretrained=opts.pretrained_encoder,
+                                normalize_input=opts.normalize_input)
+    if kind == "densenet":
+        return DenseEncoder(normalize_input=opts.normalize_input, pretrained=opts.pretrained_encoder)
+    if kind in ("mobilenet", "mobilenet_light"):
+        return MobileNetV2Encoder(pretrained=opts.pretrained_encoder, use_last_layer=(kind == "mobilenet"),
+                                  normalize_input=opts.normalize_input)
+    raise NotImplementedError("encoder_type %r" % (kind,))
+
+
+# (use_wavelets, use_224, use_sparse) -> decoder class; a missing row is a combination the reference refuses (model.py:41)
+_DECODERS = {
+    (False, False): Decoder,
+    (False, True): Decoder224,
+    (True, False, False): DecoderWave,
+    (True, True, False): DecoderWave224,
+    (True, False, True): SparseDecoderWave,
+}
+
+
 class Model(nn.Module):
+    DECODER_WIDTH = 0.5
+
     def __init__(self, opts, encoder=None):
         super().__init__()
-        decoder_width = 0.5
-        if encoder is not None:
-            self.encoder = encoder
-        elif opts.encoder_type == "resnet":
-            self.encoder = NyuResnetEncoder(num_layers=opts.num_layers, pretrained=opts.pretrained_encoder,
-                                            normalize_input=opts.normalize_input)
-        elif opts.encoder_type in ("densenet", "mobilenet", "mobilenet_light"):
-            raise NotImplementedError("the %s encoder comes from torchvision, which is not part of this package: build it "
-                                      "and pass it as Model(opts, encoder=...)" % opts.encoder_type)
+        self.encoder = _build_encoder(opts) if encoder is None else encoder
+        wave, w224 = bool(opts.use_wavelets), bool(opts.use_224)
+        depthwise = dict(dw_waveconv=opts.dw_waveconv, dw_upconv=opts.dw_upconv)
+        chans = self.encoder.num_ch_enc
+        if not wave:
+            # the sparse switch only exists for the wavelet decoders (model.py:36-47 never looks at it otherwise)
+            self.use_sparse = False
+            self.decoder = _DECODERS[(False, w224)](enc_features=chans, is_depthwise=any(depthwise.values()))
+            return
+        self.use_sparse = bool(getattr(opts, "use_sparse", False))    # namespaces written before the option existed: dense
+        cls = _DECODERS.get((True, w224, self.use_sparse))
+        if cls is None:
+            raise NotImplementedError("there is no sparse 224x224 wavelet decoder")
+        if self.use_sparse:
+            self.decoder = cls(enc_features=chans, decoder_width=self.DECODER_WIDTH)
         else:
-            raise NotImplementedError
-
-        self.use_sparse = False
-        if opts.use_wavelets:
-            # model.py:37-46: a namespace without `use_sparse` means dense; sparse + 224 is refused
-            try:
-                if opts.use_sparse:
-                    self.use_sparse = True
-                    if opts.use_224:
-                        raise NotImplementedError
-            except AttributeError:
-                opts.use_sparse = False
-                self.use_sparse = False
-            if opts.use_sparse:
-                self.decoder = SparseDecoderWave(enc_features=self.encoder.num_ch_enc, decoder_width=decoder_width)
-            else:
-                decoder_wave = DecoderWave224 if opts.use_224 else DecoderWave
-                self.decoder = decoder_wave(enc_features=self.encoder.num_ch_enc, decoder_width=decoder_width,
-                                            dw_waveconv=opts.dw_waveconv, dw_upconv=opts.dw_upconv)
-        else:
-            decoder = Decoder224 if opts.use_224 else Decoder
-            self.decoder = decoder(enc_features=self.encoder.num_ch_enc,
-                                   is_depthwise=(opts.dw_waveconv or opts.dw_upconv))
+            self.decoder = cls(enc_features=chans, decoder_width=self.DECODER_WIDTH, **depthwise)
 
     def forward(self, x, threshold=-1):
-        x = self.encoder(x)
-        if self.use_sparse:
-            return self.decoder(x, threshold)
-        return self.decoder(x)
+        feats = self.encoder(x)
+        return self.decoder(feats, threshold) if self.use_sparse else self.decoder(feats)

@@ -39,6 +39,21 @@ def _c(t):
 # ---------------------------------------------------------------------------------------------
 
 _PACK_CACHE = os.environ.get("WMD_PACK_CACHE", "1") != "0"
+_pack_generation = [0]
+
+
+def pack_generation():
+    return _pack_generation[0]
+
+
+def invalidate_packs():
+    """Forget every memoised packed-weight image and every captured hipGraph keyed on weights.
+
+    The memo tags are (autograd version counter, data_ptr): optimizer steps, `load_state_dict`, `copy_` & co. bump the
+    counter and are picked up automatically.  Writes that go through `.data` (`p.data.mul_()` for EMA, manual init) or
+    through raw pointers do NOT bump it — call this afterwards (or update the weights with version-bumping ops), otherwise
+    the forward keeps multiplying by the stale image."""
+    _pack_generation[0] += 1
 
 
 def pack_weights(weight, dgrad=False):
@@ -48,7 +63,7 @@ def pack_weights(weight, dgrad=False):
     pointer, so it is rebuilt whenever the weight is updated in place (optimizer step, load_state_dict) and
     reused while it is constant (inference).  WMD_PACK_CACHE=0 disables the memo."""
     l = _lib.lib()
-    tag = (weight._version, weight.data_ptr(), weight.device)
+    tag = (weight._version, weight.data_ptr(), weight.device, _pack_generation[0])
     slot = "_wmd_pack_d" if dgrad else "_wmd_pack_f"
     if _PACK_CACHE:
         hit = getattr(weight, slot, None)
@@ -76,7 +91,7 @@ def pack_weights_wino(weight, dgrad=False):
     if not _WINOGRAD or weight.shape[-1] != 3:
         return None
     l = _lib.lib()
-    tag = (weight._version, weight.data_ptr(), weight.device)
+    tag = (weight._version, weight.data_ptr(), weight.device, _pack_generation[0])
     slot = "_wmd_pack_wd" if dgrad else "_wmd_pack_wf"
     if _PACK_CACHE:
         hit = getattr(weight, slot, None)
@@ -376,7 +391,7 @@ def stacked_pack(weights, biases):
     couts = [w.shape[0] for w in weights]
     if any(c % 16 for c in couts[:-1]):
         raise _lib.WmdError("stacked heads need out-channel counts that are multiples of 16")
-    tag = tuple((w._version, w.data_ptr(), b._version, b.data_ptr()) for w, b in zip(weights, biases))
+    tag = tuple((w._version, w.data_ptr(), b._version, b.data_ptr()) for w, b in zip(weights, biases)) + (_pack_generation[0],)
     hit = getattr(weights[0], "_wmd_pack_stack", None) if _PACK_CACHE else None
     if hit is not None and hit[0] == tag:
         return hit[1], hit[2]
@@ -426,7 +441,7 @@ def head3x3_nograd(x_full, cin, off_p, weight_p, bias_p, off_n=None, weight_n=No
 
 def _tap_partial_pack(w3p, w3n):
     """[3,C,3,3] x 2 -> two packed [27,C,1,1] images (row co*9+tap), memoised on w3p."""
-    tag = (w3p._version, w3p.data_ptr(), w3n._version, w3n.data_ptr())
+    tag = (w3p._version, w3p.data_ptr(), w3n._version, w3n.data_ptr(), _pack_generation[0])
     hit = getattr(w3p, "_wmd_pack_t27", None) if _PACK_CACHE else None
     if hit is not None and hit[0] == tag:
         return hit[1]
@@ -530,19 +545,22 @@ def idwt_haar(yl, yh, disp_scale=None, clamp01=False):
 
 
 def dwt_haar(x, J=1):
-    """J-level Haar analysis of x [B,C,H,W] (H, W divisible by 2^J). Returns (yl, [yh_fine..yh_coarse]).
-    The reference only uses it on ground truth (no gradient, NYUv2/train.py:289)."""
+    """J-level Haar analysis of x [B,C,H,W] = DWT(J, "haar", mode="reflect"): returns (yl, [yh_fine..yh_coarse]).  An odd
+    axis is extended by one reflected sample (pytorch_wavelets' padding for mode="reflect"), so every level has
+    ceil(size/2) coefficients.  The reference only uses it on ground truth (no gradient, NYUv2/train.py:289)."""
     _require_gpu(x)
     l = _lib.lib()
     ll = _c(x.detach())
     yh = []
     for _ in range(J):
         B, Cc, H, W = ll.shape
+        h, w = (H + 1) // 2, (W + 1) // 2
+        nl = torch.empty((B, Cc, h, w), device=x.device, dtype=torch.float32)
+        nh = torch.empty((B, Cc, 3, h, w), device=x.device, dtype=torch.float32)
         if H % 2 or W % 2:
-            raise _lib.WmdError("dwt_haar: odd size %dx%d (reference pads by reflection; not needed on its inputs)" % (H, W))
-        nl = torch.empty((B, Cc, H // 2, W // 2), device=x.device, dtype=torch.float32)
-        nh = torch.empty((B, Cc, 3, H // 2, W // 2), device=x.device, dtype=torch.float32)
-        check(l.wmd_dwt_haar_fwd(ptr(ll), ptr(nl), ptr(nh), B * Cc, H // 2, W // 2, current_stream()), "wmd_dwt_haar_fwd")
+            check(l.wmd_dwt_haar_reflect_fwd(ptr(ll), ptr(nl), ptr(nh), B * Cc, H, W, current_stream()), "wmd_dwt_haar_reflect_fwd")
+        else:
+            check(l.wmd_dwt_haar_fwd(ptr(ll), ptr(nl), ptr(nh), B * Cc, h, w, current_stream()), "wmd_dwt_haar_fwd")
         yh.append(nh)
         ll = nl
     return ll, yh

@@ -155,9 +155,10 @@ class LossOptions:
 
     def __init__(self, height=192, width=640, frame_ids=(0, -1, 1), loss_scales=(0, 1, 2, 3), min_depth=0.1, max_depth=100.0,
                  v1_multiscale=False, disable_automasking=False, avg_reprojection=False, no_ssim=False, use_depth_hints=False,
-                 disparity_smoothness=1e-3):
+                 disparity_smoothness=1e-3, scales=(0, 1, 2, 3)):
         self.height, self.width = height, width
         self.frame_ids, self.loss_scales = list(frame_ids), list(loss_scales)
+        self.scales = list(scales)      # --scales: the normaliser of the total loss (trainer.py:47,557), separate from --loss_scales
         self.min_depth, self.max_depth = min_depth, max_depth
         self.v1_multiscale, self.disable_automasking, self.avg_reprojection = v1_multiscale, disable_automasking, avg_reprojection
         self.no_ssim, self.use_depth_hints, self.disparity_smoothness = no_ssim, use_depth_hints, disparity_smoothness
@@ -254,5 +255,5 @@ def compute_losses(inputs, outputs, opt, tie_break_noise=None):
         loss = loss + opt.disparity_smoothness * get_smooth_loss(norm_disp, color) / (2 ** scale)
         total_loss = total_loss + loss
         losses["loss/{}".format(scale)] = loss
-    losses["loss"] = total_loss / len(opt.loss_scales)
+    losses["loss"] = total_loss / len(getattr(opt, "scales", opt.loss_scales))   # self.num_scales = len(opt.scales), trainer.py:47,557
     return losses

@@ -42,7 +42,9 @@ class IDWT(nn.Module):
 
 
 class DWT(nn.Module):
-    """`DWT(J, wave="haar", mode="reflect")` on even sizes: forward(x) -> (yl, [yh_1 .. yh_J])."""
+    """`DWT(J, wave="haar", mode="reflect")`: forward(x) -> (yl, [yh_1 .. yh_J]).  For the 2-tap Haar filters every padding mode
+    gives the same coefficients on even sizes; on an odd axis only mode="reflect" (the reference's, NYUv2/train.py:258) is
+    implemented: one reflected sample on the right / bottom."""
 
     def __init__(self, J=1, wave="haar", mode="reflect"):
         super().__init__()
@@ -52,6 +54,12 @@ class DWT(nn.Module):
         self.mode = mode
 
     def forward(self, x):
+        if self.mode != "reflect":
+            h, w = x.shape[-2:]
+            for _ in range(self.J):
+                if h % 2 or w % 2:
+                    raise NotImplementedError("DWT on odd sizes is implemented for mode='reflect' only (got %r)" % self.mode)
+                h, w = h // 2, w // 2
         return ops.dwt_haar(x, self.J)
 
 
