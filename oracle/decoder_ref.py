@@ -90,9 +90,22 @@ def conv_block(x, sd, key, pad):
     return F.elu(conv3x3(x, sd[key + ".conv.conv.weight"], sd[key + ".conv.conv.bias"], pad))
 
 
-def wave_head(x, sd, key):
+def leaky(z, slope, key=None, branch=None, trace=None):
+    """LeakyReLU(slope).  Test support for the GPU gradient checks (LeakyReLU is the only kink on the path — ELU(alpha=1) is
+    C1 and the clamp is never active on the test inputs): `trace[key] = z` records the pre-activation, and `branch[key]`
+    (bool tensor, True = identity piece) evaluates AND differentiates a prescribed linear piece per element, so that the
+    handful of elements whose pre-activation lies within fp32 rounding of 0 are differentiated on the same side of the kink
+    as the device did (forward values differ by < 1e-6 there; the derivative would differ by a factor 1/slope)."""
+    if trace is not None and key is not None:
+        trace[key] = z.detach()
+    if branch is not None and key in branch:
+        return torch.where(branch[key], z, slope * z)
+    return F.leaky_relu(z, slope)
+
+
+def wave_head(x, sd, key, bkey=None, branch=None, trace=None):
     """nn.Sequential(Conv1x1, LeakyReLU(0.1), Conv3x3(refl)) (depth_decoder.py:104-120)."""
-    t = F.leaky_relu(conv1x1(x, sd[key + ".0.conv.weight"], sd[key + ".0.conv.bias"]), 0.1)
+    t = leaky(conv1x1(x, sd[key + ".0.conv.weight"], sd[key + ".0.conv.bias"]), 0.1, bkey, branch, trace)
     return conv3x3(t, sd[key + ".2.conv.weight"], sd[key + ".2.conv.bias"], "reflect")
 
 
@@ -141,19 +154,20 @@ def kitti_wave_param_shapes(num_ch_enc):
     return shapes
 
 
-def kitti_wave_coefficients(x, sd, keys, i, with_ll):
+def kitti_wave_coefficients(x, sd, keys, i, with_ll, branch=None, trace=None):
     """get_coefficients (depth_decoder.py:126-136)."""
+    head = lambda j: wave_head(x, sd, "decoder.%d" % keys[("waveconv", i, j)], ("waveconv", i, j), branch, trace)
     yl = None
     if with_ll:
-        yl = 2 ** i * torch.sigmoid(wave_head(x, sd, "decoder.%d" % keys[("waveconv", i, 0)]))
-    pos = torch.sigmoid(wave_head(x, sd, "decoder.%d" % keys[("waveconv", i, 1)])).unsqueeze(1)
-    neg = torch.sigmoid(wave_head(x, sd, "decoder.%d" % keys[("waveconv", i, -1)])).unsqueeze(1)
+        yl = 2 ** i * torch.sigmoid(head(0))
+    pos = torch.sigmoid(head(1)).unsqueeze(1)
+    neg = torch.sigmoid(head(-1)).unsqueeze(1)
     yh = 2 ** (i - 1) * pos - 2 ** (i - 1) * neg
     return yl, yh
 
 
-def kitti_wave_decoder(feats, sd):
-    """DepthWaveProgressiveDecoder.forward (depth_decoder.py:138-168)."""
+def kitti_wave_decoder(feats, sd, branch=None, trace=None):
+    """DepthWaveProgressiveDecoder.forward (depth_decoder.py:138-168).  branch / trace: see `leaky` (keys ("waveconv", i, j))."""
     keys = kitti_wave_keys()
     out = {}
     x = feats[-1]
@@ -162,7 +176,7 @@ def kitti_wave_decoder(feats, sd):
         x = conv_block(x, sd, "decoder.%d" % keys[("upconv", i, 0)], "reflect")
         x = torch.cat([up2(x), feats[i - 1]], 1)
         x = conv_block(x, sd, "decoder.%d" % keys[("upconv", i, 1)], "reflect")
-        ll_new, yh = kitti_wave_coefficients(x, sd, keys, i, with_ll=(i == 4))
+        ll_new, yh = kitti_wave_coefficients(x, sd, keys, i, with_ll=(i == 4), branch=branch, trace=trace)
         if i == 4:
             yl = ll_new
         out[("wavelets", i - 1, "LL")] = yl
@@ -512,10 +526,11 @@ def nyu_wave224_param_shapes(enc_features=(96, 96, 192, 384, 2208), decoder_widt
     return sh
 
 
-def nyu_up_block(x, skip, sd, key, pad="reflect"):
-    """UpSampleBlock (NYUv2/networks/layers.py:57-67): up2 -> cat -> Conv3x3(padding) -> LeakyReLU(0.2)."""
+def nyu_up_block(x, skip, sd, key, pad="reflect", branch=None, trace=None):
+    """UpSampleBlock (NYUv2/networks/layers.py:57-67): up2 -> cat -> Conv3x3(padding) -> LeakyReLU(0.2).
+    branch / trace: see `leaky` (keyed by the block name)."""
     t = torch.cat([up2(x), skip], 1)
-    return F.leaky_relu(nyu_conv3x3(t, sd, key + ".convA", pad), 0.2)
+    return leaky(nyu_conv3x3(t, sd, key + ".convA", pad), 0.2, key, branch, trace)
 
 
 def nyu_baseline_decoder(x_blocks, sd, variant224=False):
@@ -548,11 +563,11 @@ def nyu_wave224_decoder(x_blocks, sd):
     return out
 
 
-def nyu_wave_decoder(x_blocks, sd):
-    """DecoderWave.forward (densedepth_decoder.py:117-148)."""
+def nyu_wave_decoder(x_blocks, sd, branch=None, trace=None):
+    """DecoderWave.forward (densedepth_decoder.py:117-148).  branch / trace: see `leaky` (keys "up1" .. "up3")."""
     out = {}
     x_d0 = conv3x3(x_blocks[-1], sd["conv2.conv.weight"], sd["conv2.conv.bias"], "replicate")
-    x_d1 = nyu_up_block(x_d0, x_blocks[-2], sd, "up1")
+    x_d1 = nyu_up_block(x_d0, x_blocks[-2], sd, "up1", branch=branch, trace=trace)
     ll = 8 * conv3x3(x_d1, sd["wave1_ll.conv.weight"], sd["wave1_ll.conv.bias"], "replicate")
     out[("disp", 3)] = ll / 8
     h = 4 * nyu_conv3x3(x_d1, sd, "wave1", "zero").unsqueeze(1)
@@ -560,12 +575,12 @@ def nyu_wave_decoder(x_blocks, sd):
     out[("wavelets", 2, "LH")], out[("wavelets", 2, "HL")], out[("wavelets", 2, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
     ll = haar_idwt(ll, h)
     out[("disp", 2)] = ll / 4
-    x_d2 = nyu_up_block(x_d1, x_blocks[-3], sd, "up2")
+    x_d2 = nyu_up_block(x_d1, x_blocks[-3], sd, "up2", branch=branch, trace=trace)
     h = 2 * nyu_conv3x3(x_d2, sd, "wave2", "zero").unsqueeze(1)
     out[("wavelets", 1, "LH")], out[("wavelets", 1, "HL")], out[("wavelets", 1, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
     ll = haar_idwt(ll, h)
     out[("disp", 1)] = ll / 2
-    x_d3 = nyu_up_block(x_d2, x_blocks[-4], sd, "up3")
+    x_d3 = nyu_up_block(x_d2, x_blocks[-4], sd, "up3", branch=branch, trace=trace)
     h = nyu_conv3x3(x_d3, sd, "wave3", "zero").unsqueeze(1)
     out[("wavelets", 0, "LH")], out[("wavelets", 0, "HL")], out[("wavelets", 0, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
     ll = haar_idwt(ll, h)

@@ -51,29 +51,71 @@ def _compare_grads(dec, feats_gpu, sd_cpu, feats_cpu, tol=NET_TOL, skip_feats=()
     return n
 
 
+class _BranchCapture:
+    """LeakyReLU is the only kink on the path (ELU(alpha=1) is C1, the clamp is inactive on these inputs).  Among millions of
+    pre-activations a handful lie within fp32 rounding of 0; there the device and the CPU may land on different sides, which
+    changes nothing in the forward (< 1e-6) but multiplies that element's derivative by 1/slope -- a legitimate discrete
+    difference that would swamp a 1e-4 gradient comparison.  So the gradient tests record which linear piece the DEVICE
+    used (sign of its post-activation output, via forward hooks on the modules that own the activation) and let the oracle
+    differentiate the same piece (`oracle.decoder_ref.leaky`), after checking that the two only disagree where the oracle's
+    own pre-activation is within 1e-5 of 0 relative to the tensor's scale, and on fewer than 1e-4 of the elements."""
+
+    def __init__(self, modules):
+        self.branch, self._hooks = {}, []
+        for key, m in modules.items():
+            self._hooks.append(m.register_forward_hook(self._make(key)))
+
+    def _make(self, key):
+        def hook(_m, _inp, out):
+            self.branch[key] = (out.detach() > 0).cpu()
+        return hook
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+
+    def check_against(self, trace):
+        assert set(trace) == set(self.branch), (sorted(map(str, trace)), sorted(map(str, self.branch)))
+        flips = 0
+        for key, z in trace.items():
+            dis = self.branch[key] != (z > 0)
+            n = int(dis.sum())
+            flips += n
+            if n:
+                assert float(z[dis].abs().max()) <= 1e-5 * float(z.abs().max()), "%s: the device took another LeakyReLU " \
+                    "piece at a pre-activation of %.3e (scale %.3e)" % (key, float(z[dis].abs().max()), float(z.abs().max()))
+                assert n <= max(2, 1e-4 * z.numel()), "%s: %d branch disagreements" % (key, n)
+        return flips
+
+
 def _kitti_wave_fwd_bwd_vs_oracle(dev, chans, B, H, W, seed):
     from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
     dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=seed).to(dev)
     feats = kitti_feats(B, H, W, chans, seed=seed)
+    # training path on the device first (per-head operators with saved activations), recording its LeakyReLU pieces
+    cap = _BranchCapture({k: m[0] for k, m in dec.convs.items() if k[0] == "waveconv"})
+    fg = [f.to(dev).requires_grad_(True) for f in feats]
+    og = dec(fg)
+    cap.close()
+    loss = _sq_loss(og)
+    loss.backward()
+    # the oracle and its autograd on the same linear pieces
     sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in dec.state_dict().items()}
     fc = [f.clone().requires_grad_(True) for f in feats]
-    ref = R.kitti_wave_decoder(fc, sd)
+    trace = {}
+    ref = R.kitti_wave_decoder(fc, sd, branch=cap.branch, trace=trace)
+    cap.check_against(trace)
     _sq_loss(ref).backward()
+    for k in ref:
+        assert_close(og[k], ref[k].detach(), NET_TOL, "grad-mode " + key_str(k))
+    assert abs(float(loss) - float(_sq_loss(ref))) < 1e-5 * max(1.0, abs(float(_sq_loss(ref))))
+    n = _compare_grads(dec, fg, sd, fc)
+    assert n == 52
     # inference path (fused heads, Winograd trunk, tuned tiles)
     with torch.no_grad():
         out = dec([f.to(dev) for f in feats])
     for k in ref:
         assert_close(out[k], ref[k].detach(), NET_TOL, "no_grad " + key_str(k))
-    # training path (per-head operators with saved activations) + backward kernels
-    fg = [f.to(dev).requires_grad_(True) for f in feats]
-    og = dec(fg)
-    for k in ref:
-        assert_close(og[k], ref[k].detach(), NET_TOL, "grad-mode " + key_str(k))
-    loss = _sq_loss(og)
-    loss.backward()
-    assert abs(float(loss) - float(_sq_loss(ref))) < 1e-5 * max(1.0, abs(float(_sq_loss(ref))))
-    n = _compare_grads(dec, fg, sd, fc)
-    assert n == 52
     return dec
 
 
@@ -88,74 +130,36 @@ def test_config3_r50_half_size_batch2_gradients_vs_oracle(dev):
     _kitti_wave_fwd_bwd_vs_oracle(dev, R50, 2, 160, 512, seed=4)
 
 
-def test_config3_r50_batch8_properties(dev):
-    """The full per-GPU batch of config 3 (8 x 1024x320), beyond what the CPU oracle can afford, through size-independent
-    properties: (a) per-sample independence of the forward, (b) a batch made of 8 copies of one frame has the same
-    batch-mean loss gradient w.r.t. the weights as that frame alone (wgrad's pixel/batch split reduction at full size),
-    and 1/8 of its feature gradient per copy."""
-    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
-    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R50)), seed=5).to(dev)
-    feats8 = [f.to(dev) for f in kitti_feats(8, 320, 1024, R50, seed=5)]
-    with torch.no_grad():
-        out8 = {k: v.clone() for k, v in dec(feats8).items()}
-        one = dec([f[5:6] for f in feats8])
-    for s in range(4):
-        assert_close(out8[("disp", s)][5:6], one[("disp", s)], 1e-6, "batch independence disp%d" % s)
-    del out8, one
-    f1 = [f[2:3].clone().requires_grad_(True) for f in feats8]
-    _sq_loss(dec(f1)).backward()
-    g1 = {n: p.grad.clone() for n, p in dec.named_parameters()}
-    gf1 = [f.grad.clone() for f in f1]
-    for p in dec.parameters():
-        p.grad = None
-    rep = [f[2:3].expand(8, -1, -1, -1).contiguous().requires_grad_(True) for f in feats8]
-    _sq_loss(dec(rep)).backward()
-    for n, p in dec.named_parameters():
-        assert_close(p.grad, g1[n], 2e-5, "replicated-batch dW " + n)
-    for k, f in enumerate(rep):
-        assert_close(f.grad[3:4] * 8, gf1[k], 2e-5, "replicated-batch dfeat%d" % k)
+def test_config3_r50_full_batch8_forward_and_gradients_vs_oracle(dev):
+    """The full per-GPU batch of config 3 (8 x 1024x320, what `bench.py --workload train` steps through): outputs and the
+    gradients of all five feature maps and all 52 parameter tensors against the oracle's autograd (~20 s of CPU)."""
+    _kitti_wave_fwd_bwd_vs_oracle(dev, R50, 8, 320, 1024, seed=5)
 
 
-def test_config5_densenet161_640x480_backward_vs_oracle(dev):
-    """NYUv2 DecoderWave at DenseNet161 widths, one 640x480 frame: gradients of every feature map and every parameter
-    against autograd through the oracle (2208 -> 1104 conv2, 1488 -> 552 ... 330 -> 138: wgrad with ragged K tails)."""
+@pytest.mark.parametrize("B", [1, 4])
+def test_config5_densenet161_640x480_backward_vs_oracle(dev, B):
+    """NYUv2 DecoderWave at DenseNet161 widths on 640x480 frames (B = 4 is config 5's per-GPU batch): outputs and gradients of
+    every feature map and every parameter against autograd through the oracle (2208 -> 1104 conv2, 1488 -> 552 ... 330 ->
+    138: wgrad with ragged K tails)."""
     from wavelet_monodepth_amd.nyu import DecoderWave
     enc = [96, 96, 192, 384, 2208]
     dec = synth.fill_state_dict(DecoderWave(enc_features=enc), seed=9).to(dev)
-    feats = nyu_feats(1, 480, 640, enc, seed=9, prefix="nyu_big")
-    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in dec.state_dict().items()}
-    fc = [f.clone().requires_grad_(True) for f in feats]
-    ref = R.nyu_wave_decoder(fc, sd)
-    _sq_loss(ref).backward()
+    feats = nyu_feats(B, 480, 640, enc, seed=9, prefix="nyu_big")
+    cap = _BranchCapture({"up%d" % k: getattr(dec, "up%d" % k) for k in (1, 2, 3)})
     fg = [f.to(dev).requires_grad_(True) for f in feats]
     og = dec(fg)
+    cap.close()
+    _sq_loss(og).backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in dec.state_dict().items()}
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    trace = {}
+    ref = R.nyu_wave_decoder(fc, sd, branch=cap.branch, trace=trace)
+    cap.check_against(trace)
+    _sq_loss(ref).backward()
     for k in ref:
         assert_close(og[k], ref[k].detach(), NET_TOL, key_str(k))
-    _sq_loss(og).backward()
     n = _compare_grads(dec, fg, sd, fc)
-    assert n == len(list(dec.parameters())) and n >= 20
-
-
-def test_config5_densenet161_batch4_properties(dev):
-    """Config 5's per-GPU batch (4 x 640x480): batch independence of the forward and the replicated-batch gradient identity."""
-    from wavelet_monodepth_amd.nyu import DecoderWave
-    enc = [96, 96, 192, 384, 2208]
-    dec = synth.fill_state_dict(DecoderWave(enc_features=enc), seed=10).to(dev)
-    feats4 = [f.to(dev) for f in nyu_feats(4, 480, 640, enc, seed=10, prefix="nyu_b4")]
-    with torch.no_grad():
-        out4 = {k: v.clone() for k, v in dec(feats4).items()}
-        one = dec([f[3:4] for f in feats4])
-    for s in range(4):
-        assert_close(out4[("disp", s)][3:4], one[("disp", s)], 1e-6, "batch independence disp%d" % s)
-    f1 = [f[1:2].clone().requires_grad_(True) for f in feats4]
-    _sq_loss(dec(f1)).backward()
-    g1 = {n: p.grad.clone() for n, p in dec.named_parameters()}
-    for p in dec.parameters():
-        p.grad = None
-    rep = [f[1:2].expand(4, -1, -1, -1).contiguous().requires_grad_(True) for f in feats4]
-    _sq_loss(dec(rep)).backward()
-    for n, p in dec.named_parameters():
-        assert_close(p.grad, g1[n], 2e-5, "replicated-batch dW " + n)
+    assert n == len(list(dec.parameters())) and n >= 14
 
 
 @pytest.mark.parametrize("last", [1280, 160])

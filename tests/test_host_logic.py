@@ -386,3 +386,45 @@ def test_kitti_factories_follow_the_reference_signatures():
     assert type(kitti.make_depth_decoder(enc.num_ch_enc, range(4), use_wavelets=True, use_sparse=True)) \
         is kitti.SparseDepthWaveProgressiveDecoder
     assert type(kitti.make_depth_decoder(enc.num_ch_enc, range(4))) is kitti.DepthDecoder
+
+
+# ---- encoders stay PyTorch, with torchvision's state_dict names (released / ImageNet checkpoints load with strict=True) ------
+def test_densenet161_and_mobilenetv2_state_dict_names_follow_torchvision():
+    """torchvision is not installed here, so the manifest is restated from its published architecture: densenet161 =
+    growth 48, blocks (6, 12, 36, 24), 96 stem features, bn_size 4 (`features.denseblockK.denselayerL.{norm1,conv1,norm2,
+    conv2}`, `features.transitionK.{norm,conv}`, `features.norm5`, `classifier`); mobilenet_v2 `features.N...` as the
+    reference's own MobileNetV2Encoder builds them (mobilenetv2_encoder.py:112-136)."""
+    import torch
+    from wavelet_monodepth_amd.encoders import DenseEncoder, MobileNetV2Encoder
+    sd = DenseEncoder().state_dict()
+    want = {"original_model.features.conv0.weight": (96, 3, 7, 7), "original_model.classifier.weight": (1000, 2208),
+            "original_model.features.norm5.weight": (2208,)}
+    c = 96
+    for k, n in enumerate((6, 12, 36, 24), 1):
+        for l in range(1, n + 1):
+            p = "original_model.features.denseblock%d.denselayer%d." % (k, l)
+            want[p + "norm1.weight"] = (c,)
+            want[p + "conv1.weight"] = (192, c, 1, 1)
+            want[p + "norm2.running_var"] = (192,)
+            want[p + "conv2.weight"] = (48, 192, 3, 3)
+            c += 48
+        if k < 4:
+            want["original_model.features.transition%d.conv.weight" % k] = (c // 2, c, 1, 1)
+            want["original_model.features.transition%d.norm.bias" % k] = (c,)
+            c //= 2
+    for name, shape in want.items():
+        assert name in sd and tuple(sd[name].shape) == shape, name
+    # 4 tensors per conv-less BN (+ num_batches_tracked), no unexpected extras: every key belongs to a known family
+    import re
+    pat = re.compile(r"original_model\.(features\.(conv0|norm0|norm5|denseblock[1-4]\.denselayer\d+\.(norm[12]|conv[12])|"
+                     r"transition[1-3]\.(norm|conv))|classifier)\.(weight|bias|running_mean|running_var|num_batches_tracked)$")
+    assert all(pat.match(k) for k in sd), [k for k in sd if not pat.match(k)][:5]
+    msd = MobileNetV2Encoder().state_dict()
+    assert tuple(msd["features.0.0.weight"].shape) == (32, 3, 3, 3)
+    assert tuple(msd["features.1.conv.0.0.weight"].shape) == (32, 1, 3, 3)          # t = 1 block: depthwise first
+    assert tuple(msd["features.2.conv.0.0.weight"].shape) == (96, 16, 1, 1)         # expansion 6
+    assert tuple(msd["features.17.0.weight"].shape) == (1280, 160, 1, 1)            # the reference drops the 320 stage
+    x = torch.rand(1, 3, 64, 96)
+    with torch.no_grad():
+        feats = DenseEncoder().eval()(x)
+    assert [tuple(f.shape[1:]) for f in feats] == [(96, 32, 48), (96, 16, 24), (192, 8, 12), (384, 4, 6), (2208, 2, 3)]

@@ -515,20 +515,39 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
         aoff[v] = (unsigned)(((size_t)cot * a.nci4 * 16 * 64 + rem) * 4);
     }
     constexpr int NPB = CK * NPOS, NPIECES = NPB + T::NAV;
-    auto stage_piece = [&](int chunk, int buf, int q) {
+    // Where a chunk's CK channels come from is decided ONCE per chunk (wave-uniform, scalar unit): a chunk that lies entirely
+    // in one source tensor -- the usual case, C1 and C2 multiples of CK -- selects that tensor's descriptor, per-lane
+    // offsets and plane stride up front, and every piece is then descriptor + (base + j * stride): no per-piece channel
+    // arithmetic, comparisons or branches in the MFMA stream (measured with SQ_INSTS_SALU: 4.75 scalar instructions per
+    // MFMA before, see profiles/r02_wino_counters.md).  A chunk that straddles the C1 boundary or the channel tail takes the
+    // generic per-channel path.
+    struct ChunkSrc {
+        bool pure, in1;
+        unsigned base, step;
+        unsigned ob[NPOS];
+    };
+    auto chunk_src = [&](int chunk) {
+        ChunkSrc cs;
+        const int ci0 = chunk * CK;
+        cs.in1 = ci0 + CK <= a.C1;
+        cs.pure = cs.in1 || (ci0 >= a.C1 && ci0 + CK <= a.Cin);
+        cs.base = cs.in1 ? (unsigned)ci0 * pb1 : (unsigned)max(ci0 - a.C1, 0) * pb2;
+        cs.step = cs.in1 ? pb1 : pb2;
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) cs.ob[i] = cs.in1 ? ob1[i] : ob2[i];
+        return cs;
+    };
+    auto stage_piece = [&](int chunk, int buf, int q, const ChunkSrc& cs) {
         if (q < NPB) {
             const int j = q / NPOS, i = q % NPOS;
-            const int ci0 = chunk * CK;
             if (NPOS * NT == T::NPOSITIONS || tid + i * NT < T::NPOSITIONS) {
                 lds_ptr_t d = (lds_ptr_t)(lds + buf * T::B_FLOATS + wave * 64 + j * PS + i * NT);
-                // a chunk that lies entirely in one source tensor (the usual case: C1, C2 multiples of CK) needs no
-                // per-channel descriptor / offset selection: one wave-uniform branch, one scalar add per piece
-                if (ci0 + CK <= a.C1) {
-                    lds_dma4(r1, d, ob1[i], (unsigned)(ci0 + j) * pb1);
-                } else if (ci0 >= a.C1 && ci0 + CK <= a.Cin) {
-                    lds_dma4(r2, d, ob2[i], (unsigned)(ci0 + j - a.C1) * pb2);
+                if (cs.pure) {
+                    const unsigned soff = cs.base + (unsigned)j * cs.step;
+                    if (cs.in1) lds_dma4(r1, d, cs.ob[i], soff);
+                    else lds_dma4(r2, d, cs.ob[i], soff);
                 } else {
-                    const int ci = ci0 + j;
+                    const int ci = chunk * CK + j;
                     const bool from_x1 = ci < a.C1;
                     const bool chan_ok = ci < a.Cin;
                     const unsigned soff = from_x1 ? (unsigned)ci * pb1 : (unsigned)max(ci - a.C1, 0) * pb2;
@@ -560,8 +579,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     const int c_begin = ks * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
     if (c_begin < c_end) {
+        const ChunkSrc cs0 = chunk_src(c_begin);
 #pragma unroll
-        for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
+        for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q, cs0);
     }
     float bias_v[MRW];   // requested now, used in the epilogue (see conv_fwd_kernel)
 #pragma unroll
@@ -582,6 +602,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
         const float* bsrc = lds + buf * T::B_FLOATS + boff;
         const float* asrc = ldsA + buf * T::A_FLOATS + a_lane;
         float d[16], v[2][16], wf[RS][MRW];
+        ChunkSrc csn;
+        if constexpr (PREFETCH) csn = chunk_src(c + 1);
         auto fetch_patch = [&](int kk) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -622,7 +644,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
             if constexpr (PREFETCH) {
 #pragma unroll
                 for (int q = 0; q < NPIECES; ++q)
-                    if (q * SP / NPIECES == s2) stage_piece(c + 1, buf ^ 1, q);
+                    if (q * SP / NPIECES == s2) stage_piece(c + 1, buf ^ 1, q, csn);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
