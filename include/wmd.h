@@ -125,6 +125,12 @@ typedef struct {
     int tune_ksplit;    /* 0: cost model; k>0: force k-way split of the Cin reduction    */
     const float* wp_wino; /* optional (3x3 only): wmd_conv_pack_weights_wino image; enables the Winograd F(2x2,3x3)
                              configurations ("conv_wino_kernel<...>": 2.25x fewer MFMAs, ~1e-6 relative rounding) */
+    const float* gate;  /* optional [B,Cout,H,W]: y = act(conv + bias) * act_gate'(gate), the derivative written in terms of
+                           an activation OUTPUT (ELU: g > 0 ? 1 : g + 1; LeakyReLU: g > 0 ? 1 : slope).  Lets a consumer's
+                           data gradient hand the producer dz = dy * f'(y) directly (no separate wmd_act_bwd pass).
+                           Direct kernels only (the Winograd configurations are skipped when it is set).             */
+    int gate_act;       /* wmd_act of the gate                                          */
+    float gate_slope;
 } wmd_conv_args;
 
 /* Fused  upsample(x1) ++ x2  ->  pad  ->  conv kxk  ->  + bias  ->  activation.
@@ -163,6 +169,10 @@ typedef struct {
     int tune_cfg;       /* as in wmd_conv_args: 0 = cost model, k > 0 forces configuration k-1 */
     int tune_ksplit;
     const float* wp_dgrad_wino; /* optional (3x3): wmd_conv_pack_weights_wino(..., dgrad = 1) image, enables Winograd */
+    const float* x1_fwd; /* optional: the forward's x1 [B,C1,H/up1,W/up1], itself the OUTPUT of an activation x1_act: dx1 is
+                            then multiplied by x1_act'(x1), i.e. it is already the producer's pre-activation gradient     */
+    int x1_act;          /* wmd_act (WMD_ACT_NONE: no gating)                            */
+    float x1_slope;
 } wmd_conv_dgrad_args;
 
 size_t wmd_conv_dgrad_workspace_floats(const wmd_conv_dgrad_args* args);
@@ -179,7 +189,14 @@ typedef struct {
     float* dbias;       /* [Cout] or NULL    (overwritten)                              */
     float* workspace;
     size_t workspace_floats;
+    int tune_cfg;       /* 0 = library model; k > 0 forces entry k-1 of the Winograd F(2x2,3x3) weight-gradient table
+                           (wmd_conv_wgrad_num_configs / _config_name; 3x3 only); -1 = direct kernel, library's tile */
+    int tune_nsplit;    /* 0 = library model; > 0 forces the number of pixel-tile slices (= partial sums)          */
 } wmd_conv_wgrad_args;
+
+/* the Winograd weight-gradient tile table (for autotuners; names are stable across versions) */
+int wmd_conv_wgrad_num_configs(void);
+const char* wmd_conv_wgrad_config_name(int index);
 
 size_t wmd_conv_wgrad_workspace_floats(const wmd_conv_wgrad_args* args);
 /* Weight + bias gradient (deterministic two-stage split over the B*H*W reduction). */

@@ -93,10 +93,12 @@ def _kitti_wave_fwd_bwd_vs_oracle(dev, chans, B, H, W, seed):
     dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=seed).to(dev)
     feats = kitti_feats(B, H, W, chans, seed=seed)
     # training path on the device first (per-head operators with saved activations), recording its LeakyReLU pieces
-    cap = _BranchCapture({k: m[0] for k, m in dec.convs.items() if k[0] == "waveconv"})
+    cap = _BranchCapture({k: m[0] for k, m in dec.convs.items() if k[0] == "waveconv"})   # per-head operator path
+    dec.branch_trace = cap.branch                                                          # stacked-heads path
     fg = [f.to(dev).requires_grad_(True) for f in feats]
     og = dec(fg)
     cap.close()
+    dec.branch_trace = None
     loss = _sq_loss(og)
     loss.backward()
     # the oracle and its autograd on the same linear pieces

@@ -22,7 +22,7 @@ class ConvArgs(C.Structure):
                 ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int), ("slope", C.c_float),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
-                ("wp_wino", C.c_void_p)]
+                ("wp_wino", C.c_void_p), ("gate", C.c_void_p), ("gate_act", C.c_int), ("gate_slope", C.c_float)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -30,14 +30,14 @@ class ConvDgradArgs(C.Structure):
                 ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int),
                 ("dz", C.c_void_p), ("wp_dgrad", C.c_void_p), ("dx1", C.c_void_p), ("dx2", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
-                ("wp_dgrad_wino", C.c_void_p)]
+                ("wp_dgrad_wino", C.c_void_p), ("x1_fwd", C.c_void_p), ("x1_act", C.c_int), ("x1_slope", C.c_float)]
 
 
 class ConvWgradArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("up1", C.c_int), ("C2", C.c_int),
                 ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("dz", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_nsplit", C.c_int)]
 
 
 class HeadArgs(C.Structure):
@@ -133,6 +133,8 @@ SIGNATURES = {
     "wmd_conv_dgrad": (C.c_int, [C.POINTER(ConvDgradArgs), C.c_void_p]),
     "wmd_conv_wgrad_workspace_floats": (C.c_size_t, [C.POINTER(ConvWgradArgs)]),
     "wmd_conv_wgrad": (C.c_int, [C.POINTER(ConvWgradArgs), C.c_void_p]),
+    "wmd_conv_wgrad_num_configs": (C.c_int, []),
+    "wmd_conv_wgrad_config_name": (C.c_char_p, [C.c_int]),
     "wmd_head3x3_fwd": (C.c_int, [C.POINTER(HeadArgs), C.c_void_p]),
     "wmd_head3x3_workspace_floats": (C.c_size_t, [C.POINTER(HeadArgs)]),
     "wmd_head_fused_fwd": (C.c_int, [C.POINTER(HeadFusedArgs), C.c_void_p]),

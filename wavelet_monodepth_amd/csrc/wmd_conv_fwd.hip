@@ -52,6 +52,10 @@ struct ConvKArgs {
     const float* wp2;   // per side: packed [27 -> 32 rows, CO_T] image
     float* t;           // [B, sides*27, H*W]
     int t_ctot;
+    // optional multiplicative gate of the final output (data-gradient path): y *= gate_act'(gate), gate laid out like y
+    const float* gate;
+    int gate_act;
+    float gate_slope;
 };
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, int NBUF = 2>
@@ -384,6 +388,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
                 if (final_out) v[r] = act_apply(v[r] + bv, a.act, a.slope);
             }
             float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
+            if (final_out && a.gate) {
+                const float* gp = a.gate + ((size_t)b * a.Cout + co) * plane2 + (size_t)oy * W + ox;
+                if (vec_ok && ox + 3 < W) {
+                    const float4 gv = *reinterpret_cast<const float4*>(gp);
+                    v[0] *= act_deriv(gv.x, a.gate_act, a.gate_slope);
+                    v[1] *= act_deriv(gv.y, a.gate_act, a.gate_slope);
+                    v[2] *= act_deriv(gv.z, a.gate_act, a.gate_slope);
+                    v[3] *= act_deriv(gv.w, a.gate_act, a.gate_slope);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ox + r < W) v[r] *= act_deriv(gp[r], a.gate_act, a.gate_slope);
+                }
+            }
             if (vec_ok && ox + 3 < W) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 // split-K second stage: y = act(bias + sum_s partial[s])
 __global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                           float* __restrict__ y, size_t n, size_t plane, int Cout, int ksplit,
-                                          int act, float slope) {
+                                          int act, float slope, const float* __restrict__ gate, int gate_act, float gate_slope) {
     // the ksplit partial loads of an element are independent: issue them four at a time (a plain `v += partial[...]` loop
     // with a run-time trip count waits for every round trip in turn), summing in the fixed order s = 0 .. ksplit-1
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -411,7 +429,9 @@ __global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, con
         }
         for (; s < ksplit; ++s) v += partial[(size_t)s * n + i];
         if (bias) v += bias[(i / plane) % Cout];
-        y[i] = act_apply(v, act, slope);
+        v = act_apply(v, act, slope);
+        if (gate) v *= act_deriv(gate[i], gate_act, gate_slope);
+        y[i] = v;
     }
 }
 
@@ -1123,6 +1143,10 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.ksplit = plan.ksplit;
     a.chunks_per_split = plan.chunks_per_split;
     a.y = plan.ksplit > 1 ? g->workspace : g->y;
+    a.gate = g->gate;
+    a.gate_act = g->gate_act;
+    a.gate_slope = g->gate_slope;
+    if (g->gate && wino) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: the output gate is implemented for the direct kernels only");
     const int cob = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
     dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y), (unsigned)cob, (unsigned)plan.ksplit);
     if (env_int("WMD_CONV_VERBOSE", 0))
@@ -1143,7 +1167,8 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
         const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
         ProfScope prof("conv_splitk_reduce_kernel", (double)n * plan.ksplit, 4.0 * n * (plan.ksplit + 1), (hipStream_t)stream);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->workspace,
-                           g->bias, g->y, n, (size_t)g->H * g->W, g->Cout, plan.ksplit, g->act, g->slope);
+                           g->bias, g->y, n, (size_t)g->H * g->W, g->Cout, plan.ksplit, g->act, g->slope, g->gate, g->gate_act,
+                           g->gate_slope);
         st = check_launch("conv_splitk_reduce_kernel");
     }
     return st;

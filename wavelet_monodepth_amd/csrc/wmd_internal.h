@@ -51,6 +51,16 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 
+// f'(x) written in terms of the activation OUTPUT y = f(x)
+__device__ __forceinline__ float act_deriv(float y, int act, float slope) {
+    switch (act) {
+        case WMD_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;     // y = e^x - 1  =>  dy/dx = y + 1
+        case WMD_ACT_LEAKY: return y > 0.f ? 1.f : slope;
+        case WMD_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
 // map a padded coordinate g in [-1, n] to a source coordinate; returns false when the tap reads zero
 __device__ __forceinline__ bool pad_coord(int& g, int n, int pad_mode) {
     if (pad_mode == WMD_PAD_REFLECT) {

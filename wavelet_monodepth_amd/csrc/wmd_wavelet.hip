@@ -133,13 +133,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
                                size_t n, int act, float slope) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float g = dy[i], v = y[i];
-        float d;
-        switch (act) {
-            case WMD_ACT_ELU: d = v > 0.f ? 1.f : v + 1.f; break;         // y = e^x - 1  =>  dy/dx = y + 1
-            case WMD_ACT_LEAKY: d = v > 0.f ? 1.f : slope; break;
-            case WMD_ACT_SIGMOID: d = v * (1.f - v); break;
-            default: d = 1.f;
-        }
+        const float d = act_deriv(v, act, slope);
         dz[i] = g * d;
     }
 }

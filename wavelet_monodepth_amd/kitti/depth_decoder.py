@@ -60,6 +60,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self.tanh = nn.Tanh()
         self._graph_mode = False
         self._graphs = GraphCache()
+        self.stack_heads = os.environ.get("WMD_STACKED_HEADS", "1") == "1"   # training: one launch per stage over all heads of a level
+        self.branch_trace = None   # set to a dict to record the LeakyReLU pieces of a training-mode forward
         self.fuse_heads = True   # inference: fused 1x1 -> 3x3 -> IDWT head kernels where the width allows (32/64/128)
         self.overlap_heads = os.environ.get("WMD_OVERLAP_HEADS", "0") == "1"   # opt-in (graph mode): heads on a second stream; measured no gain
         self._side_stream = None
@@ -67,25 +69,40 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self._segments = {}
 
     # -- pieces ------------------------------------------------------------------------------
-    def _head_mid(self, x, key):
+    def _head_mid(self, x, key, x_gate=None):
+        # the 1x1's LeakyReLU output `mid` is consumed by the head's 3x3 only, whose backward returns d mid * leaky'(mid)
+        # (x_gate on that side): the 1x1's backward takes its incoming gradient as dz
         head = self.convs[key]
-        return head[0](x, act="leaky", slope=0.1)
+        return head[0](x, act="leaky", slope=0.1, x1_gate=x_gate, grad_is_dz=True)
 
-    def get_coefficients(self, input_features, scale=1, return_ll=False):
-        """(LL, [LH, HL, HH]) from the features of level `scale` (reference :126-136)."""
+    def get_coefficients(self, input_features, scale=1, return_ll=False, _x_gate=None):
+        """(LL, [LH, HL, HH]) from the features of level `scale` (reference :126-136).
+        _x_gate (internal, set by forward()): input_features is the ELU output of this decoder's own trunk convolution."""
         if not torch.is_grad_enabled():
             return self._coefficients_stacked(input_features, scale, return_ll)
+        if self.stack_heads:
+            hd = lambda j: (lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias))(self.convs[("waveconv", scale, j)])
+            yh, yl, mid = ops.stacked_heads(input_features, hd(1), hd(-1), 2.0 ** (scale - 1), hd(0) if return_ll else None,
+                                            2.0 ** scale, x_gate=_x_gate, return_mid=True)
+            if self.branch_trace is not None:   # which LeakyReLU piece each element took (gradient-parity diagnostics)
+                o = 0
+                for j in ([0] if return_ll else []) + [1, -1]:
+                    c = self.convs[("waveconv", scale, j)][0].conv.weight.shape[0]
+                    self.branch_trace[("waveconv", scale, j)] = (mid[:, o:o + c] > 0).cpu()
+                    o += c
+            return yl, yh.unsqueeze(1)
         yl = None
+        leaky = ("leaky", 0.1)
         if return_ll:
-            mid = self._head_mid(input_features, ("waveconv", scale, 0))
+            mid = self._head_mid(input_features, ("waveconv", scale, 0), _x_gate)
             c3 = self.convs[("waveconv", scale, 0)][2].conv
-            yl = ops.head3x3(mid, c3.weight, c3.bias, pad="reflect", mode=1, scale=2.0 ** scale)
-        mp = self._head_mid(input_features, ("waveconv", scale, 1))
-        mn = self._head_mid(input_features, ("waveconv", scale, -1))
+            yl = ops.head3x3(mid, c3.weight, c3.bias, pad="reflect", mode=1, scale=2.0 ** scale, x_gate=leaky)
+        mp = self._head_mid(input_features, ("waveconv", scale, 1), _x_gate)
+        mn = self._head_mid(input_features, ("waveconv", scale, -1), _x_gate)
         cp = self.convs[("waveconv", scale, 1)][2].conv
         cn = self.convs[("waveconv", scale, -1)][2].conv
         yh = ops.head3x3(mp, cp.weight, cp.bias, mn, cn.weight, cn.bias, pad="reflect", mode=2,
-                         scale=2.0 ** (scale - 1))
+                         scale=2.0 ** (scale - 1), x_gate=leaky)
         return yl, yh.unsqueeze(1)
 
     def _coefficients_stacked(self, x, scale, return_ll):
@@ -201,10 +218,14 @@ class DepthWaveProgressiveDecoder(nn.Module):
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream if overlap else None
         keep = []   # tensors that cross streams stay referenced until the streams have joined
+        # training: every consumer of a trunk activation (the next trunk convolution, the heads' 1x1 convolutions) returns its
+        # data gradient already multiplied by ELU'(activation), so no trunk convolution runs a separate activation-backward
+        # pass (ops.conv2d_fused: x1_gate / grad_is_dz)
+        elu = ("elu", 0.0) if torch.is_grad_enabled() else None
         for i in range(4, 0, -1):
-            x = self.convs[("upconv", i, 0)](x)
+            x = self.convs[("upconv", i, 0)](x, x1_gate=elu if i < 4 else None, grad_is_dz=elu is not None)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
-            x = self.convs[("upconv", i, 1)](x, skip=skip, up=2)  # fused upsample + concat
+            x = self.convs[("upconv", i, 1)](x, skip=skip, up=2, x1_gate=elu, grad_is_dz=elu is not None)  # fused upsample + concat
             if overlap:
                 keep.append(x)
                 x.record_stream(side)
@@ -235,10 +256,11 @@ class DepthWaveProgressiveDecoder(nn.Module):
                 scale=2.0 ** (i - 1), yl=yl, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
             self.outputs[("wavelets", i - 1, "LL")] = yl_in
         else:
+            gate = ("elu", 0.0) if torch.is_grad_enabled() else None   # x is this decoder's own ELU output (see _forward_impl)
             if i == 4:
-                yl, yh = self.get_coefficients(x, scale=i, return_ll=True)
+                yl, yh = self.get_coefficients(x, scale=i, return_ll=True, _x_gate=gate)
             else:
-                _, yh = self.get_coefficients(x, scale=i, return_ll=False)
+                _, yh = self.get_coefficients(x, scale=i, return_ll=False, _x_gate=gate)
             self.outputs[("wavelets", i - 1, "LL")] = yl
         self.outputs[("wavelets", i - 1, "LH")] = yh[:, :, 0]
         self.outputs[("wavelets", i - 1, "HL")] = yh[:, :, 1]

@@ -22,9 +22,9 @@ class Conv3x3(nn.Module):
         self.pad_mode = "reflect" if use_refl else "zero"
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3, stride=stride, bias=use_bias)
 
-    def forward(self, x, skip=None, up=1, act="none", slope=0.0):
+    def forward(self, x, skip=None, up=1, act="none", slope=0.0, x1_gate=None, grad_is_dz=False):
         return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, x2=skip, up1=up, pad=self.pad_mode, act=act,
-                                slope=slope)
+                                slope=slope, x1_gate=x1_gate, grad_is_dz=grad_is_dz)
 
 
 class Conv1x1(nn.Module):
@@ -34,8 +34,9 @@ class Conv1x1(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 1, stride=1, padding=0)
 
-    def forward(self, x, act="none", slope=0.0):
-        return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, pad="zero", act=act, slope=slope)
+    def forward(self, x, act="none", slope=0.0, x1_gate=None, grad_is_dz=False):
+        return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, pad="zero", act=act, slope=slope, x1_gate=x1_gate,
+                                grad_is_dz=grad_is_dz)
 
 
 class ConvBlock(nn.Module):
@@ -53,10 +54,10 @@ class ConvBlock(nn.Module):
             raise NotImplementedError
         self.kernel_size = kernel_size
 
-    def forward(self, x, skip=None, up=1):
+    def forward(self, x, skip=None, up=1, x1_gate=None, grad_is_dz=False):
         if self.kernel_size == 3:
-            return self.conv(x, skip=skip, up=up, act="elu")
-        return self.conv(x, act="elu")
+            return self.conv(x, skip=skip, up=up, act="elu", x1_gate=x1_gate, grad_is_dz=grad_is_dz)
+        return self.conv(x, act="elu", x1_gate=x1_gate, grad_is_dz=grad_is_dz)
 
 
 class NyuConv3x3(nn.Module):

@@ -157,7 +157,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, ksize, pad, act, slope, up1):
+    def forward(ctx, x1, x2, weight, bias, ksize, pad, act, slope, up1, x1_gate=None, grad_is_dz=False):
         x1c, x2c = _c(x1), _c(x2)
         wp = pack_weights(weight)
         y = _conv_fwd_raw(x1c, x2c, wp, _c(bias), weight.shape[0], ksize, pad, act, slope, up1, pack_weights_wino(weight))
@@ -165,6 +165,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.has_x2 = x2 is not None
         ctx.has_bias = bias is not None
         ctx.cfg = (ksize, pad, act, slope, up1)
+        ctx.x1_gate, ctx.grad_is_dz = x1_gate, grad_is_dz
         return y
 
     @staticmethod
@@ -177,11 +178,12 @@ class _ConvFn(torch.autograd.Function):
         B, cout, H, W = y.shape
         C1 = x1.shape[1]
         C2 = 0 if x2 is None else x2.shape[1]
-        if ACT[act] != 0:
+        if ACT[act] != 0 and not ctx.grad_is_dz:
             dz = torch.empty_like(dy)
             check(l.wmd_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), ACT[act], float(slope), s), "wmd_act_bwd")
         else:
-            dz = dy
+            dz = dy     # no activation, or every consumer already multiplied its contribution by f'(y) (x1_gate on their side)
+        gate_act, gate_slope = (ACT[ctx.x1_gate[0]], float(ctx.x1_gate[1])) if ctx.x1_gate else (0, 0.0)
         need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and x2 is not None, ctx.needs_input_grad[2]
         dx1 = dx2 = dw = db = None
         if need_x1 or need_x2:
@@ -191,29 +193,62 @@ class _ConvFn(torch.autograd.Function):
             dx2 = torch.empty_like(x2) if need_x2 else None
             a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
                                    dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=ptr(dx2), workspace=None,
-                                   workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_dgrad_wino=ptr(wpdw))
+                                   workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_dgrad_wino=ptr(wpdw),
+                                   x1_fwd=ptr(x1) if gate_act else None, x1_act=gate_act, x1_slope=gate_slope)
             _dgrad_launch(a, dy.device, 9 if ksize == 3 else 1)
         if need_w or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw = torch.empty_like(weight)
             db = torch.empty(cout, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
             a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
                                    x1=ptr(x1), x2=ptr(x2), dz=ptr(dz), dw=ptr(dw), dbias=ptr(db), workspace=None,
-                                   workspace_floats=0)
-            n = l.wmd_conv_wgrad_workspace_floats(C.byref(a))
-            ws = torch.empty(max(n, 1), device=dy.device, dtype=torch.float32)
-            a.workspace, a.workspace_floats = ptr(ws), n
-            check(l.wmd_conv_wgrad(C.byref(a), s), "wmd_conv_wgrad")
-        return dx1, dx2, dw, db, None, None, None, None, None
+                                   workspace_floats=0, tune_cfg=0, tune_nsplit=0)
+            _wgrad_launch(a, dy.device)
+        return dx1, dx2, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d_fused(x1, weight, bias=None, x2=None, up1=1, pad="reflect", act="none", slope=0.0):
-    """act( conv_kxk( pad( cat[ nearest_up(x1, up1), x2 ] ) ) + bias ), k taken from `weight`."""
+_WGRAD_NAMES = None
+
+
+def _wgrad_launch(a, device):
+    """wmd_conv_wgrad with the kernel family / tile chosen per problem signature on the device (3x3: the Winograd
+    F(2x2,3x3) weight-gradient tiles against the direct kernel), like the forward and the data gradient."""
+    global _WGRAD_NAMES
+    l = _lib.lib()
+    stream = current_stream()
+    keep = []
+
+    def launch(cfg):
+        a.tune_cfg, a.tune_nsplit = cfg, 0
+        n = l.wmd_conv_wgrad_workspace_floats(C.byref(a))
+        ws = torch.empty(max(n, 1), device=device, dtype=torch.float32)
+        keep[:] = [ws]
+        a.workspace, a.workspace_floats = ptr(ws), n
+        return l.wmd_conv_wgrad(C.byref(a), stream)
+
+    cfg = 0
+    if tuner.enabled and a.ksize == 3:
+        if _WGRAD_NAMES is None:
+            _WGRAD_NAMES = [l.wmd_conv_wgrad_config_name(i).decode() for i in range(l.wmd_conv_wgrad_num_configs())]
+        key = "wgrad|%d|%d|%d|%d|%d|%d|%d|%d" % (a.B, a.H, a.W, a.C1, a.up1, a.C2, a.Cout, a.ksize)
+        cands = [("library", 0), ("direct", -1)] + [(n, i + 1) for i, n in enumerate(_WGRAD_NAMES)]
+        cfg = tuner.choose(key, cands, launch)
+    check(launch(cfg), "wmd_conv_wgrad")
+
+
+def conv2d_fused(x1, weight, bias=None, x2=None, up1=1, pad="reflect", act="none", slope=0.0, x1_gate=None, grad_is_dz=False):
+    """act( conv_kxk( pad( cat[ nearest_up(x1, up1), x2 ] ) ) + bias ), k taken from `weight`.
+
+    Backward-only hints for callers that own the whole graph around this op (the decoders): `x1_gate=(act, slope)` says x1
+    is the output of that activation and makes the data gradient return dx1 * act'(x1) -- the pre-activation gradient of
+    x1's producer -- from the same kernel; `grad_is_dz=True` on that producer says EVERY consumer of its output does so,
+    so its backward takes the incoming gradient as dz (no wmd_act_bwd pass).  The derivative is linear, so gating each
+    consumer's contribution before autograd sums them equals gating the sum."""
     _require_gpu(x1, x2, weight, bias)
     ksize = weight.shape[-1]
     cin = x1.shape[1] + (0 if x2 is None else x2.shape[1])
     if weight.shape[1] != cin:
         raise _lib.WmdError("weight expects %d input channels, got %d" % (weight.shape[1], cin))
-    return _ConvFn.apply(x1, x2, weight, bias, ksize, pad, act, slope, up1)
+    return _ConvFn.apply(x1, x2, weight, bias, ksize, pad, act, slope, up1, x1_gate, grad_is_dz)
 
 
 class _DwConvFn(torch.autograd.Function):
@@ -289,7 +324,8 @@ class _HeadFn(torch.autograd.Function):
     Backward reuses the generic MFMA dgrad/wgrad kernels on dz = dy*scale*sigma'(.)"""
 
     @staticmethod
-    def forward(ctx, xp, wp_, bp, xn, wn, bn, pad, mode, scale):
+    def forward(ctx, xp, wp_, bp, xn, wn, bn, pad, mode, scale, x_gate=None):
+        ctx.x_gate = x_gate
         xp, xn = _c(xp), _c(xn)
         y, sp, sn = _head_raw(xp, _c(wp_), _c(bp), xn, _c(wn), _c(bn), pad, mode, scale,
                                save_sig=any(ctx.needs_input_grad))
@@ -302,7 +338,7 @@ class _HeadFn(torch.autograd.Function):
         xp, wp_, xn, wn, sp, sn = ctx.saved_tensors
         pad, mode, scale, has_bp, has_bn = ctx.cfg
         dy = _c(dy)
-        outs = [None] * 9
+        outs = [None] * 10
         sides = [(xp, wp_, sp, +1.0, 0, has_bp)]
         if mode == 2:
             sides.append((xn, wn, sn, -1.0, 3, has_bn))
@@ -312,7 +348,7 @@ class _HeadFn(torch.autograd.Function):
             else:
                 dz = dy * sig * (1.0 - sig) * (sign * scale)
             dx, dw, db = _conv_backward_raw(x, None, w, dz, 3, pad, 1, has_b,
-                                            ctx.needs_input_grad[base], True)
+                                            ctx.needs_input_grad[base], True, x1_gate=ctx.x_gate)
             outs[base], outs[base + 1], outs[base + 2] = dx, dw, db
         return tuple(outs)
 
@@ -345,7 +381,7 @@ def _dgrad_launch(a, device, taps):
     check(launch(*choice), "wmd_conv_dgrad")
 
 
-def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, need_w):
+def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, need_w, x1_gate=None):
     """dgrad + wgrad through the C ABI for an already-differentiated pre-activation gradient dz."""
     l = _lib.lib()
     s = current_stream()
@@ -358,26 +394,165 @@ def _conv_backward_raw(x1, x2, weight, dz, ksize, pad, up1, has_bias, need_x, ne
         wpd = pack_weights(weight, dgrad=True)
         wpdw = pack_weights_wino(weight, dgrad=True)
         dx1 = torch.empty_like(x1)
+        gate_act, gate_slope = (ACT[x1_gate[0]], float(x1_gate[1])) if x1_gate else (0, 0.0)
         a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
                                dz=ptr(dz), wp_dgrad=ptr(wpd), dx1=ptr(dx1), dx2=None, workspace=None, workspace_floats=0,
-                               tune_cfg=0, tune_ksplit=0, wp_dgrad_wino=ptr(wpdw))
+                               tune_cfg=0, tune_ksplit=0, wp_dgrad_wino=ptr(wpdw),
+                               x1_fwd=ptr(x1) if gate_act else None, x1_act=gate_act, x1_slope=gate_slope)
         _dgrad_launch(a, dz.device, 9 if ksize == 3 else 1)
     if need_w:
         dw = torch.empty_like(weight)
         db = torch.empty(cout, device=dz.device, dtype=torch.float32) if has_bias else None
         a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad],
                                x1=ptr(x1), x2=ptr(x2), dz=ptr(dz), dw=ptr(dw), dbias=ptr(db), workspace=None,
-                               workspace_floats=0)
-        n = l.wmd_conv_wgrad_workspace_floats(C.byref(a))
-        ws = torch.empty(max(n, 1), device=dz.device, dtype=torch.float32)
-        a.workspace, a.workspace_floats = ptr(ws), n
-        check(l.wmd_conv_wgrad(C.byref(a), s), "wmd_conv_wgrad")
+                               workspace_floats=0, tune_cfg=0, tune_nsplit=0)
+        _wgrad_launch(a, dz.device)
     return dx1, dw, db
 
 
-def head3x3(xp, weight_p, bias_p, xn=None, weight_n=None, bias_n=None, pad="reflect", mode=0, scale=1.0):
+def head3x3(xp, weight_p, bias_p, xn=None, weight_n=None, bias_n=None, pad="reflect", mode=0, scale=1.0, x_gate=None):
+    """x_gate: backward-only hint as conv2d_fused's x1_gate (xp / xn are outputs of that activation: their gradients come
+    back multiplied by its derivative)."""
     _require_gpu(xp, weight_p, bias_p, xn, weight_n, bias_n)
-    return _HeadFn.apply(xp, weight_p, bias_p, xn, weight_n, bias_n, pad, mode, scale)
+    return _HeadFn.apply(xp, weight_p, bias_p, xn, weight_n, bias_n, pad, mode, scale, x_gate)
+
+
+class _StackedHeadsFn(torch.autograd.Function):
+    """All wavelet heads of one decoder level in training mode (depth_decoder.py:104-136): 2 (or, with the LL head of the
+    coarsest level, 3) chains  Conv1x1 -> LeakyReLU(0.1) -> Conv3x3(refl) -> sigmoid  of the SAME input, combined as
+    yh = s (sigma+ - sigma-) [, yl = s_ll sigma_ll].
+
+    Forward: ONE stacked 1x1 GEMM (x read once) + the 3x3 head kernel on channel slices of its output.
+    Backward: the heads are handled as one convolution pair with stacked / block-diagonal weights, so every stage is a
+    single launch over both (three) heads: the 3x3 weight gradient ([n_out, Ct, 3, 3]: the off-diagonal blocks are
+    computed and dropped -- they ride in MFMA rows that would be padding anyway), the 3x3 data gradient (returned already
+    multiplied by LeakyReLU'(mid)), the 1x1 weight gradient and the 1x1 data gradient (multiplied by x_gate'(x) when x is
+    itself an activation output of the caller).  No per-head dgrad / wgrad / act_bwd launches, no autograd accumulation of
+    per-head dx contributions.
+
+    inputs: x, x_gate, scale_hf, scale_ll, then (w1, b1, w3, b3) of the + head, the - head and optionally the LL head."""
+
+    @staticmethod
+    def forward(ctx, x, x_gate, scale_hf, scale_ll, *params):
+        l = _lib.lib()
+        x = _c(x)
+        heads = [params[i:i + 4] for i in range(0, len(params), 4)]       # [+, -, (LL)]
+        has_ll = len(heads) == 3
+        order = ([2] if has_ll else []) + [0, 1]                            # stacked channel order: [LL, +, -]
+        w1s, b1s = [heads[k][0] for k in order], [heads[k][1] for k in order]
+        mid = conv1x1_stacked_nograd(x, w1s, b1s, act="leaky", slope=0.1)
+        offs, o = {}, 0
+        for k in order:
+            offs[k] = o
+            o += heads[k][0].shape[0]
+        B, Ct, H, W = mid.shape
+        plane = H * W
+        base = mid.data_ptr()
+
+        def run(mode, scale, kp, kn=None):
+            w3p, b3p = heads[kp][2], heads[kp][3]
+            cout = w3p.shape[0]
+            y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+            sp = torch.empty_like(y)
+            sn = torch.empty_like(y) if kn is not None else None
+            a = _lib.HeadArgs(B=B, H=H, W=W, C=w3p.shape[1], Cout=cout, pad_mode=PAD["reflect"], mode=mode, scale=float(scale),
+                              xp=base + 4 * offs[kp] * plane, wgt_p=ptr(_c(w3p.detach())), bias_p=ptr(b3p),
+                              xn=None if kn is None else base + 4 * offs[kn] * plane,
+                              wgt_n=None if kn is None else ptr(_c(heads[kn][2].detach())),
+                              bias_n=None if kn is None else ptr(heads[kn][3]),
+                              y=ptr(y), sig_p=ptr(sp), sig_n=ptr(sn), xp_bstride=Ct * plane, xn_bstride=Ct * plane)
+            _head_launch(l, a, x.device)
+            return y, sp, sn
+
+        yh, sp, sn = run(2, scale_hf, 0, 1)
+        yl, sl = None, None
+        if has_ll:
+            yl, sl, _ = run(1, scale_ll, 2)
+        ctx.save_for_backward(x, mid, sp, sn, sl, *params)
+        ctx.meta = (x_gate, float(scale_hf), float(scale_ll), has_ll, order, offs)
+        ctx.mark_non_differentiable(mid)
+        return (yh, yl if has_ll else yh.new_empty(0), mid)
+
+    @staticmethod
+    def backward(ctx, d_yh, d_yl, _d_mid):
+        l = _lib.lib()
+        x, mid, sp, sn, sl = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        x_gate, s_hf, s_ll, has_ll, order, offs = ctx.meta
+        heads = [params[i:i + 4] for i in range(0, len(params), 4)]
+        B, Ct, H, W = mid.shape
+        C_in = x.shape[1]
+        dev = x.device
+        # pre-sigmoid gradients of every head, stacked in the channel order of `mid`: [LL (1)], + (3), - (3)
+        parts = []
+        if has_ll:
+            parts.append(torch.zeros_like(sl) if d_yl is None or d_yl.numel() == 0 else _c(d_yl) * sl * (1.0 - sl) * s_ll)
+        d_yh = _c(d_yh)
+        parts.append(d_yh * sp * (1.0 - sp) * s_hf)
+        parts.append(d_yh * sn * (1.0 - sn) * (-s_hf))
+        dy3 = torch.cat(parts, 1)
+        n_out = dy3.shape[1]
+        rows, r = {}, 0
+        for k in order:
+            rows[k] = r
+            r += heads[k][2].shape[0]
+        # block-diagonal 3x3 filter [n_out, Ct, 3, 3] and stacked 1x1 filter [Ct, C, 1, 1]
+        w3bd = torch.zeros((n_out, Ct, 3, 3), device=dev, dtype=torch.float32)
+        for k in order:
+            w3 = heads[k][2].detach()
+            w3bd[rows[k]:rows[k] + w3.shape[0], offs[k]:offs[k] + w3.shape[1]] = w3
+        w1s = torch.cat([heads[k][0].detach() for k in order], 0)
+        # 3x3: weight gradient of the stacked filter (diagonal blocks are the heads' gradients) ...
+        dw3f = torch.empty_like(w3bd)
+        db3f = torch.empty(n_out, device=dev, dtype=torch.float32)
+        a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=Ct, up1=1, C2=0, Cout=n_out, ksize=3, pad_mode=PAD["reflect"], x1=ptr(mid), x2=None,
+                               dz=ptr(dy3), dw=ptr(dw3f), dbias=ptr(db3f), workspace=None, workspace_floats=0, tune_cfg=0,
+                               tune_nsplit=0)
+        _wgrad_launch(a, dev)
+        # ... and data gradient, gated by LeakyReLU'(mid): dzmid
+        dzmid = torch.empty_like(mid)
+        wpd = pack_weights(w3bd, dgrad=True)
+        wpdw = pack_weights_wino(w3bd, dgrad=True)
+        a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=Ct, up1=1, C2=0, Cout=n_out, ksize=3, pad_mode=PAD["reflect"], dz=ptr(dy3),
+                               wp_dgrad=ptr(wpd), dx1=ptr(dzmid), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
+                               tune_ksplit=0, wp_dgrad_wino=ptr(wpdw), x1_fwd=ptr(mid), x1_act=ACT["leaky"], x1_slope=0.1)
+        _dgrad_launch(a, dev, 9)
+        # 1x1: weight gradient of the stacked filter ...
+        dw1f = torch.empty_like(w1s)
+        db1f = torch.empty(Ct, device=dev, dtype=torch.float32)
+        a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], x1=ptr(x), x2=None,
+                               dz=ptr(dzmid), dw=ptr(dw1f), dbias=ptr(db1f), workspace=None, workspace_floats=0, tune_cfg=0,
+                               tune_nsplit=0)
+        _wgrad_launch(a, dev)
+        # ... and data gradient (one GEMM over all heads' mid channels), gated by the caller's activation if x has one
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gate_act, gate_slope = (ACT[x_gate[0]], float(x_gate[1])) if x_gate else (0, 0.0)
+            wpd1 = pack_weights(w1s, dgrad=True)
+            a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], dz=ptr(dzmid),
+                                   wp_dgrad=ptr(wpd1), dx1=ptr(dx), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
+                                   tune_ksplit=0, wp_dgrad_wino=None, x1_fwd=ptr(x) if gate_act else None, x1_act=gate_act,
+                                   x1_slope=gate_slope)
+            _dgrad_launch(a, dev, 1)
+        grads = []
+        for k in range(len(heads)):
+            w1, _b1, w3, _b3 = heads[k]
+            c1, c3 = w1.shape[0], w3.shape[0]
+            grads += [dw1f[offs[k]:offs[k] + c1].reshape(w1.shape), db1f[offs[k]:offs[k] + c1],
+                      dw3f[rows[k]:rows[k] + c3, offs[k]:offs[k] + w3.shape[1]].contiguous(), db3f[rows[k]:rows[k] + c3]]
+        return (dx, None, None, None) + tuple(grads)
+
+
+def stacked_heads(x, head_p, head_n, scale_hf, head_ll=None, scale_ll=1.0, x_gate=None, return_mid=False):
+    """Training-mode wavelet heads of one level (see _StackedHeadsFn).  head_* = (w1, b1, w3, b3).
+    Returns (yh [B,3,H,W], yl [B,1,H,W] or None)."""
+    params = tuple(head_p) + tuple(head_n) + (tuple(head_ll) if head_ll is not None else ())
+    _require_gpu(x, *params)
+    yh, yl, mid = _StackedHeadsFn.apply(x, x_gate, scale_hf, scale_ll, *params)
+    if return_mid:   # [B, (C/4 +) 2C, H, W]: LeakyReLU outputs in the order [LL], +, - (diagnostics; carries no gradient)
+        return yh, (yl if head_ll is not None else None), mid
+    return yh, (yl if head_ll is not None else None)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -111,3 +111,50 @@ def tune(key, taps, launch):
     if os.environ.get("WMD_TUNE_VERBOSE"):
         print("[wmd tuner] %s -> %s ksplit %d (%.1f us)" % (key, names[cfg - 1], ks, t * 1e3))
     return (cfg, ks)
+
+
+def choose(key, cands, launch):
+    """Generic form for the other kernel families (weight gradient): cands = [(label, arg), ...], launch(arg) -> status.
+    Returns the arg of the fastest candidate (min of 2 runs each, then a 5-run play-off between the best three); the
+    winner's LABEL is cached under `key`, so the cache survives table edits.  With tuning disabled or inside a stream
+    capture the first candidate (the library's own model) is returned."""
+    _load()
+    hit = _cache.get(key)
+    if hit is not None:
+        for label, arg in cands:
+            if label == hit[0]:
+                return arg
+    if not enabled or torch.cuda.is_current_stream_capturing() or len(cands) == 1:
+        return cands[0][1]
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+
+    def t_of(arg, reps):
+        best = float("inf")
+        for _ in range(reps):
+            e0.record()
+            st = launch(arg)
+            e1.record()
+            e1.synchronize()
+            if st != 0:
+                return None
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    res = []
+    for label, arg in cands:
+        if launch(arg) != 0:          # warm-up run doubles as the validity check
+            continue
+        t = t_of(arg, 2)
+        if t is not None:
+            res.append((t, label, arg))
+    if not res:
+        return cands[0][1]
+    res.sort(key=lambda r: r[0])
+    final = sorted(((t_of(arg, 5), label, arg) for _, label, arg in res[:3]), key=lambda r: r[0])
+    t, label, arg = final[0]
+    _cache[key] = (label, 0)
+    _save()
+    if os.environ.get("WMD_TUNE_VERBOSE"):
+        print("[wmd tuner] %s -> %s (%.1f us)" % (key, label, t * 1e3))
+    return arg
