@@ -94,8 +94,9 @@ def _train_setup(kind, args, rank, world, dev):
     kitti: BASELINE.json configs[2] -- ResNet encoder (PyTorch/MIOpen) + HIP wavelet decoder forward/backward, loss =
            sum_s mean|disp_s - target_s|, Adam (trainer.py:96-98,208-212).
     nyu:   BASELINE.json configs[4] -- DenseNet161 encoder + HIP DecoderWave at 640x480, the reference's supervised loss
-           (NYUv2/train.py:258,289-314): 0.1 * L1(bilinear-upsampled disp_s, depth) over the four scales + L1(LL3,
-           DWT_J4(depth).yl)/16, Adam.
+           (NYUv2/train.py:258,289-322): 0.1 * L1(bilinear-upsampled disp_s, depth) over the four scales (+ L1(LL3,
+           DWT_J4(depth).yl)/16 when the decoder logs ("wavelets", 3, "LL"): DecoderWave224 does, DecoderWave does not and
+           the reference then skips the term), Adam.
     One process per GPU; for world > 1 the gradients go through GradientExchange (RCCL: ~25 MB buckets, decoder first, on a
     side stream while the encoder backward still runs)."""
     from wavelet_monodepth_amd import ops, synth
@@ -133,7 +134,11 @@ def _train_setup(kind, args, rank, world, dev):
             for s in range(4):
                 pred = ops.upsample_bilinear(out[("disp", s)], (H // 2, W // 2), align_corners=True)
                 total = total + 0.1 * (pred - depth).abs().mean()
-            return total + (out[("wavelets", 3, "LL")] - yl_gt).abs().mean() / 16
+            try:      # train.py:316-322: DecoderWave logs its LL under ("wavelets", 2, "LL"), so the reference skips this term
+                total = total + (out[("wavelets", 3, "LL")] - yl_gt).abs().mean() / 16
+            except KeyError:
+                pass
+            return total
         what = "NYUv2 DenseNet161 %dx%d training step, batch %d per GPU, L1 on upsampled disparities + LL3 vs DWT(J=4) of the " \
                "ground truth (BASELINE.json configs[4])" % (W, H, B)
     params = list(enc.parameters()) + list(dec.parameters())

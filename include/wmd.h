@@ -131,6 +131,14 @@ typedef struct {
                            Direct kernels only (the Winograd configurations are skipped when it is set).             */
     int gate_act;       /* wmd_act of the gate                                          */
     float gate_slope;
+    /* Block-sparse execution (3x3; the threshold-gated sparse decoders on the dense MFMA kernels when several frames are
+     * decoded together): with out_mask [B,H,W] only the pixel tiles that contain an active output pixel are computed (every
+     * block tests its own tile's mask bytes and returns when there is none), outputs outside the mask are written as 0 and
+     * tiles without active pixels are NOT touched (y must be zero-initialised); with in_mask [B,H,W] a padded input
+     * position outside the mask reads 0 for x1 and x2 alike -- the mask test after the coordinate padding of
+     * sparse_conv3x3 (KITTI/layers.py:439-453).  No split-K in this mode.                                            */
+    const uint8_t* in_mask;
+    const uint8_t* out_mask;
 } wmd_conv_args;
 
 /* Fused  upsample(x1) ++ x2  ->  pad  ->  conv kxk  ->  + bias  ->  activation.
@@ -333,6 +341,10 @@ typedef struct {
 } wmd_dilate_spec;
 /* All dilated variants of one mask in a single launch (n <= 8). */
 int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wmd_dilate_spec* specs, int n, void* stream);
+/* Batched forms (extension: the reference's sparse decoder asserts batch 1, depth_decoder.py:297; on a 256-CU GPU one
+ * 640x192 frame cannot fill the machine, so B frames -- each with its own range, threshold mask, pixel lists and counts --
+ * go through the SAME launches): mask [B,h,w], every specs[i].out [B,h*up,w*up].                                        */
+int wmd_mask_dilate_multi_b(const uint8_t* mask, int B, int h, int w, const wmd_dilate_spec* specs, int n, void* stream);
 
 /* wmd_minmax + wmd_mask_threshold + wmd_mask_dilate_multi of one decoder level in ONE launch
  * (depth_decoder.py:308-319): thr = (max(yl) - min(yl)) * thresh_ratio over yl[n_yl]; base[p] = max_b |yh[b,p]| > thr
@@ -341,6 +353,10 @@ int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wmd_dilate_sp
  * three separate calls (min/max are order-independent, the threshold is the same fp32 expression).          */
 int wmd_mask_level(const float* yl, size_t n_yl, const float* yh, float thresh_ratio, int h, int w,
                    const wmd_dilate_spec* specs, int n, void* stream);
+/* batched: yl [B,n_yl], yh [B,3,h,w], outputs [B,...]; the range (max - min) is taken per frame.  minmax_scratch: optional
+ * [B,2] device floats -- with it the ranges come from one extra launch instead of a whole-plane reduction in every block */
+int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, float thresh_ratio, int B, int h, int w,
+                     const wmd_dilate_spec* specs, int n, float* minmax_scratch, void* stream);
 
 typedef struct {
     const uint8_t* mask;   /* [npix]                                                               */
@@ -351,6 +367,9 @@ typedef struct {
 /* Stream compaction (mask2idxmap / mask2yx, KITTI/layers.py:371-389) of up to 8 masks in one launch:
  * one workgroup per mask, wavefront ballot + popcount prefix sums, raster order preserved.        */
 int wmd_mask_compact_multi(const wmd_compact_spec* specs, int n, void* stream);
+/* batched: specs[i].mask / .coords are [B,npix]; specs[i].nnz points at the count of (frame 0, mask i) of an int32 [B,n]
+ * array (the counts of one frame are contiguous)                                                                      */
+int wmd_mask_compact_multi_b(const wmd_compact_spec* specs, int n, int B, void* stream);
 
 typedef struct {
     int H, W;              /* output resolution                                                    */
@@ -378,6 +397,9 @@ typedef struct {
                                   * 16-pixel tile while (tiles x slices) stays below this count, and take longer
                                   * channel ranges of separate tiles beyond it (decided on the device from *out_nnz);
                                   * 1 = never split, INT_MAX = always split.  Results agree to fp32 rounding.      */
+    int B;                       /* frames decoded by this launch (0 or 1: one).  x1 [B,C1tot,..], x2 [B,C2,H,W], in_mask
+                                  * [B,H,W], out_coords [B,max_out], y [B,Cout,H,W]; weights are shared               */
+    int nnz_stride;              /* int32 elements between the counts of consecutive frames (out_nnz + b*nnz_stride)  */
 } wmd_sparse_conv_args;
 
 /* Gather-GEMM convolution on the active pixels (sparse_conv3x3 / sparse_conv1x1 / sparse_upsample /

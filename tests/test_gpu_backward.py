@@ -260,3 +260,129 @@ def test_rccl_two_rank_exchange_equals_full_batch_gradient(dev, tmp_path):
     for n, p in list(enc.named_parameters()) + list(dec.named_parameters()):
         if p.grad is not None:
             assert_close(r0["grads"][n], p.grad, 5e-5, n)
+
+
+# ---- round 2: Winograd weight gradient, activation-derivative gating, stacked heads ---------------------------------------
+WINO_WGRAD_CASES = [
+    # B, C1, C2, up, Cout, H, W, pad
+    (2, 19, 0, 1, 7, 6, 10, "zero"),            # ragged channels, map smaller than a tile row
+    (1, 32, 64, 2, 32, 12, 40, "reflect"),      # upconv(1,1) structure (fused upsample + concat)
+    (2, 24, 0, 1, 40, 7, 21, "replicate"),      # odd sizes: tile overhang in both directions
+    (1, 64, 0, 1, 3, 16, 48, "reflect"),        # a head's Cout = 3 filter (16-row out-channel tiles)
+    (3, 8, 0, 1, 16, 2, 2, "reflect"),          # smallest legal reflect size
+]
+
+
+@pytest.mark.parametrize("case", WINO_WGRAD_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_wgrad_winograd_every_configuration_vs_oracle(dev, case):
+    """conv_wgrad_wino_kernel: every entry of the Winograd F(2x2,3x3) weight-gradient table forced through
+    wmd_conv_wgrad_args.tune_cfg (and two pixel splits), plus the direct kernel (tune_cfg = -1), against autograd through
+    the oracle's convolution.  dU = sum_tiles (A dY A^T) (x) (B^T d B), dg = G^T dU G is exact algebra: 2e-5 like the direct
+    form."""
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib
+    B, C1, C2, up, Cout, H, W, pad = case
+    x1 = t(synth.normal((B, C1, H // up, W // up), "wwx1", 5)).requires_grad_(False)
+    x2 = t(synth.normal((B, C2, H, W), "wwx2", 5)) if C2 else None
+    w = t(synth.normal((Cout, C1 + C2, 3, 3), "www", 5)).requires_grad_(True)
+    b = t(synth.normal((Cout,), "wwb", 5)).requires_grad_(True)
+    dz = t(synth.normal((B, Cout, H, W), "wwdz", 5))
+    xin = R.up2(x1) if up == 2 else x1
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    (R.conv3x3(xin, w, b, pad) * dz).sum().backward()
+    l = _lib.lib()
+    g = lambda v: None if v is None else v.to(dev)
+    x1d, x2d, dzd = g(x1), g(x2), g(dz)
+    names = [l.wmd_conv_wgrad_config_name(i).decode() for i in range(l.wmd_conv_wgrad_num_configs())]
+    assert len(names) >= 9 and all(n.startswith("conv_wgrad_wino_kernel<") for n in names)
+    tested = 0
+    for cfg in [-1] + list(range(1, len(names) + 1)):
+        for ns in (0, 3):
+            dw = torch.full((Cout, C1 + C2, 3, 3), float("nan"), device=dev)
+            db = torch.full((Cout,), float("nan"), device=dev)
+            a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=C2, Cout=Cout, ksize=3, pad_mode=_lib.PAD[pad], x1=x1d.data_ptr(),
+                                   x2=None if x2d is None else x2d.data_ptr(), dz=dzd.data_ptr(), dw=dw.data_ptr(), dbias=db.data_ptr(),
+                                   workspace=None, workspace_floats=0, tune_cfg=cfg, tune_nsplit=ns)
+            n = l.wmd_conv_wgrad_workspace_floats(C.byref(a))
+            ws = torch.empty(max(n, 1), device=dev)
+            a.workspace, a.workspace_floats = ws.data_ptr(), n
+            _lib.check(l.wmd_conv_wgrad(C.byref(a), torch.cuda.current_stream().cuda_stream), "cfg %d" % cfg)
+            what = "direct" if cfg < 0 else names[cfg - 1]
+            assert_close(dw, w.grad, 2e-5, "dW %s nsplit %d" % (what, ns))
+            assert_close(db, b.grad, 2e-5, "db %s nsplit %d" % (what, ns))
+            tested += 1
+    assert tested == 2 * (len(names) + 1)
+
+
+def test_activation_gating_equals_separate_activation_backward(dev):
+    """conv -> ELU -> {conv 3x3 (upsampled + skip), conv 1x1}: with x1_gate on both consumers and grad_is_dz on the producer
+    (what the decoders do in training) every gradient equals the ungated graph's and the oracle's."""
+    from wavelet_monodepth_amd import ops
+    x = t(synth.normal((2, 12, 6, 10), "gx", 8)).requires_grad_(True)
+    skip = t(synth.normal((2, 5, 12, 20), "gs", 8)).requires_grad_(True)
+    (w0, b0), (w1, b1), (w2, b2) = [[t(a).requires_grad_(True) for a in synth.conv_params(n, co, ci, k, 8)]
+                                    for n, co, ci, k in (("g0", 16, 12, 3), ("g1", 7, 21, 3), ("g2", 9, 16, 1))]
+    elu = torch.nn.functional.elu
+    y = elu(R.conv3x3(x, w0, b0, "reflect"))
+    o1 = torch.nn.functional.leaky_relu(R.conv3x3(torch.cat([R.up2(y), skip], 1), w1, b1, "reflect"), 0.1)
+    o2 = R.conv1x1(y, w2, b2)
+    ((o1 ** 2).sum() + (o2 ** 2).sum()).backward()
+    leaves = [x, skip, w0, b0, w1, b1, w2, b2]
+    for gated in (False, True):
+        d = [v.detach().to(dev).requires_grad_(True) for v in leaves]
+        gx, gs, gw0, gb0, gw1, gb1, gw2, gb2 = d
+        gate = ("elu", 0.0) if gated else None
+        yy = ops.conv2d_fused(gx, gw0, gb0, pad="reflect", act="elu", grad_is_dz=gated)
+        p1 = ops.conv2d_fused(yy, gw1, gb1, x2=gs, up1=2, pad="reflect", act="leaky", slope=0.1, x1_gate=gate)
+        p2 = ops.conv2d_fused(yy, gw2, gb2, pad="zero", x1_gate=gate)
+        ((p1 ** 2).sum() + (p2 ** 2).sum()).backward()
+        for a_, b_, name in zip(d, leaves, ("x", "skip", "w0", "b0", "w1", "b1", "w2", "b2")):
+            assert_close(a_.grad, b_.grad, GRAD_TOL, "%s (gated=%s)" % (name, gated))
+
+
+def test_stacked_heads_equal_per_head_operators_and_the_oracle(dev):
+    """ops.stacked_heads (one launch per stage over the +, - and LL heads) against the per-head operator path and against
+    autograd through the oracle, values and every gradient."""
+    from wavelet_monodepth_amd import ops
+    C, H, W, B = 64, 10, 24, 2
+    x = t(synth.normal((B, C, H, W), "shx", 9))
+    mk = lambda tag, mid, out: [t(a) for a in synth.conv_params(tag + "1", mid, C, 1, 9)] + [t(a) for a in synth.conv_params(tag + "3", out, mid, 3, 9)]
+    hp, hn, hl = mk("shp", C, 3), mk("shn", C, 3), mk("shl", C // 4, 1)
+    gyh = t(synth.normal((B, 3, H, W), "shgy", 9))
+    gyl = t(synth.normal((B, 1, H, W), "shgl", 9))
+    lk = lambda v: torch.nn.functional.leaky_relu(v, 0.1)
+
+    def oracle(xx, p, n, ll):
+        sig = lambda h: torch.sigmoid(R.conv3x3(lk(R.conv1x1(xx, h[0], h[1])), h[2], h[3], "reflect"))
+        return 4.0 * (sig(p) - sig(n)), 16.0 * sig(ll)
+
+    leaves = [x] + hp + hn + hl
+    ref = [v.clone().requires_grad_(True) for v in leaves]
+    yh_r, yl_r = oracle(ref[0], ref[1:5], ref[5:9], ref[9:13])
+    ((yh_r * gyh).sum() + (yl_r * gyl).sum()).backward()
+    d = [v.to(dev).requires_grad_(True) for v in leaves]
+    yh, yl = ops.stacked_heads(d[0], d[1:5], d[5:9], 4.0, head_ll=d[9:13], scale_ll=16.0)
+    assert float((yh.cpu() - yh_r).abs().max()) < 2e-5 and float((yl.cpu() - yl_r).abs().max()) < 4e-5
+    ((yh * gyh.to(dev)).sum() + (yl * gyl.to(dev)).sum()).backward()
+    for a_, b_, k in zip(d, ref, range(13)):
+        assert_close(a_.grad, b_.grad, GRAD_TOL, "stacked heads: leaf %d" % k)
+    # two heads only (levels 3..1)
+    d2 = [v.to(dev).requires_grad_(True) for v in leaves[:9]]
+    yh2, none = ops.stacked_heads(d2[0], d2[1:5], d2[5:9], 4.0)
+    assert none is None and float((yh2 - yh).abs().max()) < 1e-6
+
+
+def test_kitti_decoder_per_head_training_path_still_matches_reference_gradients(dev):
+    """dec.stack_heads = False keeps the round-1 per-head operators (with the new gating); same reference gradients."""
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    g = load_golden("kitti_dense_r18_64x64_grads.npz")
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=1).to(dev)
+    dec.stack_heads = False
+    feats = [f.to(dev).requires_grad_(True) for f in kitti_feats(2, 64, 64)]
+    out = dec(feats)
+    sum(out[("disp", s)].mean() for s in range(4)).backward()
+    for k, f in enumerate(feats):
+        assert_close(f.grad, g["dfeat%d" % k], 1e-4, "dfeat%d" % k)
+    for name, p in dec.named_parameters():
+        assert_close(sample(p.grad.cpu().numpy()), g["d|" + name], 1e-4, name)

@@ -284,3 +284,38 @@ def test_nyu_sparse_decoder_vs_reference_golden_with_reference_masks(dev):
     force = {lvl: t(gold["wavelet_mask|%d" % (1 - lvl)])[0, 0, ::2, ::2] for lvl in (0, 1)}
     out = _nyu(dev)([f[:1].to(dev) for f in nyu_feats(2, 64, 96, NYU_ENC)], 0.1, _force_masks=force)
     _check_nyu(out, gold)
+
+
+@pytest.mark.parametrize("thr,forced", [(0.15, False), (0.05, True), (2.0, False)])
+def test_sparse_decoder_batched_equals_per_frame(dev, thr, forced):
+    """Extension over the reference's batch-1 assert (depth_decoder.py:297): B frames decoded through the same launches,
+    each with its own coefficient range, masks, pixel lists and counts.  Every per-frame output -- maps, the five mask
+    families, the integer op model -- must equal the batch-1 decode of that frame; eager and from the replayed graph."""
+    sp = _decoder(dev, seed=3)
+    B = 3
+    frames = [[f.to(dev) for f in kitti_feats(1, 96, 160, seed=20 + k)] for k in range(B)]
+    batch = [torch.cat([fr[j] for fr in frames], 0) for j in range(5)]
+    force_b = force_k = None
+    if forced:
+        gen = torch.Generator().manual_seed(7)
+        shapes = {3: (6, 10), 2: (12, 20), 1: (24, 40)}
+        force_b = {i: (torch.rand((B,) + hw, generator=gen) < 0.25).to(torch.uint8).to(dev) for i, hw in shapes.items()}
+        force_k = [{i: m[k].clone() for i, m in force_b.items()} for k in range(B)]
+    singles = [dict(sp(frames[k], thr, _force_masks=None if not forced else force_k[k]).items()) for k in range(B)]
+    for graph in (False, True):
+        sp.enable_graph(graph)
+        for _ in range(2 if graph else 1):
+            out = sp(batch, thr, _force_masks=force_b)
+        assert isinstance(out["total_ops"], list) and len(out["total_ops"]) == B
+        for k in range(B):
+            for key, ref in singles[k].items():
+                v = out[key]
+                if torch.is_tensor(ref):
+                    if ref.dtype == torch.bool:
+                        assert torch.equal(v[k:k + 1], ref), "frame %d %s" % (k, key_str(key))
+                    else:
+                        # (a batch runs the trunk on the block-sparse Winograd kernels, one frame on the gather-GEMM)
+                        assert_close(v[k:k + 1], ref, 1e-5, "frame %d %s" % (k, key_str(key)))
+                else:
+                    assert v[k] == ref, "frame %d %s: %s vs %s" % (k, key_str(key), v[k], ref)
+    sp.enable_graph(False)

@@ -62,6 +62,73 @@ if "sparse" in which:
         print("sparse: injected density %.2f -> masks %.2f %.2f %.2f  total_ops %.3f G  %.3f ms  %.0f frames/s" % (
             p, dens[0], dens[1], dens[2], out["total_ops"] / 1e9, t * 1e3, 1 / t))
 
+if "sparse-throughput" in which:
+    # BASELINE config 4 as a THROUGHPUT question: a single 640x192 frame cannot fill 256 CUs (dense: ~25 dependent launches,
+    # sparse: ~35, both latency-bound), so independent frames are decoded concurrently -- K captured graphs replayed on K
+    # streams (the sparse forward never waits for the host: total_ops is lazy) -- against the dense decoder run the same
+    # way and as one batch of K.
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder, SparseDepthWaveProgressiveDecoder
+    chans = [64, 64, 128, 256, 512]
+    K = 12
+    sp = synth.fill_state_dict(SparseDepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
+    dn = DepthWaveProgressiveDecoder(np.array(chans)).to(dev)
+    dn.load_state_dict(sp.state_dict())
+    dn.two_stream_graphs = False
+    sp._graphs._max = dn._graphs._max = 4 * K
+    frames = [[torch.from_numpy(f).to(dev) for f in synth.encoder_features(1, 192, 640, chans, seed=10 + k)] for k in range(K)]
+    batch = [torch.cat([fr[j] for fr in frames], 0) for j in range(5)]
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    sp.enable_graph(True)
+    dn.enable_graph(True)
+
+    def concurrent(fn, n=20):
+        def once():
+            cur = torch.cuda.current_stream()
+            for k in range(K):
+                streams[k].wait_stream(cur)
+                with torch.cuda.stream(streams[k]):
+                    fn(k)
+            for k in range(K):
+                cur.wait_stream(streams[k])
+        t = timeit(once, n=n)
+        return t
+
+    with torch.no_grad():
+        t_b = timeit(lambda: dn(batch), n=20)
+        print("throughput: dense decoder, one batch of %d: %.3f ms  %.0f frames/s" % (K, t_b * 1e3, K / t_b))
+        t_d = concurrent(lambda k: dn(frames[k]))
+        print("throughput: dense decoder, %d frames on %d streams: %.3f ms  %.0f frames/s" % (K, K, t_d * 1e3, K / t_d))
+    # batched sparse decode: the K frames, each with its own masks, through ONE chain of launches
+    with torch.no_grad():
+        for p in (0.05, 0.10, 0.20, 0.50, 1.00):
+            fb = {i: (torch.from_numpy(synth.uniform((K, h, w), "bdens%d" % i, 3, 0.0, 1.0)) < p).to(torch.uint8).to(dev)
+                  for i, (h, w) in zip((3, 2, 1), ((12, 40), (24, 80), (48, 160)))}
+            out = sp(batch, 0.05, _force_masks=fb)
+            t_s = timeit(lambda: sp(batch, 0.05, _force_masks=fb), n=20)
+            print("throughput: sparse decoder, ONE batch of %d, injected density %.2f (mean total_ops %.3f G): %.3f ms  %.0f frames/s"
+                  % (K, p, float(np.mean(out["total_ops"])) / 1e9, t_s * 1e3, K / t_s))
+        for thr in (0.05, 0.10, 0.15, 0.20):
+            out = sp(batch, thr)
+            t_s = timeit(lambda: sp(batch, thr), n=20)
+            dens = [float(out[("wavelet_mask", s)].float().mean()) for s in (2, 1, 0)]
+            print("throughput: sparse decoder, ONE batch of %d, thresh %.2f (densities %.2f %.2f %.2f, mean total_ops %.3f G): %.3f ms  %.0f frames/s"
+                  % (K, thr, dens[0], dens[1], dens[2], float(np.mean(out["total_ops"])) / 1e9, t_s * 1e3, K / t_s))
+    for p in (0.10,):
+        forces = []
+        for k in range(K):
+            forces.append({i: (torch.from_numpy(synth.uniform((h, w), "dens%d_%d" % (i, k), 3, 0.0, 1.0)) < p).to(torch.uint8).to(dev)
+                           for i, (h, w) in zip((3, 2, 1), ((12, 40), (24, 80), (48, 160)))})
+        t_s = concurrent(lambda k: sp(frames[k], 0.05, _force_masks=forces[k]))
+        out = sp(frames[0], 0.05, _force_masks=forces[0])
+        print("throughput: sparse decoder, injected density %.2f (total_ops %.3f G), %d frames on %d streams: %.3f ms  %.0f frames/s"
+              % (p, out["total_ops"] / 1e9, K, K, t_s * 1e3, K / t_s))
+    for thr in (0.15,):
+        t_s = concurrent(lambda k: sp(frames[k], thr))
+        out = sp(frames[0], thr)
+        dens = [float(out[("wavelet_mask", s)].float().mean()) for s in (2, 1, 0)]
+        print("throughput: sparse decoder, thresh %.2f (densities %.2f %.2f %.2f, total_ops %.3f G), %d frames on %d streams: %.3f ms  %.0f frames/s"
+              % (thr, dens[0], dens[1], dens[2], out["total_ops"] / 1e9, K, K, t_s * 1e3, K / t_s))
+
 if "nyu" in which:
     from wavelet_monodepth_amd.nyu import DecoderWave
     enc = [96, 96, 192, 384, 2208]

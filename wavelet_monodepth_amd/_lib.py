@@ -22,7 +22,8 @@ class ConvArgs(C.Structure):
                 ("Cout", C.c_int), ("ksize", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int), ("slope", C.c_float),
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
-                ("wp_wino", C.c_void_p), ("gate", C.c_void_p), ("gate_act", C.c_int), ("gate_slope", C.c_float)]
+                ("wp_wino", C.c_void_p), ("gate", C.c_void_p), ("gate_act", C.c_int), ("gate_slope", C.c_float),
+                ("in_mask", C.c_void_p), ("out_mask", C.c_void_p)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -103,7 +104,8 @@ class SparseConvArgs(C.Structure):
                 ("slope", C.c_float), ("x1", C.c_void_p), ("x2", C.c_void_p), ("in_mask", C.c_void_p),
                 ("out_coords", C.c_void_p), ("out_nnz", C.c_void_p), ("max_out", C.c_int),
                 ("wp", C.c_void_p), ("bias", C.c_void_p), ("wp2", C.c_void_p), ("bias2", C.c_void_p),
-                ("c1_off2", C.c_int), ("out_scale", C.c_float), ("y", C.c_void_p), ("split_waves", C.c_int)]
+                ("c1_off2", C.c_int), ("out_scale", C.c_float), ("y", C.c_void_p), ("split_waves", C.c_int),
+                ("B", C.c_int), ("nnz_stride", C.c_int)]
 
 
 _lib = None
@@ -147,6 +149,10 @@ SIGNATURES = {
     "wmd_mask_level": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int,
                        C.c_void_p]),
     "wmd_mask_compact_multi": (C.c_int, [C.POINTER(CompactSpec), C.c_int, C.c_void_p]),
+    "wmd_mask_dilate_multi_b": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),
+    "wmd_mask_level_b": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int,
+                         C.c_void_p, C.c_void_p]),
+    "wmd_mask_compact_multi_b": (C.c_int, [C.POINTER(CompactSpec), C.c_int, C.c_int, C.c_void_p]),
     "wmd_sparse_conv": (C.c_int, [C.POINTER(SparseConvArgs), C.c_void_p]),
     "wmd_upsample_bilinear_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
     "wmd_upsample_bilinear_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),

@@ -56,6 +56,12 @@ struct ConvKArgs {
     const float* gate;
     int gate_act;
     float gate_slope;
+    // block-sparse execution (threshold-gated sparse decoder on the dense kernels): a block whose TH x TW pixel tile holds
+    // no pixel of out_mask [B,H,W] returns at once (it tests the tile's mask bytes itself: no tile list, no counter, no
+    // extra launch); a padded input position outside in_mask [B,H,W] reads 0 (the mask test follows the coordinate padding,
+    // layers.py:439-453) and outputs outside out_mask are written as 0
+    const uint8_t* in_mask;
+    const uint8_t* out_mask;
 };
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, int NBUF = 2>
@@ -126,6 +132,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const int y0 = ty * TH, x0 = tx * TW;
     const int ks = blockIdx.z;
     const int H = a.H, W = a.W;
+    if (a.out_mask) {   // block-sparse: nothing to do for a tile without active output pixels (its outputs stay zero)
+        int any = 0;
+        for (int i = tid; i < TH * TW; i += (int)blockDim.x) {
+            const int yy = y0 + i / TW, xx = x0 + i % TW;
+            if (yy < H && xx < W) any |= a.out_mask[(size_t)b * H * W + (size_t)yy * W + xx];
+        }
+        if (!__syncthreads_or(any)) return;
+    }
 
     // ---- staging geometry: each thread owns NPOS patch positions for every channel ----------
     // Staging is LDS-DMA (buffer_load ... lds): a wavefront instruction gathers 64 arbitrary global dwords
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;  // tile overhang (H % TH != 0)
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
+        if (a.in_mask) ok = ok && a.in_mask[(size_t)b * H * W + gy * W + gx] != 0;   // sparse support of the virtual input
         ob2[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
         int sy = gy - a.shift1, sx = gx - a.shift1;
         if (a.up1 == 2) {
@@ -388,6 +403,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
                 if (final_out) v[r] = act_apply(v[r] + bv, a.act, a.slope);
             }
             float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
+            if (a.out_mask) {
+                const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W + ox;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ox + r < W && mp[r] == 0) v[r] = 0.f;
+            }
             if (final_out && a.gate) {
                 const float* gp = a.gate + ((size_t)b * a.Cout + co) * plane2 + (size_t)oy * W + ox;
                 if (vec_ok && ox + 3 < W) {
@@ -494,6 +515,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     const int y0 = ty * TH, x0 = tx * TW;
     const int ks = blockIdx.z;
     const int H = a.H, W = a.W;
+    if (a.out_mask) {   // block-sparse: nothing to do for a tile without active output pixels (its outputs stay zero)
+        int any = 0;
+        for (int i = tid; i < TH * TW; i += (int)blockDim.x) {
+            const int yy = y0 + i / TW, xx = x0 + i % TW;
+            if (yy < H && xx < W) any |= a.out_mask[(size_t)b * H * W + (size_t)yy * W + xx];
+        }
+        if (!__syncthreads_or(any)) return;
+    }
 
     // ---- staging geometry (identical to conv_fwd_kernel: see the comments there) -------------------------------
     constexpr unsigned kOOB = 0x80000000u;
@@ -509,6 +538,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
         ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
+        if (a.in_mask) ok = ok && a.in_mask[(size_t)b * H * W + gy * W + gx] != 0;   // sparse support of the virtual input
         ob2[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
         int sy = gy - a.shift1, sx = gx - a.shift1;
         if (a.up1 == 2) {
@@ -710,6 +740,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (final_out) yrow[j][e] = act_apply(yrow[j][e] + bv, a.act, a.slope);
+            if (a.out_mask) {
+                const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)(oy + j) * W + ox;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ox + e < W && mp[e] == 0) yrow[j][e] = 0.f;
+            }
             if (vec_ok && ox + 7 < W) {
                 *reinterpret_cast<float4*>(dst) = make_float4(yrow[j][0], yrow[j][1], yrow[j][2], yrow[j][3]);
                 *reinterpret_cast<float4*>(dst + 4) = make_float4(yrow[j][4], yrow[j][5], yrow[j][6], yrow[j][7]);
@@ -924,7 +960,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * c.TAPS;   // MFMA work (Winograd: 16 positions x 16 tiles)
         for (int ks = 1; ks <= 32; ++ks) {
             if (force_ks > 0 ? ks != force_ks : (ks & (ks - 1)) != 0 || ks > 16) continue;  // model: powers of two
-            if (ks > 1 && (!have_ws || nchunks < ks)) continue;
+            if (ks > 1 && (!have_ws || nchunks < ks || g->out_mask)) continue;   // block-sparse mode: one pass
             const int cps = (nchunks + ks - 1) / ks;
             const int ks_eff = (nchunks + cps - 1) / cps;
             if (ks > 1 && (size_t)ks_eff * g->B * g->Cout * g->H * g->W > ws_floats) continue;
@@ -1146,7 +1182,9 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.gate = g->gate;
     a.gate_act = g->gate_act;
     a.gate_slope = g->gate_slope;
-    if (g->gate && wino) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: the output gate is implemented for the direct kernels only");
+    a.in_mask = g->in_mask;
+    a.out_mask = g->out_mask;
+    if ((g->out_mask || g->in_mask) && taps != 9) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: masks (block-sparse execution) are a 3x3 feature");
     const int cob = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
     dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y), (unsigned)cob, (unsigned)plan.ksplit);
     if (env_int("WMD_CONV_VERBOSE", 0))

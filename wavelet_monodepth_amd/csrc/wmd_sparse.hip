@@ -22,6 +22,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void minmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out2) {
+    x += (size_t)blockIdx.x * n;      // blockIdx.x = frame of a batch: x [B,n], out2 [B,2]
+    out2 += 2 * blockIdx.x;
     float lo = INFINITY, hi = -INFINITY;
     for (size_t i = threadIdx.x; i < n; i += 1024) {
         const float v = x[i];
@@ -62,9 +64,11 @@ struct DilateKArgs {
     wmd_dilate_spec s[8];
 };
 
-__global__ void mask_dilate_multi_kernel(const uint8_t* __restrict__ mask, int h, int w, const DilateKArgs a) {
-    const wmd_dilate_spec sp = a.s[blockIdx.y];
+__global__ void mask_dilate_multi_kernel(const uint8_t* __restrict__ mask0, int h, int w, const DilateKArgs a) {
+    wmd_dilate_spec sp = a.s[blockIdx.y];
     const int H = h * sp.up, W = w * sp.up, r = sp.radius;
+    const uint8_t* mask = mask0 + (size_t)blockIdx.z * h * w;   // blockIdx.z = frame of the batch
+    sp.out += (size_t)blockIdx.z * H * W;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
         const int y = i / W, x = i % W;
         uint8_t v = 0;
@@ -86,6 +90,7 @@ __global__ void mask_dilate_multi_kernel(const uint8_t* __restrict__ mask, int h
 // itself (exact whatever the order), and a dilated pixel is the OR of the thresholded coefficients of the COARSE cells
 // its window covers -- the base mask is never read back.  Spec (1, 0) is the base mask itself.
 struct MaskLevelKArgs {
+    const float* mm;     // optional [B,2] precomputed (min, max) of every frame's yl: skips the in-block reduction
     const float* yl;
     const float* yh;
     float ratio;
@@ -121,36 +126,46 @@ __device__ __forceinline__ void mask_level_body(const MaskLevelKArgs& a, const w
     }
 }
 
-__global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a) {
-    float lo = INFINITY, hi = -INFINITY;
-    // eight independent loads per round (clamped index, the duplicate of the last element changes neither min nor max):
-    // a rolled one-load-per-iteration loop would be one memory round trip per 256 values
-    for (int i = threadIdx.x; i < a.n_yl; i += 256 * 8) {
-        float v[8];
+__global__ __launch_bounds__(256) void mask_level_kernel(MaskLevelKArgs a) {
+    // blockIdx.z = frame of the batch: its own LL plane, coefficients, range and masks
+    a.yl += (size_t)blockIdx.z * a.n_yl;
+    a.yh += (size_t)blockIdx.z * 3 * a.h * a.w;
+    float lo, hi;
+    if (a.mm) {          // batched decode: every block re-reducing its frame's whole LL plane was 40 us per level at 12 frames
+        lo = a.mm[2 * blockIdx.z];
+        hi = a.mm[2 * blockIdx.z + 1];
+    } else {
+        lo = INFINITY, hi = -INFINITY;
+        // eight independent loads per round (clamped index, the duplicate of the last element changes neither min nor max):
+        // a rolled one-load-per-iteration loop would be one memory round trip per 256 values
+        for (int i = threadIdx.x; i < a.n_yl; i += 256 * 8) {
+            float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = a.yl[min(i + k * 256, a.n_yl - 1)];
+            for (int k = 0; k < 8; ++k) v[k] = a.yl[min(i + k * 256, a.n_yl - 1)];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            lo = fminf(lo, v[k]);
-            hi = fmaxf(hi, v[k]);
+            for (int k = 0; k < 8; ++k) {
+                lo = fminf(lo, v[k]);
+                hi = fmaxf(hi, v[k]);
+            }
         }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, o));
-        hi = fmaxf(hi, __shfl_xor(hi, o));
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        __shared__ float slo[4], shi[4];
+        if ((threadIdx.x & 63) == 0) {
+            slo[threadIdx.x >> 6] = lo;
+            shi[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
     }
-    __shared__ float slo[4], shi[4];
-    if ((threadIdx.x & 63) == 0) {
-        slo[threadIdx.x >> 6] = lo;
-        shi[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
-    hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
     const float thr = (hi - lo) * a.ratio;   // same fp32 expression as mask_threshold_kernel
 
-    const wmd_dilate_spec sp = a.s[blockIdx.y];
+    wmd_dilate_spec sp = a.s[blockIdx.y];
+    sp.out += (size_t)blockIdx.z * (a.h * sp.up) * (a.w * sp.up);
     switch (sp.up == 2 ? sp.radius + 1 : 2 * sp.radius + 1) {
         case 1: mask_level_body<1>(a, sp, thr); break;
         case 2: mask_level_body<2>(a, sp, thr); break;
@@ -169,7 +184,11 @@ struct CompactKArgs {
 // bit field and counts them; counts are scanned inside the wavefront by shuffles and across the 16 wavefronts through
 // LDS (two barriers per 16 384 pixels); a thread then writes its own pixels in ascending order => raster order.
 __global__ __launch_bounds__(1024) void mask_compact_multi_kernel(const CompactKArgs a) {
-    const wmd_compact_spec sp = a.s[blockIdx.x];
+    wmd_compact_spec sp = a.s[blockIdx.x];
+    // blockIdx.y = frame of the batch: masks / lists are [B][npix], the counts [B][n masks]
+    sp.mask += (size_t)blockIdx.y * sp.npix;
+    sp.coords += (size_t)blockIdx.y * sp.npix;
+    sp.nnz += (size_t)blockIdx.y * gridDim.x;
     __shared__ int wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (reinterpret_cast<uintptr_t>(sp.mask) & 15) == 0;
@@ -226,6 +245,7 @@ struct SparseKArgs {
     int nci4, ncot, W1;
     int split_waves;   // (tiles x K-slices) that must stay in flight before a wave takes a longer K range
     size_t plane, plane1;
+    int nnz_stride;    // ints between the counts of consecutive frames (batched decode: blockIdx.z = frame)
 };
 
 // WK wavefronts share one (16-pixel tile, MR out-channel tiles) task and split the input-channel loop between them;
@@ -246,8 +266,20 @@ struct __attribute__((packed, aligned(4))) Window3 {
 };
 
 template <int MR, int TAPS, bool DUAL, int WK, int UN, bool ROWS>
-__global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs a) {
+__global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs a0) {
     static_assert(!ROWS || TAPS == 9, "row windows are a 3x3 feature");
+    // batched decode: every frame has its own activations, masks, pixel list and count; the weights are shared
+    SparseKArgs a = a0;
+    {
+        const size_t b = blockIdx.z;
+        wmd_sparse_conv_args& gm = a.g;
+        gm.x1 += b * gm.C1tot * a.plane1;
+        if (gm.x2) gm.x2 += b * gm.C2 * a.plane;
+        if (gm.in_mask) gm.in_mask += b * a.plane;
+        gm.out_coords += b * gm.max_out;
+        gm.out_nnz += b * a.nnz_stride;
+        gm.y += b * gm.Cout * a.plane;
+    }
     const wmd_sparse_conv_args& g = a.g;
     const int lane = threadIdx.x & 63;
     const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -272,20 +304,10 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
         if (ntile * (WK >> q) >= a.split_waves) sq = q;   // merge K slices only while enough wavefronts stay busy
     const int S = WK >> sq;
     const int tpb = WK / S;
-    if ((int)blockIdx.x * tpb * 16 >= nnz) return;      // whole block idle
-    const int tile = (int)blockIdx.x * tpb + wk / S;
     const int ks = wk % S;                               // this wave's K slice
-    const bool tile_ok = tile * 16 < nnz;                // wave-uniform; an idle wave still joins the barrier below
-    int praw = praw_s[0];
-#pragma unroll
-    for (int q = 1; q < NS; ++q) praw = sq == q ? praw_s[q] : praw;
-    const int pidx = tile * 16 + j;
-    const bool px_ok = pidx < nnz;
-    const int plive = __shfl(praw, lane & 48);           // executed by every lane; lane 16k holds pixel tile*16 (< nnz)
-    const int p = tile_ok ? (px_ok ? praw : plive) : 0;
-    const int oy = p / g.W, ox = p % g.W;
     const int Cin = g.C1 + g.C2;
     const int cot0 = blockIdx.y * MR;
+    __shared__ f32x4 red[WK > 1 ? WK : 1][DUAL ? 2 * MR : MR][64];
 
     float bias_v[MR][4], bias2_v[DUAL ? MR : 1][4];
 #pragma unroll
@@ -296,6 +318,27 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
             bias_v[m][r] = (g.bias && co < g.Cout) ? g.bias[co] : 0.f;
             if (DUAL) bias2_v[m][r] = (g.bias2 && co < g.Cout) ? g.bias2[co] : 0.f;
         }
+
+    // The grid is sized for the machine, not for the pixel capacity: a block walks the task sequence tb = blockIdx.x,
+    // blockIdx.x + gridDim.x, ... while tasks remain (device-side count).  With a capacity grid a 10 % dense level spent its
+    // time launching and retiring idle blocks (12 frames x 1920 tile slots x out-channel groups: 87 us per call for ~10 us
+    // of work).  The first task still uses the pixel-list entries requested together with the count.
+    for (int tb = blockIdx.x; tb * tpb * 16 < nnz; tb += gridDim.x) {
+    const int tile = tb * tpb + wk / S;
+    const bool tile_ok = tile * 16 < nnz;                // wave-uniform; an idle wave still joins the barriers below
+    int praw;
+    if (tb == (int)blockIdx.x) {
+        praw = praw_s[0];
+#pragma unroll
+        for (int q = 1; q < NS; ++q) praw = sq == q ? praw_s[q] : praw;
+    } else {
+        praw = g.out_coords[min(tile * 16 + j, g.max_out - 1)];
+    }
+    const int pidx = tile * 16 + j;
+    const bool px_ok = pidx < nnz;
+    const int plive = __shfl(praw, lane & 48);           // executed by every lane; lane 16k holds pixel tile*16 (< nnz)
+    const int p = tile_ok ? (px_ok ? praw : plive) : 0;
+    const int oy = p / g.W, ox = p % g.W;
 
     // neighbour coordinates through the coordinate padding (layers.py:439-453); the input-mask test only gates the value
     int o1[TAPS], o2[TAPS];
@@ -415,7 +458,6 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
     }
 
     if (WK > 1 && S > 1) {   // S is block-uniform
-        __shared__ f32x4 red[WK][DUAL ? 2 * MR : MR][64];
         if (ks > 0) {
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
@@ -424,31 +466,34 @@ __global__ __launch_bounds__(64 * WK) void sparse_conv_kernel(const SparseKArgs 
             }
         }
         __syncthreads();
-        if (ks > 0) return;
-        for (int w = 1; w < S; ++w)
+        if (ks == 0) {
+            for (int w = 1; w < S; ++w)
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                acc[m] += red[wk + w][m][lane];
-                if (DUAL) acc2[m] += red[wk + w][MR + m][lane];
+                for (int m = 0; m < MR; ++m) {
+                    acc[m] += red[wk + w][m][lane];
+                    if (DUAL) acc2[m] += red[wk + w][MR + m][lane];
+                }
+        }
+    }
+    if (ks == 0 && tile_ok && px_ok) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (cot0 + m) * 16 + kq * 4 + r;
+                if (co < g.Cout) {
+                    float v = acc[m][r] + bias_v[m][r];
+                    v = g.out_scale * act_apply(v, g.act, g.slope);
+                    if (DUAL) {
+                        float u = acc2[m][r] + bias2_v[m][r];
+                        v = v - g.out_scale * act_apply(u, g.act, g.slope);
+                    }
+                    g.y[(size_t)co * a.plane + p] = v;
+                }
             }
     }
-    if (!tile_ok) return;
-    if (!px_ok) return;
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = (cot0 + m) * 16 + kq * 4 + r;
-            if (co < g.Cout) {
-                float v = acc[m][r] + bias_v[m][r];
-                v = g.out_scale * act_apply(v, g.act, g.slope);
-                if (DUAL) {
-                    float u = acc2[m][r] + bias2_v[m][r];
-                    v = v - g.out_scale * act_apply(u, g.act, g.slope);
-                }
-                g.y[(size_t)co * a.plane + p] = v;
-            }
-        }
+    if (WK > 1 && S > 1) __syncthreads();   // `red` is rewritten by the next task
+    }   // task loop
 }
 
 }  // namespace wmd
@@ -475,8 +520,13 @@ extern "C" int wmd_mask_threshold(const float* yh, const float* minmax, float th
 }
 
 extern "C" int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wmd_dilate_spec* specs, int n, void* stream) {
+    return wmd_mask_dilate_multi_b(mask, 1, h, w, specs, n, stream);
+}
+
+extern "C" int wmd_mask_dilate_multi_b(const uint8_t* mask, int B, int h, int w, const wmd_dilate_spec* specs, int n, void* stream) {
     if (!mask || !specs) return fail(WMD_ERR_BAD_ARG, "wmd_mask_dilate_multi: null pointer");
-    if (h <= 0 || w <= 0 || n <= 0 || n > 8) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_dilate_multi: h=%d w=%d n=%d", h, w, n);
+    if (B <= 0 || B > 65535 || h <= 0 || w <= 0 || n <= 0 || n > 8)
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_dilate_multi: B=%d h=%d w=%d n=%d", B, h, w, n);
     DilateKArgs a;
     int maxpix = 0;
     for (int i = 0; i < n; ++i) {
@@ -485,18 +535,29 @@ extern "C" int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wm
         a.s[i] = specs[i];
         maxpix = std::max(maxpix, h * specs[i].up * w * specs[i].up);
     }
-    ProfScope prof("mask_dilate_multi_kernel", 25.0 * maxpix * n, 2.0 * maxpix * n, (hipStream_t)stream);
-    hipLaunchKernelGGL(mask_dilate_multi_kernel, dim3(std::min((maxpix + 255) / 256, 1024), n), dim3(256), 0,
+    ProfScope prof("mask_dilate_multi_kernel", 25.0 * maxpix * n * B, 2.0 * maxpix * n * B, (hipStream_t)stream);
+    hipLaunchKernelGGL(mask_dilate_multi_kernel, dim3(std::min((maxpix + 255) / 256, 1024), n, B), dim3(256), 0,
                        (hipStream_t)stream, mask, h, w, a);
     return check_launch("mask_dilate_multi_kernel");
 }
 
 extern "C" int wmd_mask_level(const float* yl, size_t n_yl, const float* yh, float thresh_ratio, int h, int w,
                               const wmd_dilate_spec* specs, int n, void* stream) {
+    return wmd_mask_level_b(yl, n_yl, yh, thresh_ratio, 1, h, w, specs, n, nullptr, stream);
+}
+
+extern "C" int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, float thresh_ratio, int B, int h, int w,
+                                const wmd_dilate_spec* specs, int n, float* minmax_scratch, void* stream) {
     if (!yl || !yh || !specs) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level: null pointer");
+    if (B <= 0 || B > 65535) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: B=%d", B);
     if (n_yl == 0 || n_yl > (size_t)1 << 24) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: n_yl=%zu", n_yl);
     if (h <= 0 || w <= 0 || n <= 0 || n > 8) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: h=%d w=%d n=%d", h, w, n);
     MaskLevelKArgs a;
+    a.mm = nullptr;
+    if (B > 1 && minmax_scratch) {   // one min/max launch per batch instead of a whole-plane reduction in every block of every frame
+        hipLaunchKernelGGL(minmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, yl, n_yl, minmax_scratch);
+        a.mm = minmax_scratch;
+    }
     a.yl = yl;
     a.yh = yh;
     a.ratio = thresh_ratio;
@@ -510,14 +571,18 @@ extern "C" int wmd_mask_level(const float* yl, size_t n_yl, const float* yh, flo
         a.s[i] = specs[i];
         maxpix = std::max(maxpix, h * specs[i].up * w * specs[i].up);
     }
-    ProfScope prof("mask_level_kernel", 25.0 * maxpix * n, 2.0 * maxpix * n + 16.0 * h * w, (hipStream_t)stream);
-    hipLaunchKernelGGL(mask_level_kernel, dim3(std::min((maxpix + 255) / 256, 1024), n), dim3(256), 0, (hipStream_t)stream, a);
+    ProfScope prof("mask_level_kernel", 25.0 * maxpix * n * B, (2.0 * maxpix * n + 16.0 * h * w) * B, (hipStream_t)stream);
+    hipLaunchKernelGGL(mask_level_kernel, dim3(std::min((maxpix + 255) / 256, 1024), n, B), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("mask_level_kernel");
 }
 
 extern "C" int wmd_mask_compact_multi(const wmd_compact_spec* specs, int n, void* stream) {
+    return wmd_mask_compact_multi_b(specs, n, 1, stream);
+}
+
+extern "C" int wmd_mask_compact_multi_b(const wmd_compact_spec* specs, int n, int B, void* stream) {
     if (!specs) return fail(WMD_ERR_BAD_ARG, "wmd_mask_compact_multi: null pointer");
-    if (n <= 0 || n > 8) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_compact_multi: n=%d", n);
+    if (n <= 0 || n > 8 || B <= 0 || B > 65535) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_compact_multi: n=%d B=%d", n, B);
     CompactKArgs a;
     double px = 0;
     for (int i = 0; i < n; ++i) {
@@ -526,8 +591,8 @@ extern "C" int wmd_mask_compact_multi(const wmd_compact_spec* specs, int n, void
         a.s[i] = specs[i];
         px += specs[i].npix;
     }
-    ProfScope prof("mask_compact_multi_kernel", px, 5.0 * px, (hipStream_t)stream);
-    hipLaunchKernelGGL(mask_compact_multi_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, a);
+    ProfScope prof("mask_compact_multi_kernel", px * B, 5.0 * px * B, (hipStream_t)stream);
+    hipLaunchKernelGGL(mask_compact_multi_kernel, dim3(n, B), dim3(1024), 0, (hipStream_t)stream, a);
     return check_launch("mask_compact_multi_kernel");
 }
 
@@ -557,23 +622,34 @@ extern "C" int wmd_sparse_conv(const wmd_sparse_conv_args* g, void* stream) {
     a.W1 = g->W / g->up1;
     a.plane = (size_t)g->H * g->W;
     a.plane1 = (size_t)(g->H / g->up1) * a.W1;
+    const int B = g->B > 1 ? g->B : 1;
+    if (B > 65535) return fail(WMD_ERR_BAD_SHAPE, "wmd_sparse_conv: B=%d", B);
+    a.nnz_stride = B > 1 ? g->nnz_stride : 0;
     static const int split_waves = [] { const char* e = getenv("WMD_SPARSE_SPLIT_WAVES"); return e ? atoi(e) : 2048; }();
     if (g->split_waves < 0) return fail(WMD_ERR_BAD_ARG, "wmd_sparse_conv: split_waves=%d", g->split_waves);
     a.split_waves = g->split_waves > 0 ? g->split_waves : split_waves;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (g->max_out + 15) / 16;
     const int taps = g->ksize == 3 ? 9 : 1;
-    ProfScope prof("sparse_conv_kernel", 0.0, 0.0, s);
+    char pname[96] = "sparse_conv_kernel";
+    if (g_prof_on && getenv("WMD_SPARSE_PROF_SHAPES"))   // development: one profile line per layer shape
+        snprintf(pname, sizeof(pname), "sparse_conv_kernel C%d+%d->%d k%d %dx%d%s", g->C1, g->C2, g->Cout, g->ksize, g->H, g->W,
+                 g->wp2 ? " dual" : "");
+    ProfScope prof(pname, 0.0, 0.0, s);
     // MR out-channel tiles per block: as few as keeps the grid near the machine size -- a sparse launch has far fewer
     // pixel tiles than the GPU has SIMDs, so out-channel tiles go to separate blocks (each re-gathers the same few
     // pixels out of L2) until the capacity grid reaches ~512 blocks (measured: tools/sparse_microbench.py); a full-density fine level keeps MR large and
     // gathers once.  UN K-steps per wave are in flight together: the whole K-slice of a wave when registers allow.
     static const int mr_force = [] { const char* e = getenv("WMD_SPARSE_MR"); return e ? atoi(e) : 0; }();
     int MR = 1;
-    while (MR < 4 && MR < a.ncot && (long)tiles * ((a.ncot + MR - 1) / MR) > 512) MR *= 2;
+    while (MR < 4 && MR < a.ncot && (long)tiles * B * ((a.ncot + MR - 1) / MR) > 512) MR *= 2;
     if (mr_force == 1 || mr_force == 2 || mr_force == 4) MR = std::min(mr_force, a.ncot >= 4 ? 4 : a.ncot >= 2 ? 2 : 1);
+    // grid.x: enough blocks to fill the machine a few times over, never more than the capacity (a block walks further tasks
+    // itself); WMD_SPARSE_GRID overrides the total block target (development)
+    static const int grid_target = [] { const char* e = getenv("WMD_SPARSE_GRID"); return e ? atoi(e) : 2048; }();
 #define WMD_SPARSE_LAUNCH(MR_, TAPS_, DUAL_, WK_, UN_, ROWS_)                                                          \
-    hipLaunchKernelGGL((sparse_conv_kernel<MR_, TAPS_, DUAL_, WK_, UN_, ROWS_>), dim3(tiles, (a.ncot + MR_ - 1) / MR_), \
+    hipLaunchKernelGGL((sparse_conv_kernel<MR_, TAPS_, DUAL_, WK_, UN_, ROWS_>),                                       \
+                       dim3(std::max(1, std::min(tiles, grid_target / (((a.ncot + MR_ - 1) / MR_) * B))), (a.ncot + MR_ - 1) / MR_, B), \
                        dim3(64 * WK_), 0, s, a)
     static const int rows_off = [] { const char* e = getenv("WMD_SPARSE_ROWS"); return e && atoi(e) == 0; }();
     if (taps == 9 && g->W >= 3 && a.W1 >= 3 && !rows_off) {

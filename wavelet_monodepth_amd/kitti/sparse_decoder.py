@@ -2,11 +2,15 @@
 (/root/reference/KITTI/networks/decoders/depth_decoder.py:171-428): same constructor, parameters and
 state_dict keys as the dense decoder (checkpoints are interchangeable), `forward(input_features,
 thresh_ratio=0.05, sparse_scales=[0,1,2,3])`, same output keys incl. the five mask families and the
-`total_ops` op model.  Batch 1, inference only.
+`total_ops` op model.  Inference only; batch 1 like the reference, or (extension) a batch of frames decoded together.
 
 Differences that are not observable in the outputs: activations stay dense and zero-initialised instead of
-being compacted (see include/wmd.h), there is ONE host synchronisation per forward (to turn the device-side
-pixel counts into the python-int `total_ops`), and nothing is printed (the reference prints 'sparse: i').
+being compacted (see include/wmd.h); the forward never waits for the GPU -- the python-int `total_ops` entries are
+resolved from the device-side pixel counts on first access (sparse_ops.LazyOpsDict), so independent frames can be
+decoded concurrently on several streams; nothing is printed (the reference prints 'sparse: i').
+`sparse_scales`: a level outside the list runs densely.  The reference only survives lists whose sparse levels are the
+finest ones (its dense branch keeps reading the stale dense activation of the last dense level and crashes on the channel
+mismatch); here a dense level below a sparse one simply convolves the zero-initialised sparse activations.
 """
 import os
 
@@ -115,6 +119,12 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                                 pad="reflect", mode=2, scale=2.0 ** (i - 1))
         return yl, yh.unsqueeze(1)
 
+    def _block_sparse(self, B):
+        """Trunk convolutions of the sparse levels: gather-GEMM over compacted pixel lists (one frame: shortest dependent
+        chain) or block-sparse execution of the dense kernels (several frames: throughput).  WMD_SPARSE_TILES=0/1 forces."""
+        e = os.environ.get("WMD_SPARSE_TILES")
+        return (B >= 2) if e is None else e == "1"
+
     def enable_graph(self, on=True):
         """Capture the whole device-side chain (≈35 launches, all pixel counts stay on the device) into one hipGraph
         per (inputs, threshold, scales) and replay it; only the python-int op model is computed on the host after."""
@@ -124,7 +134,10 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
 
     @torch.no_grad()
     def forward(self, input_features, thresh_ratio=0.05, sparse_scales=[0, 1, 2, 3], _force_masks=None):
-        assert input_features[-1].shape[0] == 1, "works with single input only"
+        # The reference asserts batch 1 ("works with single input only", depth_decoder.py:297).  Extension: a batch decodes
+        # B frames -- each with its own coefficient range, masks, pixel lists and counts -- through the SAME launches (one
+        # 640x192 frame is a few dozen to a few hundred 16-pixel tiles per launch and cannot fill 256 CUs); every per-frame
+        # output equals the batch-1 result, and the `total_ops` entries become lists with one integer per frame.
         forced_on_device = _force_masks is None or all(m.is_cuda for m in _force_masks.values())
         if self._graph_mode and forced_on_device:
             thr, scales = float(thresh_ratio), tuple(sparse_scales)
@@ -141,14 +154,14 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
 
     def _device_chain(self, input_features, thresh_ratio, sparse_scales, _force_masks):
         out = {}
-        x = input_features[-1]
+        x = input_features[-1].contiguous()
         dev = x.device
+        B = x.shape[0]           # frames decoded together: every frame has its own range, masks, pixel lists and counts
         sparse_scales = list(sparse_scales)
-        counters = []          # (level, nnz tensor [3]) resolved into python ints once, at the end
+        counters = []          # (level, nnz tensor [B,3]) resolved into python ints lazily
         static_ops = {}
         yl = yh = None
-        xbuf = None            # dense [C,h,w] activations carried between sparse levels
-        x = x.contiguous()
+        xbuf = None            # dense [B,C,h,w] activations carried between levels
         # every zero-initialised activation plane of the sparse levels comes out of ONE pooled buffer (one fill per
         # forward instead of four per level; at batch 1 the chain is launch-latency bound)
         pool_floats = 0
@@ -157,8 +170,8 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 hh, ww = input_features[i].shape[-2:]
                 c0w, c1w = self.convs[("upconv", i, 0)].conv.conv.weight, self.convs[("upconv", i, 1)].conv.conv.weight
                 cm = self.convs[("waveconv", i, 1)][0].conv.weight.shape[0]
-                pool_floats += sum(_round64(c * n) for c, n in ((c0w.shape[0], hh * ww), (c1w.shape[0], 4 * hh * ww),
-                                                                (2 * cm, 4 * hh * ww), (3, 4 * hh * ww)))
+                pool_floats += sum(_round64(B * c * n) for c, n in ((c0w.shape[0], hh * ww), (c1w.shape[0], 4 * hh * ww),
+                                                                    (2 * cm, 4 * hh * ww), (3, 4 * hh * ww)))
         pool = torch.zeros(pool_floats, device=dev) if pool_floats else None
         pool_used = [0]
 
@@ -175,20 +188,24 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             forced = _force_masks is not None and i in _force_masks
             if i == 4 and not forced:
                 # all-ones mask: every dilation of it is all ones too (MaxPool2d pads with -inf) -- one fill, five views
-                ones = torch.ones(2 * h * w + 3 * 4 * h * w, device=dev, dtype=torch.uint8)
-                lowres, upconv0 = ones[:h * w].view(h, w), ones[h * w:2 * h * w].view(h, w)
-                upsample_m, upconv1, wavelet = (ones[2 * h * w + k * 4 * h * w:2 * h * w + (k + 1) * 4 * h * w].view(2 * h, 2 * w)
+                ones = torch.ones(B * (2 * h * w + 3 * 4 * h * w), device=dev, dtype=torch.uint8)
+                lowres, upconv0 = ones[:B * h * w].view(B, h, w), ones[B * h * w:2 * B * h * w].view(B, h, w)
+                o4 = 2 * B * h * w
+                upsample_m, upconv1, wavelet = (ones[o4 + k * 4 * B * h * w:o4 + (k + 1) * 4 * B * h * w].view(B, 2 * h, 2 * w)
                                                 for k in range(3))
             elif forced:
-                mask = _force_masks[i].to(dev).reshape(h, w).to(torch.uint8).contiguous()
-                lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask, SPECS)
-            elif os.environ.get("WMD_SPARSE_UNFUSED_MASKS", "0") == "1":   # the three-launch form (parity tests)
+                mask = _force_masks[i].to(dev).reshape(-1, h, w).to(torch.uint8)
+                if mask.shape[0] != B:           # one injected mask shared by every frame
+                    mask = mask.expand(B, h, w)
+                lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask.contiguous(), SPECS)
+            elif os.environ.get("WMD_SPARSE_UNFUSED_MASKS", "0") == "1" and B == 1:   # the three-launch form (parity tests)
                 mask = S.mask_threshold(yh, S.minmax(yl), thresh_ratio)
-                lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask, SPECS)
+                lowres, upconv0, upsample_m, upconv1, wavelet = [m.unsqueeze(0) for m in S.dilate_multi(mask, SPECS)]
             else:
-                lowres, upconv0, upsample_m, upconv1, wavelet = S.mask_level(yl, yh, thresh_ratio, SPECS)
+                lowres, upconv0, upsample_m, upconv1, wavelet = [m.reshape(B, *m.shape[-2:]) for m in
+                                                                 S.mask_level(yl, yh, thresh_ratio, SPECS)]
             H2, W2 = 2 * h, 2 * w
-            b = lambda m: m.view(torch.bool).reshape(1, 1, *m.shape)
+            b = lambda m: m.view(torch.bool).reshape(B, 1, *m.shape[-2:])
             out[("lowres_mask", i - 1)] = b(lowres)
             out[("upconv0_mask", i - 1)] = b(upconv0)
             out[("upsample_mask", i - 1)] = b(upsample_m)
@@ -200,33 +217,43 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             if i in sparse_scales:
                 assert self.use_skips and i > 0 and yl is not None
                 scale_ops = level_static_ops(i, h, w, True)
-                (co0, co1, cow), nnz = S.compact_multi([upconv0, upconv1, wavelet])
-                src = xbuf if xbuf is not None else x[0]
+                (co0, co1, cow), nnz = S.compact_multi([upconv0, upconv1, wavelet])      # coords [B,npix], counts [B,3]
+                src = xbuf if xbuf is not None else x
                 C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
-                x0 = zeros(C0, h, w)
-                S.sparse_conv(x0, src, ops.pack_weights(c0.weight), c0.bias, C0, 3, co0, nnz.data_ptr(), h * w,
-                              in_mask=lowres, pad="reflect", act="elu")
-                skip = input_features[i - 1][0].contiguous()
-                x1 = zeros(C1_, H2, W2)
-                S.sparse_conv(x1, x0, ops.pack_weights(c1.weight), c1.bias, C1_, 3, co1, nnz.data_ptr() + 4, H2 * W2,
-                              x2=skip, up1=2, in_mask=upsample_m, pad="reflect", act="elu")
+                x0 = zeros(B, C0, h, w)
+                skip = input_features[i - 1].contiguous()
+                x1 = zeros(B, C1_, H2, W2)
+                if self._block_sparse(B):
+                    # several frames: the trunk convolutions run on the dense Winograd / MFMA kernels over the pixel TILES
+                    # that contain active pixels (tile list built on the device), input support and output mask folded
+                    # into the patch gather / the epilogue -- same values as the gather-GEMM, dense-kernel throughput
+                    ops._conv_fwd_raw(src, None, ops.pack_weights(c0.weight), c0.bias, C0, 3, "reflect", "elu", 0.0, 1,
+                                      ops.pack_weights_wino(c0.weight), in_mask=lowres, out_mask=upconv0, out=x0)
+                    ops._conv_fwd_raw(x0, skip, ops.pack_weights(c1.weight), c1.bias, C1_, 3, "reflect", "elu", 0.0, 2,
+                                      ops.pack_weights_wino(c1.weight), in_mask=upsample_m, out_mask=upconv1, out=x1)
+                else:
+                    S.sparse_conv(x0, src, ops.pack_weights(c0.weight), c0.bias, C0, 3, co0, nnz.data_ptr(), h * w,
+                                  in_mask=lowres, pad="reflect", act="elu", nnz_stride=3)
+                    S.sparse_conv(x1, x0, ops.pack_weights(c1.weight), c1.bias, C1_, 3, co1, nnz.data_ptr() + 4, H2 * W2,
+                                  x2=skip, up1=2, in_mask=upsample_m, pad="reflect", act="elu", nnz_stride=3)
                 # heads: stacked 1x1 + LeakyReLU on the upconv1 support, dual 3x3 + sigmoid on the wavelet mask
                 hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
                 wstack, bstack = ops.stacked_pack([hp[0].conv.weight, hn[0].conv.weight], [hp[0].conv.bias, hn[0].conv.bias])
                 Cm = hp[0].conv.weight.shape[0]
-                mid = zeros(2 * Cm, H2, W2)
-                S.sparse_conv(mid, x1, wstack, bstack, 2 * Cm, 1, co1, nnz.data_ptr() + 4, H2 * W2, act="leaky", slope=0.1)
-                yh_d = zeros(1, 3, H2, W2)
-                S.sparse_conv(yh_d[0], mid, ops.pack_weights(hp[2].conv.weight), hp[2].conv.bias, 3, 3, cow,
+                mid = zeros(B, 2 * Cm, H2, W2)
+                S.sparse_conv(mid, x1, wstack, bstack, 2 * Cm, 1, co1, nnz.data_ptr() + 4, H2 * W2, act="leaky", slope=0.1,
+                              nnz_stride=3)
+                yh_d = zeros(B, 3, H2, W2)
+                S.sparse_conv(yh_d, mid, ops.pack_weights(hp[2].conv.weight), hp[2].conv.bias, 3, 3, cow,
                               nnz.data_ptr() + 8, H2 * W2, in_mask=upconv1, pad="reflect", act="sigmoid",
                               out_scale=2.0 ** (i - 1), c1=Cm, c1_off=0, wp2=ops.pack_weights(hn[2].conv.weight),
-                              bias2=hn[2].conv.bias, c1_off2=Cm)
+                              bias2=hn[2].conv.bias, c1_off2=Cm, nnz_stride=3)
                 yh = yh_d.unsqueeze(1)
                 counters.append((i, nnz, (c0.weight.shape[1], C0), (c1.weight.shape[1], C1_),
                                  (hp[0].conv.weight.shape[1], Cm), (hp[2].conv.weight.shape[1], 3)))
                 xbuf = x1
             else:
-                src = xbuf.unsqueeze(0) if xbuf is not None else x
+                src = xbuf if xbuf is not None else x
                 xd = ops.conv2d_fused(src, c0.weight, c0.bias, pad="reflect", act="elu")
                 skip = input_features[i - 1] if (self.use_skips and i > 0) else None
                 cin1 = xd.shape[1] + (0 if skip is None else skip.shape[1])
@@ -240,8 +267,8 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 if i == 4:
                     yl = ll_new
                 else:
-                    yh = yh * wavelet.reshape(1, 1, 1, H2, W2)   # reference :272 (all ones at i == 4)
-                xbuf = ux[0]
+                    yh = yh * wavelet.reshape(B, 1, 1, H2, W2)   # reference :272 (all ones at i == 4)
+                xbuf = ux
 
             out[("wavelets", i - 1, "LL")] = yl
             out[("wavelets", i - 1, "LH")] = yh[:, :, 0]
@@ -256,10 +283,27 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
 
     @staticmethod
     def _host_op_model(out, counters, static_ops):
-        # ---- the reference's op model needs the pixel counts as python ints: one sync for the whole forward
-        resolved = {lvl: [int(v) for v in nnz.tolist()] for (lvl, nnz, *_rest) in counters}
-        per_scale, total = resolve_total_ops(static_ops, counters, resolved)
-        for sc, n in per_scale.items():
-            out[("total_ops", sc)] = n
-        out["total_ops"] = total
+        # ---- the reference's op model needs the pixel counts as python ints.  They are copied to pinned host memory
+        # asynchronously and turned into the `total_ops` entries on first access: the forward itself never waits for the GPU
+        out = S.LazyOpsDict(out)
+        fetch = S.counts_to_host([nnz for (_lvl, nnz, *_rest) in counters])
+        levels = [lvl for (lvl, *_rest) in counters]
+
+        def resolver():
+            flat = fetch()                                      # per level: B * 3 counts, frame-major
+            B = len(flat[0]) // 3 if flat else 1
+            frames = []
+            for f in range(B):
+                resolved = {lvl: cnt[3 * f:3 * f + 3] for lvl, cnt in zip(levels, flat)}
+                frames.append(resolve_total_ops(static_ops, counters, resolved))
+            if len(frames) == 1:
+                per_scale, total = frames[0]
+                res = {("total_ops", sc): n for sc, n in per_scale.items()}
+                res["total_ops"] = total
+            else:                                               # batched decode: one integer per frame
+                res = {("total_ops", sc): [fr[0][sc] for fr in frames] for sc in frames[0][0]}
+                res["total_ops"] = [fr[1] for fr in frames]
+            return res
+
+        out.set_lazy([("total_ops", i - 1) for i in static_ops] + ["total_ops"], resolver)
         return out

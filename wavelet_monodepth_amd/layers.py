@@ -77,18 +77,19 @@ class NyuConv3x3(nn.Module):
         else:
             self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3, stride=stride, padding=0)
 
-    def forward(self, x, skip=None, up=1, act="none", slope=0.0):
+    def forward(self, x, skip=None, up=1, act="none", slope=0.0, x1_gate=None, grad_is_dz=False):
+        # x1_gate / grad_is_dz: backward-only hints of ops.conv2d_fused (plain 3x3 layers only)
         if self.is_depthwise:
             mid = ops.dwconv3x3_relu(x, self.conv[0][0].weight, x2=skip, up1=up, pad=self.pad_mode)
             return ops.conv2d_fused(mid, self.conv[1].weight, None, pad="zero", act=act, slope=slope)
         return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, x2=skip, up1=up, pad=self.pad_mode, act=act,
-                                slope=slope)
+                                slope=slope, x1_gate=x1_gate, grad_is_dz=grad_is_dz)
 
-    def head(self, x, scale):
+    def head(self, x, scale, x_gate=None):
         """scale * layer(x) for the 1- and 3-channel wavelet heads."""
         if self.is_depthwise:
             return self.forward(x) * scale
-        return ops.head3x3(x, self.conv.weight, self.conv.bias, pad=self.pad_mode, mode=0, scale=scale)
+        return ops.head3x3(x, self.conv.weight, self.conv.bias, pad=self.pad_mode, mode=0, scale=scale, x_gate=x_gate)
 
 
 class UpSampleBlock(nn.Module):
@@ -99,5 +100,5 @@ class UpSampleBlock(nn.Module):
         super().__init__()
         self.convA = NyuConv3x3(skip_input, output_features, padding=padding, is_depthwise=is_depthwise)
 
-    def forward(self, x, concat_with):
-        return self.convA(x, skip=concat_with, up=2, act="leaky", slope=0.2)
+    def forward(self, x, concat_with, x1_gate=None, grad_is_dz=False):
+        return self.convA(x, skip=concat_with, up=2, act="leaky", slope=0.2, x1_gate=x1_gate, grad_is_dz=grad_is_dz)

@@ -113,11 +113,17 @@ class DecoderWave(nn.Module):
 
     def _forward_impl(self, x_blocks):
         outputs = {}
+        # training (plain 3x3 layers): every consumer of an UpSampleBlock output -- the next block and the wavelet heads --
+        # returns its data gradient multiplied by LeakyReLU(0.2)'(output), so no block runs a separate activation-backward
+        # pass (ops.conv2d_fused: x1_gate / grad_is_dz)
+        plain = not (self.up1.convA.is_depthwise or self.wave1.is_depthwise)
+        g = ("leaky", 0.2) if (torch.is_grad_enabled() and plain) else None
+        dz = g is not None
         x_d0 = self.conv2(x_blocks[-1])
-        x_d1 = self.up1(x_d0, x_blocks[-2])
-        ll = self._wave(self.wave1_ll, x_d1, 2.0 ** 3)
+        x_d1 = self.up1(x_d0, x_blocks[-2], grad_is_dz=dz)
+        ll = self.wave1_ll.head(x_d1, 2.0 ** 3, x_gate=g)
         outputs[("disp", 3)] = ll / (2 ** 3)
-        h = self._wave(self.wave1, x_d1, 2.0 ** 2).unsqueeze(1)
+        h = self.wave1.head(x_d1, 2.0 ** 2, x_gate=g).unsqueeze(1)
         outputs[("wavelets", 2, "LL")] = ll
         outputs[("wavelets", 2, "LH")] = h[:, :, 0]
         outputs[("wavelets", 2, "HL")] = h[:, :, 1]
@@ -125,16 +131,16 @@ class DecoderWave(nn.Module):
         ll, disp = ops.idwt_haar(ll, h, disp_scale=1.0 / 2 ** 2, clamp01=False)
         outputs[("disp", 2)] = disp
 
-        x_d2 = self.up2(x_d1, x_blocks[-3])
-        h = self._wave(self.wave2, x_d2, 2.0 ** 1).unsqueeze(1)
+        x_d2 = self.up2(x_d1, x_blocks[-3], x1_gate=g, grad_is_dz=dz)
+        h = self.wave2.head(x_d2, 2.0 ** 1, x_gate=g).unsqueeze(1)
         outputs[("wavelets", 1, "LH")] = h[:, :, 0]
         outputs[("wavelets", 1, "HL")] = h[:, :, 1]
         outputs[("wavelets", 1, "HH")] = h[:, :, 2]
         ll, disp = ops.idwt_haar(ll, h, disp_scale=1.0 / 2 ** 1, clamp01=False)
         outputs[("disp", 1)] = disp
 
-        x_d3 = self.up3(x_d2, x_blocks[-4])
-        h = self._wave(self.wave3, x_d3, 1.0).unsqueeze(1)
+        x_d3 = self.up3(x_d2, x_blocks[-4], x1_gate=g, grad_is_dz=dz)
+        h = self.wave3.head(x_d3, 1.0, x_gate=g).unsqueeze(1)
         outputs[("wavelets", 0, "LH")] = h[:, :, 0]
         outputs[("wavelets", 0, "HL")] = h[:, :, 1]
         outputs[("wavelets", 0, "HH")] = h[:, :, 2]
@@ -283,8 +289,10 @@ class SparseDecoderWave(DecoderWave):
             out[("disp", s)] = disp if level == 0 else ll
             pending.append((nnz, ca.weight.shape[1], Ca, cw.weight.shape[1]))
             src = xa
-        counts = [tuple(int(v) for v in nnz.tolist()) for nnz, *_ in pending]   # one host sync for the python-int op model
-        out["total_ops"] = nyu_sparse_total_ops(xb[-1].shape[1], tuple(xb[-1].shape[2:]), w2.shape[0], xb[-2].shape[1],
-                                                x_d1.shape[1], tuple(x_d1.shape[2:]),
-                                                [(cin_a, ca_, cin_w) for _nnz, cin_a, ca_, cin_w in pending], counts)
+        # the python-int op model is resolved on first access from counts copied to pinned host memory (no sync here)
+        out = S.LazyOpsDict(out)
+        fetch = S.counts_to_host([nnz for nnz, *_ in pending])
+        shapes = (xb[-1].shape[1], tuple(xb[-1].shape[2:]), w2.shape[0], xb[-2].shape[1], x_d1.shape[1], tuple(x_d1.shape[2:]),
+                  [(cin_a, ca_, cin_w) for _nnz, cin_a, ca_, cin_w in pending])
+        out.set_lazy(["total_ops"], lambda: {"total_ops": nyu_sparse_total_ops(*shapes, [tuple(c) for c in fetch()])})
         return out

@@ -114,17 +114,22 @@ def pack_weights_wino(weight, dgrad=False):
 # dense convolution
 # ---------------------------------------------------------------------------------------------
 
-def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None):
+def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None, in_mask=None, out_mask=None, out=None):
+    """in_mask / out_mask (uint8 [B,H,W]) + out (zero-initialised [B,cout,H,W]): block-sparse execution, see
+    wmd_conv_args.in_mask in include/wmd.h."""
     l = _lib.lib()
     B, C1 = x1.shape[0], x1.shape[1]
     H, W = x1.shape[2] * up1, x1.shape[3] * up1
     C2 = 0 if x2 is None else x2.shape[1]
     if x2 is not None and (x2.shape[0] != B or x2.shape[2] != H or x2.shape[3] != W):
         raise _lib.WmdError("skip tensor %s does not match upsampled input %s" % (tuple(x2.shape), (B, C1, H, W)))
-    y = torch.empty((B, cout, H, W), device=x1.device, dtype=torch.float32)
+    if out_mask is not None and out is None:
+        raise _lib.WmdError("block-sparse convolution writes the active tiles only: pass a zero-initialised `out`")
+    y = out if out is not None else torch.empty((B, cout, H, W), device=x1.device, dtype=torch.float32)
     a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad], act=ACT[act],
                       slope=float(slope), x1=ptr(x1), x2=ptr(x2), wp=ptr(wp), bias=ptr(bias), y=ptr(y),
-                      workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_wino=ptr(wp_wino))
+                      workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_wino=ptr(wp_wino),
+                      in_mask=ptr(in_mask), out_mask=ptr(out_mask))
     stream = current_stream()
     keep = []
 
@@ -145,6 +150,8 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
         key = "conv|%d|%d|%d|%d|%d|%d|%d|%d" % (B, H, W, C1, up1, C2, cout, ksize)  # str: JSON-cacheable
         if wp_wino is None and ksize == 3:
             key += "|direct"   # a choice made with the Winograd configurations on offer must not be reused without them
+        if out_mask is not None:
+            key += "|tiles"    # block-sparse: no split-K, small tiles skip more
         choice = tuner.lookup(key)
         if choice is None:
             if torch.cuda.is_current_stream_capturing():

@@ -38,55 +38,142 @@ def mask_threshold(yh, mm, thresh_ratio):
 
 
 def dilate_multi(mask, specs):
-    """mask uint8 [h,w]; specs = [(up, radius), ...] -> list of uint8 masks [h*up, w*up] (one launch)."""
+    """mask uint8 [h,w] (or [B,h,w]: one mask per frame); specs = [(up, radius), ...] -> list of uint8 masks
+    [h*up, w*up] (or [B,h*up,w*up]), one launch."""
     _on_gpu(mask)
-    h, w = mask.shape
-    outs = [torch.empty((h * up, w * up), device=mask.device, dtype=torch.uint8) for up, _ in specs]
+    batched = mask.dim() == 3
+    B = mask.shape[0] if batched else 1
+    h, w = mask.shape[-2:]
+    mask = mask.contiguous()
+    outs = [torch.empty(((B,) if batched else ()) + (h * up, w * up), device=mask.device, dtype=torch.uint8) for up, _ in specs]
     arr = (_lib.DilateSpec * len(specs))(*[_lib.DilateSpec(up, r, ptr(o)) for (up, r), o in zip(specs, outs)])
-    check(_lib.lib().wmd_mask_dilate_multi(ptr(mask), h, w, arr, len(specs), current_stream()), "wmd_mask_dilate_multi")
+    check(_lib.lib().wmd_mask_dilate_multi_b(ptr(mask), B, h, w, arr, len(specs), current_stream()), "wmd_mask_dilate_multi")
     return outs
 
 
 def mask_level(yl, yh, thresh_ratio, specs):
     """minmax(yl) -> threshold(yh) -> every dilated variant, one launch (depth_decoder.py:308-319).
-    specs = [(up, radius), ...]; (1, 0) is the thresholded mask itself.  Bit-identical to the three separate calls."""
+    specs = [(up, radius), ...]; (1, 0) is the thresholded mask itself.  Bit-identical to the three separate calls.
+    yh [B,1,3,h,w], yl [B,1,*,*]: B > 1 = one range / threshold / mask set per frame, outputs [B,h*up,w*up]."""
     _on_gpu(yl, yh)
     h, w = yh.shape[-2:]
+    B = yh.shape[0] if yh.dim() == 5 else 1
     yl, yh = yl.contiguous(), yh.contiguous()
-    outs = [torch.empty((h * up, w * up), device=yh.device, dtype=torch.uint8) for up, _ in specs]
+    outs = [torch.empty(((B,) if B > 1 else ()) + (h * up, w * up), device=yh.device, dtype=torch.uint8) for up, _ in specs]
     arr = (_lib.DilateSpec * len(specs))(*[_lib.DilateSpec(up, r, ptr(o)) for (up, r), o in zip(specs, outs)])
-    check(_lib.lib().wmd_mask_level(ptr(yl), yl.numel(), ptr(yh), float(thresh_ratio), h, w, arr, len(specs),
-                                    current_stream()), "wmd_mask_level")
+    mm = torch.empty((B, 2), device=yh.device, dtype=torch.float32) if B > 1 else None
+    check(_lib.lib().wmd_mask_level_b(ptr(yl), yl.numel() // B, ptr(yh), float(thresh_ratio), B, h, w, arr, len(specs), ptr(mm),
+                                      current_stream()), "wmd_mask_level")
     return outs
 
 
 def compact_multi(masks):
-    """uint8 masks -> (list of int32 coordinate lists [npix capacity], int32 tensor of counts [n]) in one launch;
-    raster order, counts stay on the device."""
+    """uint8 masks [h,w] (or [B,h,w]) -> (list of int32 coordinate lists [npix capacity] (or [B,npix]), int32 tensor of
+    counts [n] (or [B,n])) in one launch; raster order, counts stay on the device."""
     _on_gpu(*masks)
     n = len(masks)
-    nnz = torch.empty(n, device=masks[0].device, dtype=torch.int32)
-    coords = [torch.empty(m.numel(), device=m.device, dtype=torch.int32) for m in masks]
-    arr = (_lib.CompactSpec * n)(*[_lib.CompactSpec(ptr(m), m.numel(), ptr(c), nnz.data_ptr() + 4 * i)
+    batched = masks[0].dim() == 3
+    B = masks[0].shape[0] if batched else 1
+    masks = [m.contiguous() for m in masks]
+    nnz = torch.empty((B, n) if batched else (n,), device=masks[0].device, dtype=torch.int32)
+    coords = [torch.empty((B, m.numel() // B) if batched else (m.numel(),), device=m.device, dtype=torch.int32) for m in masks]
+    arr = (_lib.CompactSpec * n)(*[_lib.CompactSpec(ptr(m), m.numel() // B, ptr(c), nnz.data_ptr() + 4 * i)
                                    for i, (m, c) in enumerate(zip(masks, coords))])
-    check(_lib.lib().wmd_mask_compact_multi(arr, n, current_stream()), "wmd_mask_compact_multi")
+    check(_lib.lib().wmd_mask_compact_multi_b(arr, n, B, current_stream()), "wmd_mask_compact_multi")
     return coords, nnz
 
 
 def sparse_conv(y, x1, wp, bias, cout, ksize, out_coords, out_nnz, max_out, x2=None, up1=1, in_mask=None,
                 pad="reflect", act="none", slope=0.0, out_scale=1.0, c1=None, c1_off=0, wp2=None, bias2=None,
-                c1_off2=0, split_waves=0):
-    """Gather-GEMM convolution on the active pixels; writes y [Cout,H,W] in place at those pixels."""
+                c1_off2=0, split_waves=0, nnz_stride=0):
+    """Gather-GEMM convolution on the active pixels; writes y [Cout,H,W] in place at those pixels.
+    Batched form: y [B,Cout,H,W], x1 [B,C,h,w], x2 [B,C2,H,W], in_mask [B,H,W], out_coords [B,max_out]; out_nnz is the
+    address of frame 0's count and nnz_stride the number of int32 between the counts of consecutive frames."""
     _on_gpu(y, x1, x2, wp, bias, in_mask, out_coords, wp2, bias2)
-    Cout_, H, W = y.shape
+    B = y.shape[0] if y.dim() == 4 else 1
+    Cout_, H, W = y.shape[-3:]
     assert Cout_ == cout
-    c1tot = x1.shape[0]
+    c1tot = x1.shape[-3]
     c1 = c1tot if c1 is None else c1
-    a = _lib.SparseConvArgs(H=H, W=W, C1=c1, up1=up1, C1tot=c1tot, c1_off=c1_off, C2=0 if x2 is None else x2.shape[0],
+    a = _lib.SparseConvArgs(H=H, W=W, C1=c1, up1=up1, C1tot=c1tot, c1_off=c1_off, C2=0 if x2 is None else x2.shape[-3],
                             Cout=cout, ksize=ksize, pad_mode=PAD[pad], act=ACT[act], slope=float(slope),
                             x1=ptr(x1), x2=ptr(x2), in_mask=ptr(in_mask), out_coords=ptr(out_coords),
                             out_nnz=out_nnz, max_out=int(max_out), wp=ptr(wp), bias=ptr(bias), wp2=ptr(wp2),
                             bias2=ptr(bias2), c1_off2=c1_off2, out_scale=float(out_scale), y=ptr(y),
-                            split_waves=int(split_waves))
+                            split_waves=int(split_waves), B=B, nnz_stride=int(nnz_stride))
     check(_lib.lib().wmd_sparse_conv(C.byref(a), current_stream()), "wmd_sparse_conv")
     return y
+
+
+class LazyOpsDict(dict):
+    """The output dictionary of the sparse decoders.  The reference's `total_ops` entries are python ints computed from
+    pixel counts that live on the device; resolving them costs a host synchronisation, which the forward itself no longer
+    pays: the entries are computed on first access (`out["total_ops"]`, `.items()`, `.values()`, `.get`, `==` ...), from
+    counts copied to pinned host memory behind an event recorded by the forward.  Consumers that only read the maps never
+    stall the stream; consumers that read the op counts see exactly the integers the reference returns."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = None      # callable -> {key: int}
+
+    def set_lazy(self, keys, resolver):
+        for key in keys:
+            dict.__setitem__(self, key, None)
+        self._lazy = resolver
+
+    def resolve(self):
+        if self._lazy is not None:
+            fn, self._lazy = self._lazy, None
+            for key, v in fn().items():
+                dict.__setitem__(self, key, v)
+        return self
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is None and self._lazy is not None:
+            self.resolve()
+            v = dict.__getitem__(self, key)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return dict.items(self.resolve())
+
+    def values(self):
+        return dict.values(self.resolve())
+
+    def copy(self):
+        return dict(self.resolve())
+
+    def __eq__(self, other):
+        return dict.__eq__(self.resolve(), other.resolve() if isinstance(other, LazyOpsDict) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+
+def counts_to_host(count_tensors):
+    """Start an asynchronous copy of small device count tensors into pinned host memory; -> callable returning them as
+    lists of python ints (waits for the copy only)."""
+    import torch
+    if not count_tensors:
+        return lambda: []
+    flat = torch.cat([c.reshape(-1) for c in count_tensors])
+    host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+    host.copy_(flat, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    sizes = [c.numel() for c in count_tensors]
+
+    def fetch():
+        ev.synchronize()
+        vals, out, o = host.tolist(), [], 0
+        for n in sizes:
+            out.append([int(v) for v in vals[o:o + n]])
+            o += n
+        return out
+    return fetch
