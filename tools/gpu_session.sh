@@ -15,14 +15,17 @@ tests)
     timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=15 > $OUT/pytest_gpu.log 2>&1
     tail -n 25 $OUT/pytest_gpu.log ;;
 bench)
+    [ -f $OUT/tune_cache.json ] && export WMD_TUNE_CACHE=$OUT/tune_cache.json
     timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
     tail -c 1500 $OUT/bench.json; tail -n 5 $OUT/bench.err ;;
 retune)
     WMD_BENCH_RETUNE=1 WMD_TUNE_CACHE=$OUT/tune_cache.json timeout 900 python bench.py > $OUT/bench_retune.json 2> $OUT/bench_retune.err
     tail -c 600 $OUT/bench_retune.json ;;
 stats)
+    [ -f $OUT/tune_cache.json ] && export WMD_TUNE_CACHE=$OUT/tune_cache.json
     (cd /tmp && WMD_TWO_STREAM_GRAPHS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $REPO/bench.py --no-cpu-baseline --no-train > $OUT/stats.log 2>&1) ;;
 pmc)
+    [ -f $OUT/tune_cache.json ] && export WMD_TUNE_CACHE=$OUT/tune_cache.json
     (cd /tmp && rocprofv3 -L > $OUT/counters_list.txt 2>&1)
     python - "$OUT/counters_list.txt" > $OUT/pmc_passes.txt <<'PY'
 import sys
@@ -45,6 +48,7 @@ PY
     done < $OUT/pmc_passes.txt
     head -n 40 $OUT/pmc_time_wino.txt ;;
 traffic)
+    [ -f $OUT/tune_cache.json ] && export WMD_TUNE_CACHE=$OUT/tune_cache.json
     for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
         set -- $pass
         name=$1; shift

@@ -10,7 +10,7 @@ import re
 import shutil
 import sys
 
-tag, bench, stats, fetch, write, mfma = sys.argv[1:7]
+tag, bench, stats, fetch, write, mfma = sys.argv[1:7]      # mfma may be "-" (no SQ pass in this session)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 
@@ -26,16 +26,16 @@ def per_kernel(d, counter):
 shutil.copy(bench, os.path.join(P, tag + "_bench_fwd.json"))
 shutil.copy(glob.glob(os.path.join(stats, "*", "*kernel_stats.csv"))[0], os.path.join(P, tag + "_kernel_stats.csv"))
 if len(sys.argv) > 7:
-    shutil.copy(sys.argv[7], os.path.join(P, "r01_tune_cache_config2.json"))
+    shutil.copy(sys.argv[7], os.path.join(P, tag.split("_")[0] + "_tune_cache.json"))
 f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-mb, ga = per_kernel(mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(mfma, "GRBM_GUI_ACTIVE")
+mb, ga = (per_kernel(mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(mfma, "GRBM_GUI_ACTIVE")) if mfma != "-" else ({}, {})
 out, traffic = {}, {}
 for k in f:
     if "wmd" not in k:
         continue
     row = {"launches": len(f[k]), "FETCH_SIZE_KiB_avg": sum(f[k]) / len(f[k]),
            "WRITE_SIZE_KiB_avg": sum(w.get(k, [0])) / max(1, len(w.get(k, [1])))}
-    if k in mb and sum(ga[k]):
+    if k in mb and sum(ga.get(k, [0])):
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
         row["mfma_busy_frac"] = (sum(mb[k]) / len(mb[k])) / ((sum(ga[k]) / len(ga[k])) / 8 * 1024)
     out[k] = row
@@ -52,6 +52,6 @@ json.dump({"_method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counte
                       "bench.py --steps 3 --warmup 2 --no-cpu-baseline` with the committed autotune cache; per-launch averages; bytes = "
                       "(2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md: FETCH_SIZE reports half of the fetched bytes on gfx950; "
                       "WRITE_SIZE calibrated exact on the IDWT kernel: 11520 KiB reported = 11520 KiB written)",
-           "session": tag, "kernels": traffic}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+           "session": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, session " + tag, "kernels": traffic}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 for k, v in sorted(traffic.items()):
     print(k, v)
