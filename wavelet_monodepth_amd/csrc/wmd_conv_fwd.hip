@@ -62,6 +62,8 @@ struct ConvKArgs {
     // layers.py:439-453) and outputs outside out_mask are written as 0
     const uint8_t* in_mask;
     const uint8_t* out_mask;
+    // out-channel slabs per pixel tile when the grid is 1-D (0: the slab is blockIdx.y -- the fused-head launches)
+    int cob;
 };
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, int NBUF = 2>
@@ -124,7 +126,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const int wm = wave % WM;
     const int wn = wave / WM;
 
-    int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    // Work item = (pixel tile, out-channel slab), slab fastest.  Workgroups are dealt to the 8 XCDs round-robin and every
+    // XCD has its own L2: giving an XCD one contiguous run of the item sequence puts the slabs of a tile -- which gather
+    // the SAME input patch -- on the same XCD back to back, so only the first of them fetches it from HBM (a 2-D grid
+    // launched all tiles of slab 0 before any tile of slab 1: Cout = 64 / 128 layers with 32-channel blocks moved 1.95x
+    // their algorithmic bytes), and neighbouring tiles share halo rows and 128-byte lines in that L2 as before.
+    int t, by;
+    if (a.cob > 0) {
+        const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+        t = item / a.cob;
+        by = item - t * a.cob;
+    } else {
+        t = xcd_contiguous(blockIdx.x, gridDim.x);
+        by = blockIdx.y;
+    }
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     for (int v = 0; v < T::NAV; ++v) {
         const int e = tid + v * NT;  // 16-byte piece index inside the block's weight tile
         const int run = (e * 4) / T::A_RUN, rem = (e * 4) % T::A_RUN;
-        const int cot = min((int)blockIdx.y * WM * MR + run, a.ncot - 1);
+        const int cot = min(by * WM * MR + run, a.ncot - 1);
         aoff[v] = (unsigned)(((size_t)cot * a.nci4 * TAPS * 64 + rem) * 4);
     }
 
@@ -248,8 +263,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     float bias_v[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-        const int co = FUSE ? (int)(blockIdx.y * (WM * MR * 16)) + (wm * MR + m) * 16 + (lane & 15)
-                            : ((blockIdx.y * WM + wm) * MR + m) * 16 + (lane & 15);
+        const int co = FUSE ? (int)(by * (WM * MR * 16)) + (wm * MR + m) * 16 + (lane & 15)
+                            : ((by * WM + wm) * MR + m) * 16 + (lane & 15);
         bias_v[m] = (a.bias && (FUSE || co < a.Cout)) ? a.bias[co] : 0.f;
     }
     __syncthreads();  // (hipcc drains the DMA with vmcnt(0) ahead of the barrier)
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 #pragma unroll
             for (int n = 0; n < NR; ++n) acc2[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int NCI4_2 = CO_T / 4;   // CO_T is a multiple of 16
-        const float* w2 = a.wp2 + (size_t)blockIdx.y * (2 * NCI4_2 * 64) + lane;
+        const float* w2 = a.wp2 + (size_t)by * (2 * NCI4_2 * 64) + lane;
         const float* msrc = mid + (lane >> 4) * PS2 + (lane & 15);
         // the tap-partial weights come straight from L2 (they do not fit beside `mid`): a ring of QD K-steps of fragments
         // keeps QD global loads per lane in flight so that none of them is waited for in the MFMA stream
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         for (int j = 0; j < R2W; ++j) {
             const int r2 = (WM == 1 ? j : wm) * 16 + (lane & 15);
             if (r2 >= 27) continue;
-            float* tb = a.t + ((size_t)b * a.t_ctot + blockIdx.y * 27 + r2) * plane2;
+            float* tb = a.t + ((size_t)b * a.t_ctot + by * 27 + r2) * plane2;
 #pragma unroll
             for (int n = 0; n < NR; ++n) {
                 const int ox = x0 + (wn * NR + n) * 16 + (lane >> 4) * 4;
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const bool vec_ok = (W & 3) == 0;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-        const int co = ((blockIdx.y * WM + wm) * MR + m) * 16 + (lane & 15);
+        const int co = ((by * WM + wm) * MR + m) * 16 + (lane & 15);
         const float bv = final_out ? bias_v[m] : 0.f;
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
@@ -507,7 +522,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     const int wm = wave % WM;
     const int wn = wave / WM;
 
-    int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    // Work item = (pixel tile, out-channel slab), slab fastest.  Workgroups are dealt to the 8 XCDs round-robin and every
+    // XCD has its own L2: giving an XCD one contiguous run of the item sequence puts the slabs of a tile -- which gather
+    // the SAME input patch -- on the same XCD back to back, so only the first of them fetches it from HBM (a 2-D grid
+    // launched all tiles of slab 0 before any tile of slab 1: Cout = 64 / 128 layers with 32-channel blocks moved 1.95x
+    // their algorithmic bytes), and neighbouring tiles share halo rows and 128-byte lines in that L2 as before.
+    int t, by;
+    if (a.cob > 0) {
+        const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+        t = item / a.cob;
+        by = item - t * a.cob;
+    } else {
+        t = xcd_contiguous(blockIdx.x, gridDim.x);
+        by = blockIdx.y;
+    }
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
@@ -561,7 +589,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     for (int v = 0; v < T::NAV; ++v) {
         const int e = tid + v * NT;
         const int run = (e * 4) / T::A_RUN, rem = (e * 4) % T::A_RUN;
-        const int cot = min((int)blockIdx.y * WM * MRW + run, a.ncot - 1);
+        const int cot = min(by * WM * MRW + run, a.ncot - 1);
         aoff[v] = (unsigned)(((size_t)cot * a.nci4 * 16 * 64 + rem) * 4);
     }
     constexpr int NPB = CK * NPOS, NPIECES = NPB + T::NAV;
@@ -636,7 +664,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     float bias_v[MRW];   // requested now, used in the epilogue (see conv_fwd_kernel)
 #pragma unroll
     for (int m = 0; m < MRW; ++m) {
-        const int co = ((blockIdx.y * WM + wm) * MRW + m) * 16 + (lane & 15);
+        const int co = ((by * WM + wm) * MRW + m) * 16 + (lane & 15);
         bias_v[m] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
     __syncthreads();
@@ -715,7 +743,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     const bool vec_ok = (W & 3) == 0;
 #pragma unroll
     for (int m = 0; m < MRW; ++m) {
-        const int co = ((blockIdx.y * WM + wm) * MRW + m) * 16 + (lane & 15);
+        const int co = ((by * WM + wm) * MRW + m) * 16 + (lane & 15);
         if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W) continue;
         const float bv = final_out ? bias_v[m] : 0.f;
         float yrow[2][8];
@@ -1186,7 +1214,14 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.out_mask = g->out_mask;
     if ((g->out_mask || g->in_mask) && taps != 9) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: masks (block-sparse execution) are a 3x3 feature");
     const int cob = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
-    dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y), (unsigned)cob, (unsigned)plan.ksplit);
+    // Item order: slabs of a tile back to back on one XCD (they share the gathered input patch) while the whole weight image
+    // stays resident in an XCD's 4 MB L2; for the coarse layers, whose weights are larger than that and whose patches are
+    // small, the tiles of one slab run together instead (they share that slab's weights) -- the 2-D grid.
+    const double wbytes = (double)a.ncot * 16 * a.nci4 * 4 * (wino ? 16 : taps) * 4;
+    const bool tile_major = cob > 1 && wbytes <= 3.0 * 1024 * 1024;
+    a.cob = tile_major ? cob : 0;
+    dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y * (tile_major ? cob : 1)), tile_major ? 1u : (unsigned)cob,
+              (unsigned)plan.ksplit);
     if (env_int("WMD_CONV_VERBOSE", 0))
         fprintf(stderr, "[wmd] conv %dx%d C%d+%d->%d k%d: cfg %s grid %u,%u,%u\n", g->H, g->W, g->C1, g->C2, g->Cout,
                 g->ksize, c.name, grid.x, grid.y, grid.z);
