@@ -136,7 +136,8 @@ typedef struct {
      * block tests its own tile's mask bytes and returns when there is none), outputs outside the mask are written as 0 and
      * tiles without active pixels are NOT touched (y must be zero-initialised); with in_mask [B,H,W] a padded input
      * position outside the mask reads 0 for x1 and x2 alike -- the mask test after the coordinate padding of
-     * sparse_conv3x3 (KITTI/layers.py:439-453).  No split-K in this mode.                                            */
+     * sparse_conv3x3 (KITTI/layers.py:439-453).  No split-K in this mode; implemented by the Winograd kernels (needs
+     * wp_wino), the dense instantiations carry no mask code.                                                           */
     const uint8_t* in_mask;
     const uint8_t* out_mask;
 } wmd_conv_args;

@@ -147,14 +147,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     const int y0 = ty * TH, x0 = tx * TW;
     const int ks = blockIdx.z;
     const int H = a.H, W = a.W;
-    if (a.out_mask) {   // block-sparse: nothing to do for a tile without active output pixels (its outputs stay zero)
-        int any = 0;
-        for (int i = tid; i < TH * TW; i += (int)blockDim.x) {
-            const int yy = y0 + i / TW, xx = x0 + i % TW;
-            if (yy < H && xx < W) any |= a.out_mask[(size_t)b * H * W + (size_t)yy * W + xx];
-        }
-        if (!__syncthreads_or(any)) return;
-    }
 
     // ---- staging geometry: each thread owns NPOS patch positions for every channel ----------
     // Staging is LDS-DMA (buffer_load ... lds): a wavefront instruction gathers 64 arbitrary global dwords
@@ -177,7 +169,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;  // tile overhang (H % TH != 0)
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
-        if (a.in_mask) ok = ok && a.in_mask[(size_t)b * H * W + gy * W + gx] != 0;   // sparse support of the virtual input
         ob2[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
         int sy = gy - a.shift1, sx = gx - a.shift1;
         if (a.up1 == 2) {
@@ -418,12 +409,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
                 if (final_out) v[r] = act_apply(v[r] + bv, a.act, a.slope);
             }
             float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
-            if (a.out_mask) {
-                const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W + ox;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ox + r < W && mp[r] == 0) v[r] = 0.f;
-            }
             if (final_out && a.gate) {
                 const float* gp = a.gate + ((size_t)b * a.Cout + co) * plane2 + (size_t)oy * W + ox;
                 if (vec_ok && ox + 3 < W) {
@@ -509,7 +494,9 @@ struct WinoTile {
     static_assert(CK % 4 == 0, "CK must be a whole number of 4-channel K-steps");
 };
 
-template <int TH, int TW, int MRW, int WM, int WN, int CK>
+// MASKED: the block-sparse instantiation (in_mask / out_mask of the sparse decoders); the dense instantiation carries none
+// of that code (with run-time tests alone the dense trunk layers lost 4-6 %: measured by bisection, round 2)
+template <int TH, int TW, int MRW, int WM, int WN, int CK, bool MASKED = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKArgs a) {   // <= 256 registers: 2 blocks per CU
     using T = WinoTile<TH, TW, MRW, WM, WN, CK>;
     constexpr int NT = T::NT, PW = T::PW, PS = T::PS, NPOS = T::NPOS, KSTEPS = CK / 4;
@@ -543,7 +530,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
     const int y0 = ty * TH, x0 = tx * TW;
     const int ks = blockIdx.z;
     const int H = a.H, W = a.W;
-    if (a.out_mask) {   // block-sparse: nothing to do for a tile without active output pixels (its outputs stay zero)
+    if (MASKED && a.out_mask) {   // block-sparse: nothing to do for a tile without active output pixels (its outputs stay zero)
         int any = 0;
         for (int i = tid; i < TH * TW; i += (int)blockDim.x) {
             const int yy = y0 + i / TW, xx = x0 + i % TW;
@@ -566,7 +553,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
         ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
-        if (a.in_mask) ok = ok && a.in_mask[(size_t)b * H * W + gy * W + gx] != 0;   // sparse support of the virtual input
+        if (MASKED && a.in_mask) ok = ok && a.in_mask[(size_t)b * H * W + gy * W + gx] != 0;   // sparse support of the virtual input
         ob2[i] = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
         int sy = gy - a.shift1, sx = gx - a.shift1;
         if (a.up1 == 2) {
@@ -768,7 +755,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (final_out) yrow[j][e] = act_apply(yrow[j][e] + bv, a.act, a.slope);
-            if (a.out_mask) {
+            if (MASKED && a.out_mask) {
                 const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)(oy + j) * W + ox;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -867,7 +854,8 @@ static void launch_cfg(const ConvKArgs& a, dim3 grid, hipStream_t s) {
 
 template <int TH, int TW, int MRW, int WM, int WN, int CK>
 static void launch_wino(const ConvKArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_wino_kernel<TH, TW, MRW, WM, WN, CK>), grid, dim3(WM * WN * 64), 0, s, a);
+    if (a.in_mask || a.out_mask) hipLaunchKernelGGL((conv_wino_kernel<TH, TW, MRW, WM, WN, CK, true>), grid, dim3(WM * WN * 64), 0, s, a);
+    else hipLaunchKernelGGL((conv_wino_kernel<TH, TW, MRW, WM, WN, CK, false>), grid, dim3(WM * WN * 64), 0, s, a);
 }
 // Winograd entries reuse the table's fields: MR = out-channel tiles per wave, NR = 1 (a wave owns one group of 16
 // tiles = 64 pixels), TAPS = 16 transformed positions (this is what marks them).
@@ -975,6 +963,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         const ConvCfg& c = kCfgs[i];
         const bool wino = c.TAPS == 16;
         if (wino ? (taps != 9 || !g->wp_wino) : c.TAPS != taps) continue;
+        if ((g->in_mask || g->out_mask) && !wino) continue;   // block-sparse execution lives in the Winograd kernels
         if (force >= 0 && force != i) continue;
         const int tiles_x = (W + c.TW - 1) / c.TW, tiles_y = (H + c.TH - 1) / c.TH;
         const long tiles = (long)g->B * tiles_x * tiles_y;
@@ -1212,7 +1201,8 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.gate_slope = g->gate_slope;
     a.in_mask = g->in_mask;
     a.out_mask = g->out_mask;
-    if ((g->out_mask || g->in_mask) && taps != 9) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: masks (block-sparse execution) are a 3x3 feature");
+    if ((g->out_mask || g->in_mask) && !wino)
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: masks (block-sparse execution) need a 3x3 layer and the Winograd weight image (wp_wino)");
     const int cob = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
     // Item order: slabs of a tile back to back on one XCD (they share the gathered input patch) while the whole weight image
     // stays resident in an XCD's 4 MB L2; for the coarse layers, whose weights are larger than that and whose patches are
