@@ -42,6 +42,7 @@ for k in f:
     m = re.search(r"(conv_fwd_kernel|conv_wino_kernel)<([0-9a-z, ]+)>", k)
     if m:
         name = m.group(1) + "<" + m.group(2).replace(" ", "").replace(",false,2", "") + ">"
+        name = name.replace(",false>", ">")      # dense instantiation of the Winograd kernel (MASKED = false)
         if "true" in name:
             continue
         traffic[name] = {"traffic_bytes_per_launch": int((2 * row["FETCH_SIZE_KiB_avg"] + row["WRITE_SIZE_KiB_avg"]) * 1024),

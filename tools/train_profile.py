@@ -16,11 +16,20 @@ ap.add_argument("--chans", default="64,64,128,256,512")
 ap.add_argument("--height", type=int, default=192)
 ap.add_argument("--width", type=int, default=640)
 ap.add_argument("--batch", type=int, default=12)
+ap.add_argument("--nyu", action="store_true", help="NYUv2 DecoderWave at DenseNet161 widths, 640x480 (BASELINE config 5)")
 args = ap.parse_args()
 chans = [int(c) for c in args.chans.split(",")]
 dev = torch.device("cuda:0")
-dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
-feats = [torch.from_numpy(f).to(dev).requires_grad_(True) for f in synth.encoder_features(args.batch, args.height, args.width, chans, seed=1)]
+if args.nyu:
+    from wavelet_monodepth_amd.nyu import DecoderWave
+    chans, args.height, args.width = [96, 96, 192, 384, 2208], 480, 640
+    args.batch = 4 if args.batch == 12 else args.batch
+    dec = synth.fill_state_dict(DecoderWave(enc_features=chans), seed=9).to(dev)
+    feats = [torch.from_numpy(synth.normal((args.batch, c, args.height >> (k + 1), args.width >> (k + 1)), "nyu%d" % k, 9)).to(dev).requires_grad_(True)
+             for k, c in enumerate(chans)]
+else:
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
+    feats = [torch.from_numpy(f).to(dev).requires_grad_(True) for f in synth.encoder_features(args.batch, args.height, args.width, chans, seed=1)]
 
 
 def step():
