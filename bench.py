@@ -103,6 +103,9 @@ def _train_setup(kind, args, rank, world, dev):
     from wavelet_monodepth_amd.ddp import GradientExchange, bucket_groups
 
     torch.manual_seed(0)
+    # WMD_BENCH_MIOPEN_FIND=1: MIOpen picks the encoder's kernels by timing (ResNet50: 34.8 -> 33.4 ms per step, but the find
+    # pass of DenseNet161's 160 layers takes > 10 minutes): off by default
+    torch.backends.cudnn.benchmark = os.environ.get("WMD_BENCH_MIOPEN_FIND", "0") == "1"
     if kind == "kitti":
         from wavelet_monodepth_amd.encoders import ResnetEncoder
         from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
