@@ -428,3 +428,96 @@ def test_densenet161_and_mobilenetv2_state_dict_names_follow_torchvision():
     with torch.no_grad():
         feats = DenseEncoder().eval()(x)
     assert [tuple(f.shape[1:]) for f in feats] == [(96, 32, 48), (96, 16, 24), (192, 8, 12), (384, 4, 6), (2208, 2, 3)]
+
+
+# ---- round 2 host logic ------------------------------------------------------------------------------------------------------
+def test_lazy_ops_dict_resolves_on_first_access_only():
+    """sparse_ops.LazyOpsDict: the reference's integer op counts are computed when somebody looks at them -- plain map reads
+    never trigger the resolver, every dict-style access to a lazy entry does, exactly once."""
+    from wavelet_monodepth_amd.sparse_ops import LazyOpsDict
+    calls = []
+
+    def resolver():
+        calls.append(1)
+        return {"total_ops": 42, ("total_ops", 0): 7}
+
+    d = LazyOpsDict({("disp", 0): "map"})
+    d.set_lazy(["total_ops", ("total_ops", 0)], resolver)
+    assert set(d) == {("disp", 0), "total_ops", ("total_ops", 0)} and len(d) == 3
+    assert d[("disp", 0)] == "map" and ("total_ops" in d) and not calls           # keys / plain reads: no resolution
+    assert d["total_ops"] == 42 and d[("total_ops", 0)] == 7 and len(calls) == 1
+    assert dict(d.items())["total_ops"] == 42 and d.get("total_ops") == 42 and d.get("nope", 5) == 5 and len(calls) == 1
+    e = LazyOpsDict({("disp", 0): "map"})
+    e.set_lazy(["total_ops", ("total_ops", 0)], resolver)
+    assert e == d and len(calls) == 2                                              # comparison resolves the other side once
+    assert sorted(map(str, e.values())) == sorted(map(str, d.values())) and e.copy() == dict(d)
+
+
+def test_bucket_groups_cover_every_parameter_once_in_backward_order():
+    """ddp.bucket_groups: decoder first, then the encoder in reverse registration order, cut into <= bucket_bytes messages;
+    works for ResNet, DenseNet161 (config 5: 233 MB of gradients) and MobileNetV2 alike."""
+    from wavelet_monodepth_amd.ddp import bucket_groups
+    from wavelet_monodepth_amd.encoders import DenseEncoder, MobileNetV2Encoder, ResnetEncoder
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    from wavelet_monodepth_amd.nyu import DecoderWave
+    for enc, dec in ((ResnetEncoder(50), None), (DenseEncoder(), "nyu"), (MobileNetV2Encoder(), None)):
+        dec = DecoderWave(enc_features=enc.num_ch_enc) if dec == "nyu" else DepthWaveProgressiveDecoder(enc.num_ch_enc)
+        groups = bucket_groups(enc, dec, bucket_bytes=25 << 20)
+        flat = [p for _n, ps in groups for p in ps]
+        want = list(enc.parameters()) + list(dec.parameters())
+        assert len(flat) == len(want) and {id(p) for p in flat} == {id(p) for p in want}
+        assert groups[0][0] == "decoder" and all(n.startswith("decoder") or n.startswith("encoder") for n, _ in groups)
+        first_enc = next(i for i, (n, _) in enumerate(groups) if n.startswith("encoder"))
+        assert all(n.startswith("decoder") for n, _ in groups[:first_enc]) and all(n.startswith("encoder") for n, _ in groups[first_enc:])
+        # reverse registration order: the encoder's LAST parameter leads its first bucket, its stem weight closes the last one
+        assert groups[first_enc][1][0] is list(enc.parameters())[-1] and groups[-1][1][-1] is list(enc.parameters())[0]
+        for n, ps in groups:
+            size = 4 * sum(p.numel() for p in ps)
+            assert size <= (25 << 20) or len(ps) == 1, (n, size)
+    dense_bytes = 4 * sum(p.numel() for p in DenseEncoder().parameters())
+    assert 110e6 < dense_bytes < 120e6      # + 127 MB of decoder: the 233 MB exchange of config 5 (SURVEY 8e)
+
+
+def test_tuner_choose_picks_the_fastest_valid_candidate_and_caches_its_label(monkeypatch):
+    """tuner.choose (the weight-gradient family's autotuner): invalid candidates are skipped, the winner's LABEL is cached,
+    a cached label wins without timing, tuning off returns the library's own choice."""
+    import torch
+    from wavelet_monodepth_amd import tuner
+
+    class FakeEvent:
+        now = [0.0]
+
+        def __init__(self, enable_timing=False):
+            self.t = 0.0
+
+        def record(self):
+            self.t = FakeEvent.now[0]
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    cost = {0: 5.0, -1: 3.0, 1: 1.0, 2: None, 3: 2.0, 9: 4.0}
+    launched = []
+
+    def launch(arg):
+        launched.append(arg)
+        if cost[arg] is None:
+            return -3
+        FakeEvent.now[0] += cost[arg]
+        return 0
+
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(tuner, "enabled", True)
+    monkeypatch.setattr(tuner, "_cache_file", None)
+    cands = [("library", 0), ("direct", -1), ("a", 1), ("b", 2), ("c", 3)]
+    key = "wgrad|test|%d" % id(cands)
+    assert tuner.choose(key, cands, launch) == 1 and tuner._cache[key][0] == "a"
+    n = len(launched)
+    assert tuner.choose(key, cands, launch) == 1 and len(launched) == n          # cached: nothing is timed again
+    assert tuner.choose(key, [("library", 0), ("zz", 9)], launch) == 9            # cached label gone from the table: re-tunes
+    monkeypatch.setattr(tuner, "enabled", False)
+    assert tuner.choose("wgrad|other", cands, launch) == 0

@@ -80,7 +80,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
         _x_gate (internal, set by forward()): input_features is the ELU output of this decoder's own trunk convolution."""
         if not torch.is_grad_enabled():
             return self._coefficients_stacked(input_features, scale, return_ll)
-        if self.stack_heads:
+        stackable = all(self.convs[("waveconv", scale, j)][0].conv.weight.shape[0] % 16 == 0 for j in ([0] if return_ll else []) + [1])
+        if self.stack_heads and stackable:   # (the stacked GEMM concatenates whole 16-channel tiles)
             hd = lambda j: (lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias))(self.convs[("waveconv", scale, j)])
             yh, yl, mid = ops.stacked_heads(input_features, hd(1), hd(-1), 2.0 ** (scale - 1), hd(0) if return_ll else None,
                                             2.0 ** scale, x_gate=_x_gate, return_mid=True)

@@ -494,7 +494,7 @@ class _StackedHeadsFn(torch.autograd.Function):
         parts = []
         if has_ll:
             parts.append(torch.zeros_like(sl) if d_yl is None or d_yl.numel() == 0 else _c(d_yl) * sl * (1.0 - sl) * s_ll)
-        d_yh = _c(d_yh)
+        d_yh = torch.zeros_like(sp) if d_yh is None else _c(d_yh)      # yh unused by the loss
         parts.append(d_yh * sp * (1.0 - sp) * s_hf)
         parts.append(d_yh * sn * (1.0 - sn) * (-s_hf))
         dy3 = torch.cat(parts, 1)
