@@ -366,7 +366,8 @@ typedef struct {
     int32_t* nnz;          /* device scalar                                                        */
 } wmd_compact_spec;
 /* Stream compaction (mask2idxmap / mask2yx, KITTI/layers.py:371-389) of up to 8 masks in one launch:
- * one workgroup per mask, wavefront ballot + popcount prefix sums, raster order preserved.        */
+ * one workgroup per mask; a lane packs 16 flags into a bit field (popcount), wavefront shuffle prefix sums + an LDS scan
+ * over the 16 wavefronts, raster order preserved.                                                   */
 int wmd_mask_compact_multi(const wmd_compact_spec* specs, int n, void* stream);
 /* batched: specs[i].mask / .coords are [B,npix]; specs[i].nnz points at the count of (frame 0, mask i) of an int32 [B,n]
  * array (the counts of one frame are contiguous)                                                                      */

@@ -7,7 +7,8 @@
 //   minmax_kernel            global min/max of the LL plane                      (depth_decoder.py:308)
 //   mask_threshold_kernel    max_b |yh_b| > ratio * range                        (:308-309)
 //   mask_dilate_multi_kernel every MaxPool2d(3|5)(upsample?) variant at once     (:311-319)
-//   mask_compact_multi_kernel raster-order stream compaction: wavefront __ballot + popcount prefix sums,
+//   mask_compact_multi_kernel raster-order stream compaction: 16 flags per lane packed into a bit field + __popc, wavefront
+//                            __shfl_up prefix sums (a lane's bit field plays the role of a 16-wide ballot), LDS scan over the 16 wavefronts,
 //                            one workgroup per mask, count left on the device     (layers.py:371-389)
 //   sparse_conv_kernel       gather-GEMM on fp32 MFMA over the compacted active pixels, fused
 //                            select/upsample/concat/pad/bias/activation/scatter   (layers.py:337-507)
