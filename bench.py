@@ -145,7 +145,10 @@ def _train_setup(kind, args, rank, world, dev):
         what = "NYUv2 DenseNet161 %dx%d training step, batch %d per GPU, L1 on upsampled disparities + LL3 vs DWT(J=4) of the " \
                "ground truth (BASELINE.json configs[4])" % (W, H, B)
     params = list(enc.parameters()) + list(dec.parameters())
-    opt = torch.optim.Adam(params, lr=1e-4)
+    try:       # one multi-tensor kernel per parameter chunk, step counter on the device (so the update can sit in a hipGraph)
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=True)
+    except (TypeError, RuntimeError):
+        opt = torch.optim.Adam(params, lr=1e-4, capturable=True)
     gx = None
     if world > 1:
         gx = GradientExchange(bucket_groups(enc, dec), world=world, rank=rank, backend=args.exchange_backend, modules=[enc, dec])
@@ -162,7 +165,8 @@ def _train_setup(kind, args, rank, world, dev):
         opt.step()
         return loss
     return step, gx, {"workload": what, "batch_per_gpu": B, "global_batch": B * world,
-                      "parallelism": "dp%d, %s bucketed all-reduce overlapped with the encoder backward" % (world, args.exchange_backend)}
+                      "parallelism": "dp%d, %s bucketed all-reduce overlapped with the encoder backward" % (world, args.exchange_backend)}, \
+        (loss_fn, opt, [enc, dec])
 
 
 def _timed(step, steps, warmup, world, red_dev):
@@ -191,9 +195,10 @@ def _timed(step, steps, warmup, world, red_dev):
 def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup):
     """Time the data-parallel training step with the gradient exchange on, then (world > 1) with the all-reduces switched
     off: the difference is the all-reduce time the overlap did NOT hide.  -> dict (same on every rank)."""
-    step, gx, cfg = _train_setup(kind, args, rank, world, dev)
+    step, gx, cfg, (loss_fn, opt, nets) = _train_setup(kind, args, rank, world, dev)
     elapsed, loss = _timed(step, steps, warmup, world, red_dev)
     assert torch.isfinite(loss)
+    del loss      # nothing may keep the eager autograd graph (and its default-stream AccumulateGrad nodes) alive into the capture
     B = cfg["batch_per_gpu"]
     res = {"frames_per_s": round(B * steps * world / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
            "steps": steps, "warmup": warmup, "n_gpus": world, "config": cfg}
@@ -206,6 +211,20 @@ def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup):
                     "ms_per_step_without_exchange": round(local / steps * 1e3, 3),
                     "exposed_allreduce_ms_per_step": round((elapsed - local) / steps * 1e3, 3),
                     "exchange_backend": args.exchange_backend, "exchange_world_size": gx.world})
+    if args.train_graph == "on" or (args.train_graph == "auto" and world == 1 and args.workload != "fwd"):
+        # the same step replayed from hipGraphs (graphs.TrainStepGraph).  At these sizes the eager step is NOT bound by its
+        # python launches (the replay takes as long): reported beside the eager figure, which stays the headline
+        from wavelet_monodepth_amd.graphs import TrainStepGraph
+        try:
+            tg = TrainStepGraph(loss_fn, opt, exchange=gx, warmup=1, modules=nets)
+            g_elapsed, g_loss = _timed(tg.step, steps, 2, world, red_dev)
+            assert torch.isfinite(g_loss)
+            res["graph_replay"] = {"ms_per_step": round(g_elapsed / steps * 1e3, 3), "frames_per_s": round(B * steps * world / g_elapsed, 2),
+                                   "what": "forward + backward + Adam replayed from hipGraphs (graphs.TrainStepGraph)"
+                                           + ("; bucket all-reduces between the backward graph and the update graph" if gx is not None else "")}
+        except Exception as e:
+            res["graph_replay"] = {"error": repr(e)[:300]}
+    if gx is not None:
         gx.close()
     return res
 
@@ -246,6 +265,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel training extras of the fwd workload")
+    ap.add_argument("--train-graph", choices=["auto", "on", "off"], default="auto",
+                    help="also time the training step as hipGraph replays (auto: single-GPU --workload train / train-nyu runs)")
     ap.add_argument("--workload", choices=["fwd", "train", "train-nyu"], default="fwd")
     ap.add_argument("--num-layers", type=int, default=50)
     ap.add_argument("--height", type=int, default=320)

@@ -157,6 +157,20 @@ size_t wmd_conv_fwd_workspace_floats(const wmd_conv_args* args);
 size_t wmd_conv_packed_weight_floats_wino(int Cout, int Cin);
 int wmd_conv_pack_weights_wino(const float* w, float* wp, int Cout, int Cin, int dgrad, void* stream);
 
+/* Every weight image of a set of filters in ONE launch (training repacks all of them after each optimizer step).  Each
+ * non-NULL output receives exactly what the single-filter entry point writes: fwd = wmd_conv_pack_weights, dgrad =
+ * wmd_conv_pack_weights_dgrad, wino_fwd / wino_dgrad = wmd_conv_pack_weights_wino(dgrad = 0 / 1) (3x3 filters only).
+ * Outputs may alias slices of one buffer (sizes: wmd_conv_packed_weight_floats[_wino]).                              */
+typedef struct {
+    const float* w;      /* [Cout,Cin,ksize,ksize]                                       */
+    int Cout, Cin, ksize;
+    float* fwd;
+    float* dgrad;
+    float* wino_fwd;
+    float* wino_dgrad;
+} wmd_pack_item;
+int wmd_conv_pack_many(const wmd_pack_item* items, int n, void* stream);
+
 /* Tile-configuration table (for callers that autotune: wavelet_monodepth_amd/tuner.py).
  * wmd_conv_config_name returns e.g. "conv_fwd_kernel<8,32,2,4,1,4,8,9>" (the kernel's template
  * arguments TH,TW,MR,NR,WM,WN,CK,TAPS) or NULL when i is out of range.                        */

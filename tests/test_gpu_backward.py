@@ -386,3 +386,30 @@ def test_kitti_decoder_per_head_training_path_still_matches_reference_gradients(
         assert_close(f.grad, g["dfeat%d" % k], 1e-4, "dfeat%d" % k)
     for name, p in dec.named_parameters():
         assert_close(sample(p.grad.cpu().numpy()), g["d|" + name], 1e-4, name)
+
+
+@pytest.mark.parametrize("shapes", [
+    [(32, 48, 3), (16, 16, 1), (7, 5, 3), (40, 21, 1), (3, 64, 3)],
+    [(64, 96, 3)] * 3 + [(17, 33, 3), (33, 17, 1)] + [(16, 32, 1)] * 45,      # more filters than one launch holds
+])
+def test_pack_many_writes_the_images_of_the_single_filter_entry_points(dev, shapes):
+    """ops.prepack: one launch for all filters; forward / data-gradient / Winograd images bit-identical to
+    wmd_conv_pack_weights[_dgrad] and wmd_conv_pack_weights_wino, and memoised on the tensors."""
+    from wavelet_monodepth_amd import ops
+    ws = [torch.from_numpy(synth.uniform((co, ci, k, k), "pm", i, -1.0, 1.0)).to(dev) for i, (co, ci, k) in enumerate(shapes)]
+    refs = [torch.from_numpy(synth.uniform((co, ci, k, k), "pm", i, -1.0, 1.0)).to(dev) for i, (co, ci, k) in enumerate(shapes)]
+    ops.prepack(ws)
+    for w, r in zip(ws, refs):
+        assert getattr(w, "_wmd_pack_f")[0][0] == w._version
+        for dgrad in (False, True):
+            got, want = ops.pack_weights(w, dgrad=dgrad), ops.pack_weights(r, dgrad=dgrad)
+            assert got.data_ptr() == getattr(w, "_wmd_pack_d" if dgrad else "_wmd_pack_f")[1].data_ptr()   # memo hit
+            assert torch.equal(got, want), (tuple(w.shape), dgrad)
+            if w.shape[2] == 3:
+                assert torch.equal(ops.pack_weights_wino(w, dgrad=dgrad), ops.pack_weights_wino(r, dgrad=dgrad)), (tuple(w.shape), dgrad)
+    # an in-place update invalidates the memo; prepack(dgrad=False) only rebuilds the forward images
+    with torch.no_grad():
+        ws[0].mul_(2.0)
+    ops.prepack(ws[:1], dgrad=False)
+    assert getattr(ws[0], "_wmd_pack_f")[0][0] == ws[0]._version != getattr(ws[0], "_wmd_pack_d")[0][0]
+    assert torch.equal(ops.pack_weights(ws[0]), 2.0 * ops.pack_weights(refs[0]))

@@ -521,3 +521,11 @@ def test_tuner_choose_picks_the_fastest_valid_candidate_and_caches_its_label(mon
     assert tuner.choose(key, [("library", 0), ("zz", 9)], launch) == 9            # cached label gone from the table: re-tunes
     monkeypatch.setattr(tuner, "enabled", False)
     assert tuner.choose("wgrad|other", cands, launch) == 0
+
+
+def test_train_step_graph_refuses_an_optimizer_that_cannot_be_captured():
+    import torch
+    from wavelet_monodepth_amd.graphs import TrainStepGraph
+    p = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(ValueError, match="capturable=True"):
+        TrainStepGraph(lambda: p.sum(), torch.optim.Adam([p], lr=1e-3))

@@ -16,6 +16,8 @@ ap.add_argument("--chans", default="64,64,128,256,512")
 ap.add_argument("--height", type=int, default=192)
 ap.add_argument("--width", type=int, default=640)
 ap.add_argument("--batch", type=int, default=12)
+ap.add_argument("--update", action="store_true", help="touch the weights after every step like an optimizer would (the "
+                "weight images are then rebuilt each step) and print the wall-clock time per step too")
 ap.add_argument("--nyu", action="store_true", help="NYUv2 DecoderWave at DenseNet161 widths, 640x480 (BASELINE config 5)")
 args = ap.parse_args()
 chans = [int(c) for c in args.chans.split(",")]
@@ -32,15 +34,30 @@ else:
     feats = [torch.from_numpy(f).to(dev).requires_grad_(True) for f in synth.encoder_features(args.batch, args.height, args.width, chans, seed=1)]
 
 
+params = list(dec.parameters())
+
+
 def step():
     out = dec(feats)
     loss = sum(out[("disp", s)].mean() for s in range(4))
     loss.backward()
+    if args.update:
+        with torch.no_grad():
+            torch._foreach_mul_(params, 1.0)     # bumps the version counters: every memoised weight image is stale
 
 
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+if args.update:
+    import time
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 20 * 1e3
+    print("decoder fwd+bwd + weight touch: %.3f ms wall-clock per step" % wall)
 _lib.profile_begin()
 n = 5
 for _ in range(n):

@@ -94,6 +94,11 @@ class DilateSpec(C.Structure):
     _fields_ = [("up", C.c_int), ("radius", C.c_int), ("out", C.c_void_p)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("ksize", C.c_int), ("fwd", C.c_void_p),
+                ("dgrad", C.c_void_p), ("wino_fwd", C.c_void_p), ("wino_dgrad", C.c_void_p)]
+
+
 class CompactSpec(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("npix", C.c_int), ("coords", C.c_void_p), ("nnz", C.c_void_p)]
 
@@ -126,6 +131,7 @@ SIGNATURES = {
     "wmd_conv_pack_weights_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wmd_conv_packed_weight_floats_wino": (C.c_size_t, [C.c_int, C.c_int]),
     "wmd_conv_pack_weights_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wmd_conv_pack_many": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "wmd_conv_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "wmd_conv_fwd_workspace_floats": (C.c_size_t, [C.POINTER(ConvArgs)]),
     "wmd_conv_num_configs": (C.c_int, []),

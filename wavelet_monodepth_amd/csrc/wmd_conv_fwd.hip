@@ -1118,6 +1118,112 @@ extern "C" int wmd_conv_pack_weights_wino(const float* w, float* wp, int Cout, i
     return check_launch("conv_pack_wino_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// every weight image of a set of filters in one launch (a training step repacks all of them after each optimizer update:
+// as ~50 separate 5-10 us launches that was 9 % of the decoder's forward + backward).
+// One workgroup = one 16 x 16 (Cout x Cin) tile of one filter, all taps: the 16 rows are 16*taps contiguous floats each,
+// staged once in LDS, and every requested image of that tile -- forward and data-gradient fragment order, direct and
+// Winograd -- is a contiguous 4*taps*64 (4*16*64) float run written from there.  Same arithmetic, in the same order, as
+// conv_pack_kernel / conv_pack_wino_kernel: the images are bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPackManyMax = 40;
+struct PackManyItem {
+    const float* w;
+    float *fwd, *dgrad, *wfwd, *wdgrad;
+    int Cout, Cin, taps, tile0;   // tile0 = index of this item's first tile in the launch
+};
+struct PackManyArgs {
+    int n, tiles;
+    PackManyItem it[kPackManyMax];
+};
+
+__global__ __launch_bounds__(256) void conv_pack_many_kernel(const PackManyArgs a) {
+    __shared__ float s[16 * 144];
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const int tid = threadIdx.x;
+    for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+        int k = 0;
+        while (k + 1 < a.n && a.it[k + 1].tile0 <= tile) ++k;
+        const PackManyItem& it = a.it[k];
+        const int taps = it.taps, Cout = it.Cout, Cin = it.Cin;
+        const int nb = (Cin + 15) / 16, na = (Cout + 15) / 16;
+        const int ta = (tile - it.tile0) / nb, tb = (tile - it.tile0) % nb;   // Cout tile, Cin tile
+        const int row_len = 16 * taps;
+        __syncthreads();
+        {
+            const int r = tid >> 4, m = ta * 16 + r;
+            const float* src = it.w + ((size_t)m * Cin + tb * 16) * taps;
+            const int valid = m < Cout ? (min(16, Cin - tb * 16)) * taps : 0;
+            for (int c = tid & 15; c < row_len; c += 16) s[r * 144 + c] = c < valid ? src[c] : 0.f;
+        }
+        __syncthreads();
+        const size_t fbase = ((size_t)ta * nb * 4 + 4 * tb) * 64;   // x taps (or x 16): first float of the tile's run, forward order
+        const size_t dbase = ((size_t)tb * na * 4 + 4 * ta) * 64;   // data-gradient order: rows = Cin tile, reduction = Cout tile
+        const int n_direct = 4 * taps * 64;
+        if (it.fwd)
+            for (int i = tid; i < n_direct; i += 256) {
+                const int l = i & 63, r = i >> 6, tap = r % taps, q = r / taps;
+                it.fwd[fbase * taps + i] = s[(l & 15) * 144 + (q * 4 + (l >> 4)) * taps + tap];
+            }
+        if (it.dgrad)
+            for (int i = tid; i < n_direct; i += 256) {
+                const int l = i & 63, r = i >> 6, tap = r % taps, q = r / taps;
+                it.dgrad[dbase * taps + i] = s[(q * 4 + (l >> 4)) * 144 + (l & 15) * taps + (taps - 1 - tap)];
+            }
+        if (taps == 9 && (it.wfwd || it.wdgrad))
+            for (int i = tid; i < 4 * 16 * 64; i += 256) {
+                const int l = i & 63, r = i >> 6, xi = r & 15, q = r >> 4;
+                const int pa = xi >> 2, pb = xi & 3;
+                if (it.wfwd) {
+                    const float* g = &s[(l & 15) * 144 + (q * 4 + (l >> 4)) * 9];
+                    float u = 0.f;
+                    for (int ii = 0; ii < 3; ++ii)
+                        for (int jj = 0; jj < 3; ++jj) u += G[pa][ii] * g[ii * 3 + jj] * G[pb][jj];
+                    it.wfwd[fbase * 16 + i] = u;
+                }
+                if (it.wdgrad) {
+                    const float* g = &s[(q * 4 + (l >> 4)) * 144 + (l & 15) * 9];
+                    float u = 0.f;
+                    for (int ii = 0; ii < 3; ++ii)
+                        for (int jj = 0; jj < 3; ++jj) u += G[pa][ii] * g[8 - (ii * 3 + jj)] * G[pb][jj];
+                    it.wdgrad[dbase * 16 + i] = u;
+                }
+            }
+    }
+}
+
+extern "C" int wmd_conv_pack_many(const wmd_pack_item* items, int n, void* stream) {
+    if (n < 0 || (n && !items)) return fail(WMD_ERR_BAD_ARG, "wmd_conv_pack_many: null items");
+    for (int i = 0; i < n; ++i) {
+        const wmd_pack_item& p = items[i];
+        if (!p.w) return fail(WMD_ERR_BAD_ARG, "wmd_conv_pack_many: item %d has no weights", i);
+        if (p.Cout <= 0 || p.Cin <= 0 || (p.ksize != 1 && p.ksize != 3))
+            return fail(WMD_ERR_BAD_SHAPE, "wmd_conv_pack_many: item %d Cout=%d Cin=%d ksize=%d", i, p.Cout, p.Cin, p.ksize);
+        if (p.ksize != 3 && (p.wino_fwd || p.wino_dgrad))
+            return fail(WMD_ERR_BAD_ARG, "wmd_conv_pack_many: item %d asks for a Winograd image of a %dx%d filter", i, p.ksize, p.ksize);
+    }
+    for (int i0 = 0; i0 < n; i0 += kPackManyMax) {
+        PackManyArgs a;
+        a.n = std::min(kPackManyMax, n - i0);
+        int tiles = 0;
+        double floats = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const wmd_pack_item& p = items[i0 + i];
+            a.it[i] = PackManyItem{p.w, p.fwd, p.dgrad, p.wino_fwd, p.wino_dgrad, p.Cout, p.Cin, p.ksize == 3 ? 9 : 1, tiles};
+            tiles += ((p.Cout + 15) / 16) * ((p.Cin + 15) / 16);
+            const double img = (double)wmd_conv_packed_weight_floats(p.Cout, p.Cin, p.ksize);
+            floats += (double)p.Cout * p.Cin * (p.ksize == 3 ? 9 : 1) + img * ((p.fwd != nullptr) + (p.dgrad != nullptr)) +
+                      img / 9 * 16 * ((p.wino_fwd != nullptr) + (p.wino_dgrad != nullptr));
+        }
+        a.tiles = tiles;
+        ProfScope prof("conv_pack_many_kernel", 0.0, 4.0 * floats, (hipStream_t)stream);
+        hipLaunchKernelGGL(conv_pack_many_kernel, dim3(std::min(tiles, 8192)), dim3(256), 0, (hipStream_t)stream, a);
+        int rc = check_launch("conv_pack_many_kernel");
+        if (rc) return rc;
+    }
+    return WMD_OK;
+}
+
 static int validate_conv(const wmd_conv_args* g, const char* who) {
     if (!g) return fail(WMD_ERR_BAD_ARG, "%s: null args", who);
     if (!g->x1 || !g->wp || !g->y) return fail(WMD_ERR_BAD_ARG, "%s: null tensor pointer", who);

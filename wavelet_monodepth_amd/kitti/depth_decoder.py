@@ -206,6 +206,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
 
     def _forward_impl(self, input_features):
         self.outputs = {}
+        ops.prepack_module(self)      # one launch for every weight image this pass (and its backward) will ask for
         x = input_features[-1]
         yl = None
         # Under hipGraph capture the wavelet heads run on a second stream: head(i) needs only x_i and the low-pass of
@@ -298,6 +299,7 @@ class DepthDecoder(nn.Module):
 
     def forward(self, input_features):
         self.outputs = {}
+        ops.prepack_module(self)
         x = input_features[-1]
         for i in range(4, -1, -1):
             x = self.convs[("upconv", i, 0)](x)

@@ -49,6 +49,7 @@ class Decoder(nn.Module):
         self.conv3 = NyuConv3x3(features // 16, 1, is_depthwise=True) if is_depthwise else _OutConv3x3(features // 16, 1)
 
     def _trunk(self, features):
+        ops.prepack_module(self)
         x_block0, x_block1, x_block2, x_block3, x_block4 = tuple(features)
         x_d0 = self.conv2(x_block4)
         x_d1 = self.up1(x_d0, x_block3)
@@ -113,6 +114,7 @@ class DecoderWave(nn.Module):
 
     def _forward_impl(self, x_blocks):
         outputs = {}
+        ops.prepack_module(self)
         # training (plain 3x3 layers): every consumer of an UpSampleBlock output -- the next block and the wavelet heads --
         # returns its data gradient multiplied by LeakyReLU(0.2)'(output), so no block runs a separate activation-backward
         # pass (ops.conv2d_fused: x1_gate / grad_is_dz)
@@ -180,6 +182,7 @@ class DecoderWave224(nn.Module):
 
     def forward(self, x_blocks):
         outputs = {}
+        ops.prepack_module(self)
         x = self.up1(self.conv2(x_blocks[-1]), x_blocks[-2])
         ll = self._wave(self.wave1_ll, x, 2.0 ** 4)
         for level, (wave, up, skip) in enumerate(((self.wave1, self.up2, x_blocks[-3]), (self.wave2, self.up3, x_blocks[-4]),

@@ -83,6 +83,85 @@ def pack_weights(weight, dgrad=False):
 
 
 _WINOGRAD = os.environ.get("WMD_WINOGRAD", "1") != "0"
+_PREPACK = os.environ.get("WMD_PREPACK", "1") != "0"
+
+
+def pack_many(specs, with_buffer=False):
+    """specs: [(weight [Cout,Cin,k,k], ("fwd" | "dgrad" | "wino_fwd" | "wino_dgrad", ...)), ...] -> one dict {image name:
+    tensor} per spec, all written by ONE wmd_conv_pack_many launch into one buffer, in the order given (no memo).
+    with_buffer: -> (dicts, that buffer)."""
+    l = _lib.lib()
+    sizes = []
+    for w, names in specs:
+        cout, cin, k, _k = w.shape
+        n_direct, n_wino = l.wmd_conv_packed_weight_floats(cout, cin, k), l.wmd_conv_packed_weight_floats_wino(cout, cin)
+        sizes.append([n_wino if nm.startswith("wino") else n_direct for nm in names])
+    buf = torch.empty(sum(sum(s) for s in sizes), device=specs[0][0].device, dtype=torch.float32)
+    items, out, keep, off = [], [], [], 0
+    for (w, names), sz in zip(specs, sizes):
+        cout, cin, k, _k = w.shape
+        wc = _c(w.detach())
+        keep.append(wc)
+        it = _lib.PackItem(w=ptr(wc), Cout=cout, Cin=cin, ksize=k)
+        d = {}
+        for nm, n in zip(names, sz):
+            d[nm] = buf[off:off + n]
+            setattr(it, nm, d[nm].data_ptr())
+            off += n
+        items.append(it)
+        out.append(d)
+    arr = (_lib.PackItem * len(items))(*items)
+    check(l.wmd_conv_pack_many(arr, len(items), current_stream()), "wmd_conv_pack_many")
+    return (out, buf) if with_buffer else out
+
+
+def prepack(weights, dgrad=True):
+    """Build every weight image the convolutions of `weights` ([Cout,Cin,k,k] tensors) will ask for -- forward and (dgrad)
+    data-gradient fragment order, direct and Winograd -- in ONE launch (wmd_conv_pack_many) into one buffer, and memoise
+    them on the tensors exactly as pack_weights / pack_weights_wino would.  A training step calls this once per forward
+    (the optimizer step invalidated all ~50 images); weights whose images are current are skipped, so inference pays
+    nothing.  WMD_PREPACK=0: every convolution packs for itself as before."""
+    if not (_PREPACK and _PACK_CACHE) or not weights or torch.cuda.is_current_stream_capturing():
+        return
+    todo, seen = [], set()
+    for w in weights:
+        if w is None or id(w) in seen or not w.is_cuda or w.dim() != 4 or w.shape[2] not in (1, 3):
+            continue
+        seen.add(id(w))
+        tag = (w._version, w.data_ptr(), w.device, _pack_generation[0])
+        k = w.shape[2]
+        slots = ["_wmd_pack_f"] + (["_wmd_pack_d"] if dgrad else [])
+        if k == 3 and _WINOGRAD:
+            slots += ["_wmd_pack_wf"] + (["_wmd_pack_wd"] if dgrad else [])
+        need = [sl for sl in slots if getattr(w, sl, (None,))[0] != tag]
+        if need:
+            todo.append((w, tag, need))
+    if not todo:
+        return
+    field = {"_wmd_pack_f": "fwd", "_wmd_pack_d": "dgrad", "_wmd_pack_wf": "wino_fwd", "_wmd_pack_wd": "wino_dgrad"}
+    images = pack_many([(w, tuple(field[sl] for sl in need)) for w, _, need in todo])
+    views = [(w, sl, tag, img[field[sl]]) for (w, tag, need), img in zip(todo, images) for sl in need]
+    for w, sl, tag, view in views:
+        try:
+            setattr(w, sl, (tag, view))
+        except AttributeError:
+            pass
+
+
+
+
+def prepack_module(module):
+    """prepack() for every ungrouped convolution filter below `module` (the decoders call this first thing in forward)."""
+    if not (_PREPACK and _PACK_CACHE):
+        return
+    ws = getattr(module, "_wmd_prepack_list", None)
+    if ws is None:
+        # (the 1- and 3-channel 3x3 output layers run on the head kernels, which read the raw filter)
+        ws = [m.weight for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.groups == 1
+              and not (m.kernel_size[0] == 3 and m.out_channels <= 4)]
+        module.__dict__["_wmd_prepack_list"] = ws      # plain attribute: parameters are replaced only by re-construction
+    if ws and all(w is not None and w.is_cuda for w in ws):      # (CPU tensors: the first operator refuses them)
+        prepack(ws, dgrad=torch.is_grad_enabled())
 
 
 def pack_weights_wino(weight, dgrad=False):
@@ -518,8 +597,10 @@ class _StackedHeadsFn(torch.autograd.Function):
         _wgrad_launch(a, dev)
         # ... and data gradient, gated by LeakyReLU'(mid): dzmid
         dzmid = torch.empty_like(mid)
-        wpd = pack_weights(w3bd, dgrad=True)
-        wpdw = pack_weights_wino(w3bd, dgrad=True)
+        # the three weight images of this backward (3x3 data gradient direct + Winograd, 1x1 data gradient) in one launch
+        want_dx = ctx.needs_input_grad[0]
+        imgs = pack_many([(w3bd, ("dgrad", "wino_dgrad") if _WINOGRAD else ("dgrad",))] + ([(w1s, ("dgrad",))] if want_dx else []))
+        wpd, wpdw = imgs[0]["dgrad"], imgs[0].get("wino_dgrad")
         a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=Ct, up1=1, C2=0, Cout=n_out, ksize=3, pad_mode=PAD["reflect"], dz=ptr(dy3),
                                wp_dgrad=ptr(wpd), dx1=ptr(dzmid), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
                                tune_ksplit=0, wp_dgrad_wino=ptr(wpdw), x1_fwd=ptr(mid), x1_act=ACT["leaky"], x1_slope=0.1)
@@ -533,10 +614,10 @@ class _StackedHeadsFn(torch.autograd.Function):
         _wgrad_launch(a, dev)
         # ... and data gradient (one GEMM over all heads' mid channels), gated by the caller's activation if x has one
         dx = None
-        if ctx.needs_input_grad[0]:
+        if want_dx:
             dx = torch.empty_like(x)
             gate_act, gate_slope = (ACT[x_gate[0]], float(x_gate[1])) if x_gate else (0, 0.0)
-            wpd1 = pack_weights(w1s, dgrad=True)
+            wpd1 = imgs[1]["dgrad"]
             a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], dz=ptr(dzmid),
                                    wp_dgrad=ptr(wpd1), dx1=ptr(dx), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
                                    tune_ksplit=0, wp_dgrad_wino=None, x1_fwd=ptr(x) if gate_act else None, x1_act=gate_act,
@@ -568,8 +649,6 @@ def stacked_heads(x, head_p, head_n, scale_hf, head_ll=None, scale_ll=1.0, x_gat
 
 def stacked_pack(weights, biases):
     """Packed image + bias of several [Cout_k, Cin, 1, 1] filters stacked along Cout (memoised on weights[0])."""
-    l = _lib.lib()
-    cin = weights[0].shape[1]
     couts = [w.shape[0] for w in weights]
     if any(c % 16 for c in couts[:-1]):
         raise _lib.WmdError("stacked heads need out-channel counts that are multiples of 16")
@@ -577,13 +656,7 @@ def stacked_pack(weights, biases):
     hit = getattr(weights[0], "_wmd_pack_stack", None) if _PACK_CACHE else None
     if hit is not None and hit[0] == tag:
         return hit[1], hit[2]
-    sizes = [l.wmd_conv_packed_weight_floats(c, cin, 1) for c in couts]
-    wp = torch.empty(sum(sizes), device=weights[0].device, dtype=torch.float32)
-    s = current_stream()
-    off = 0
-    for w, n, c in zip(weights, sizes, couts):
-        check(l.wmd_conv_pack_weights(ptr(_c(w.detach())), wp.data_ptr() + 4 * off, c, cin, 1, s), "wmd_conv_pack_weights")
-        off += n
+    _imgs, wp = pack_many([(w, ("fwd",)) for w in weights], with_buffer=True)   # consecutive slices = the stacked image
     bias = torch.cat([b.detach() for b in biases])
     if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
         try:
