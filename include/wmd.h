@@ -283,7 +283,13 @@ typedef struct {
     const float* wp1;
     const float* bias1;
     const float* wp2;
-    float* t;            /* [B,54,H,W]     */
+    float* t;            /* [B,t_planes,H,W]  */
+    int chain;           /* 0: the + and - chains -> t planes 0..53.
+                            1: the coarsest level's low-pass chain (C -> C/4 -> 1, depth_decoder.py:104-106,126-129) as a
+                               second launch over the same x: wp1 / bias1 = its [C/4, C, 1, 1] filter, wp2 = ONE
+                               [27, C/4, 1, 1] image whose rows 0..8 hold the nine taps -> t planes 54..62 of an 81-plane t,
+                               completed by wmd_head_shiftsum_fwd(yl_out).  C = 256 only (WMD_ERR_UNSUPPORTED otherwise)   */
+    int t_planes;        /* planes per image of t: 0 or 54, or 81 when the low-pass chain shares the buffer              */
 } wmd_head_fused_args;
 int wmd_head_fused_fwd(const wmd_head_fused_args* args, void* stream);
 
@@ -301,6 +307,12 @@ typedef struct {
     float* disp;
     float disp_scale;
     int clamp01;
+    /* optional low-pass head completed in the same pass (t then has 81 planes per image, see wmd_head_fused_args.chain):
+     * yl_out [B,H,W] = scale_ll * sigmoid(bias_ll[0] + nine shifted taps of planes 54..62); it is also the low-pass input
+     * of the synthesis (yl must be NULL).                                                                                */
+    const float* bias_ll; /* [1] or NULL */
+    float scale_ll;
+    float* yl_out;
 } wmd_head_shiftsum_args;
 int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* args, void* stream);
 

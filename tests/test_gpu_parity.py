@@ -371,6 +371,32 @@ def test_fused_head_level_vs_oracle(dev, C, H, W):
     assert_close(disp, torch.clamp(out_ref / 2 ** (s - 1), 0, 1), 2e-6, "disp")
 
 
+@pytest.mark.parametrize("C,H,W", [(256, 12, 40), (64, 9, 28), (128, 5, 7), (32, 6, 10)])
+def test_fused_head_level_with_the_low_pass_head_as_third_chain(dev, C, H, W):
+    """Coarsest level (depth_decoder.py:104-106,126-136): the LL head C -> C/4 -> 1 rides in the fused launches as a third,
+    zero-padded chain; yl = 2^s sigmoid(.), and the synthesis consumes it in the same pass.  (C = 32 takes the one-launch
+    kernel for the +/- chains and the stand-alone operators for LL: same contract.)"""
+    from wavelet_monodepth_amd import ops
+    B, s = 2, 4
+    x = t(synth.normal((B, C, H, W), "lx", 7))
+    hp = [t(a) for a in synth.conv_params("l1p", C, C, 1, 7)] + [t(a) for a in synth.conv_params("l3p", 3, C, 3, 7)]
+    hn = [t(a) for a in synth.conv_params("l1n", C, C, 1, 7)] + [t(a) for a in synth.conv_params("l3n", 3, C, 3, 7)]
+    hl = [t(a) for a in synth.conv_params("l1l", C // 4, C, 1, 7)] + [t(a) for a in synth.conv_params("l3l", 1, C // 4, 3, 7)]
+    lk = lambda v: torch.nn.functional.leaky_relu(v, 0.1)
+    sig = lambda h: torch.sigmoid(R.conv3x3(lk(R.conv1x1(x, h[0], h[1])), h[2], h[3], "reflect"))
+    yl_ref = 2.0 ** s * sig(hl)
+    yh_ref = (2 ** (s - 1) * sig(hp) - 2 ** (s - 1) * sig(hn)).unsqueeze(1)
+    out_ref = R.haar_idwt(yl_ref, yh_ref)
+    g = lambda v: v.to(dev)
+    yh, out, disp, yl = ops.head_fused_level_nograd(g(x), [g(v) for v in hp], [g(v) for v in hn], scale=2.0 ** (s - 1),
+                                                    disp_scale=1.0 / 2 ** (s - 1), clamp01=True,
+                                                    head_ll=[g(v) for v in hl], scale_ll=2.0 ** s)
+    assert float((yh.cpu() - yh_ref).abs().max()) < 3e-5          # differences of sigmoids x 8: absolute tolerance
+    assert_close(yl, yl_ref, 2e-6, "yl")
+    assert_close(out, out_ref, 4e-6, "idwt")
+    assert_close(disp, torch.clamp(out_ref / 2 ** (s - 1), 0, 1), 4e-6, "disp")
+
+
 def test_kitti_baseline_decoder_vs_reference_golden(dev):
     from wavelet_monodepth_amd.kitti import DepthDecoder
     gold = load_golden("kitti_baseline_r18_64x64.npz")

@@ -53,7 +53,8 @@ class HeadArgs(C.Structure):
 
 class HeadFusedArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("slope", C.c_float),
-                ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p), ("t", C.c_void_p)]
+                ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p), ("t", C.c_void_p),
+                ("chain", C.c_int), ("t_planes", C.c_int)]
 
 
 class HeadLevelArgs(C.Structure):
@@ -87,7 +88,7 @@ class HeadShiftsumArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pad_mode", C.c_int), ("scale", C.c_float),
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
                 ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
-                ("clamp01", C.c_int)]
+                ("clamp01", C.c_int), ("bias_ll", C.c_void_p), ("scale_ll", C.c_float), ("yl_out", C.c_void_p)]
 
 
 class DilateSpec(C.Structure):

@@ -52,6 +52,7 @@ struct ConvKArgs {
     const float* wp2;   // per side: packed [27 -> 32 rows, CO_T] image
     float* t;           // [B, sides*27, H*W]
     int t_ctot;
+    int t_row0;   // first plane of t this launch writes
     // optional multiplicative gate of the final output (data-gradient path): y *= gate_act'(gate), gate laid out like y
     const float* gate;
     int gate_act;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         for (int j = 0; j < R2W; ++j) {
             const int r2 = (WM == 1 ? j : wm) * 16 + (lane & 15);
             if (r2 >= 27) continue;
-            float* tb = a.t + ((size_t)b * a.t_ctot + by * 27 + r2) * plane2;
+            float* tb = a.t + ((size_t)b * a.t_ctot + a.t_row0 + by * 27 + r2) * plane2;
 #pragma unroll
             for (int n = 0; n < NR; ++n) {
                 const int ox = x0 + (wn * NR + n) * 16 + (lane >> 4) * 4;
@@ -1019,6 +1020,12 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     if (g->B <= 0 || g->H <= 0 || g->W <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_head_fused_fwd: B=%d H=%d W=%d", g->B, g->H, g->W);
     if (g->C != 32 && g->C != 64 && g->C != 128 && g->C != 256)
         return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: C=%d (32, 64, 128 or 256; other widths run unfused)", g->C);
+    if (g->chain != 0 && g->chain != 1) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: chain=%d", g->chain);
+    if (g->t_planes != 0 && g->t_planes != 54 && g->t_planes != 81) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: t_planes=%d", g->t_planes);
+    const int t_planes = g->t_planes ? g->t_planes : 54;
+    if (g->chain == 1 && (g->C != 256 || t_planes != 81))
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: the low-pass chain needs C = 256 and an 81-plane t (C=%d, t_planes=%d)", g->C, t_planes);
+    const int rows = g->chain == 1 ? g->C / 4 : 2 * g->C;   // stacked mid channels of this launch
     ConvKArgs a;
     memset(&a, 0, sizeof(a));
     a.x1 = g->x;
@@ -1031,21 +1038,29 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     a.W1 = a.W;
     a.C1 = g->C;
     a.Cin = g->C;
-    a.Cout = 2 * g->C;
+    a.Cout = rows;
     a.up1 = 1;
     a.act = WMD_ACT_LEAKY;
     a.slope = g->slope;
     a.nci4 = ((g->C + 15) / 16) * 4;
-    a.ncot = 2 * g->C / 16;
+    a.ncot = rows / 16;
     a.nchunks = g->C >= 128 ? g->C / 32 : 1;   // C = 32 / 64: the whole reduction is one LDS-resident chunk
     a.ksplit = 1;
     a.chunks_per_split = a.nchunks;
     a.tiles_y = 1;
     a.wp2 = g->wp2;
     a.t = g->t;
-    a.t_ctot = 54;
+    a.t_ctot = t_planes;
+    a.t_row0 = g->chain == 1 ? 54 : 0;
     hipStream_t s = (hipStream_t)stream;
     const double pix = (double)g->B * g->H * g->W;
+    if (g->chain == 1) {
+        // 64 mid channels = one 16-row tile per wave of a 4-wave block; the second GEMM (K = 64) gives rows 0..8
+        ProfScope prof("conv_fwd_kernel<fused LL head>", 2.0 * pix * (g->C * (g->C / 4.0) + 9.0 * (g->C / 4.0)), 4.0 * pix * (g->C + 9), s);
+        a.tiles_x = (a.W + 31) / 32;
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 32, 1, 2, 4, 1, 32, 1, true>), dim3(g->B * a.tiles_x, 1), dim3(256), 0, s, a);
+        return check_launch("conv_fwd_kernel<fused LL head>");
+    }
     ProfScope prof("conv_fwd_kernel<fused head>", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C),
                    4.0 * pix * (g->C + 54), s);
     if (g->C == 32) {

@@ -309,7 +309,7 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
             off[t] = gy * W + gx;
             okf[t] = ok ? 1.f : 0.f;
         }
-        const float* tb = a.t + b * 54 * plane;
+        const float* tb = a.t + b * (a.yl_out ? 81 : 54) * plane;
         float vp[27], vn[27];
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
@@ -329,8 +329,17 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
             yh[co] = a.scale * a1 - a.scale * a2;
             a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
         }
-        if (a.yl && a.out) {
-            const float l = a.yl[i];
+        float l = 0.f;
+        if (a.yl_out) {   // the low-pass head of the coarsest level: third chain of the fused launch, rows 54..62
+            float sl = a.bias_ll ? a.bias_ll[0] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sl += okf[t] * tb[(size_t)(54 + t) * plane + off[t]];
+            l = a.scale_ll / (1.f + expf(-sl));
+            a.yl_out[i] = l;
+        } else if (a.yl) {
+            l = a.yl[i];
+        }
+        if ((a.yl || a.yl_out) && a.out) {
             float v[4] = {(l + yh[0] + yh[1] + yh[2]) * 0.5f, (l + yh[0] - yh[1] - yh[2]) * 0.5f,
                           (l - yh[0] + yh[1] - yh[2]) * 0.5f, (l - yh[0] - yh[1] + yh[2]) * 0.5f};
             const size_t dst = b * 4 * plane + (size_t)(2 * y) * (2 * W) + 2 * x;
@@ -424,10 +433,12 @@ extern "C" int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* g, void* stre
     if (g->pad_mode < 0 || g->pad_mode > 2) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: pad_mode=%d", g->pad_mode);
     if (g->pad_mode == WMD_PAD_REFLECT && (g->H < 2 || g->W < 2))
         return fail(WMD_ERR_BAD_SHAPE, "wmd_head_shiftsum_fwd: reflect padding needs H,W >= 2");
-    if ((g->out != nullptr) != (g->yl != nullptr)) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: yl and out go together");
+    if (g->yl_out && g->yl) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: yl_out (low-pass head completed here) excludes yl");
+    if ((g->out != nullptr) != (g->yl != nullptr || g->yl_out != nullptr))
+        return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: yl (or yl_out) and out go together");
     const size_t n = (size_t)g->B * g->H * g->W;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof("head_shiftsum_kernel", 60.0 * n, 4.0 * n * (54 + 3 + (g->out ? (g->disp ? 9 : 5) : 0)), s);
+    ProfScope prof("head_shiftsum_kernel", 60.0 * n, 4.0 * n * ((g->yl_out ? 64 : 54) + 3 + (g->out ? (g->disp ? 9 : 5) : 0)), s);
     const unsigned threads = n < 65536 ? 64 : 256;   // coarse levels: one wavefront per block spreads the few pixels over the CUs
     hipLaunchKernelGGL(head_shiftsum_kernel, dim3((unsigned)std::min<size_t>((n + threads - 1) / threads, (size_t)kNumCU * 16)), dim3(threads),
                        0, s, *g);

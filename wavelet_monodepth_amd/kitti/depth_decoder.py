@@ -247,15 +247,18 @@ class DepthWaveProgressiveDecoder(nn.Module):
             # one launch (C = 32) or two (1x1 -> LeakyReLU -> tap-partials with mid on chip, then 9-tap gather + sigmoid +
             # combine + Haar synthesis)
             hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
-            if i == 4:   # the LL head (C -> C/4 -> 1) exists only at the coarsest level; it runs unfused
+            head_ll = None
+            if i == 4:   # the LL head (C -> C/4 -> 1) exists only at the coarsest level: a third chain of the same launches
                 h0 = self.convs[("waveconv", i, 0)]
-                mid0 = h0[0](x, act="leaky", slope=0.1)
-                yl = ops.head3x3(mid0, h0[2].conv.weight, h0[2].conv.bias, pad="reflect", mode=1, scale=2.0 ** i)
+                head_ll = (h0[0].conv.weight, h0[0].conv.bias, h0[2].conv.weight, h0[2].conv.bias)
             yl_in = yl
-            yh, yl, disp = ops.head_fused_level_nograd(
+            res = ops.head_fused_level_nograd(
                 x, (hp[0].conv.weight, hp[0].conv.bias, hp[2].conv.weight, hp[2].conv.bias),
                 (hn[0].conv.weight, hn[0].conv.bias, hn[2].conv.weight, hn[2].conv.bias),
-                scale=2.0 ** (i - 1), yl=yl, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
+                scale=2.0 ** (i - 1), yl=yl, disp_scale=1.0 / 2 ** (i - 1), clamp01=True, head_ll=head_ll, scale_ll=2.0 ** i)
+            yh, yl, disp = res[:3]
+            if head_ll is not None:
+                yl_in = res[3]
             self.outputs[("wavelets", i - 1, "LL")] = yl_in
         else:
             gate = ("elu", 0.0) if torch.is_grad_enabled() else None   # x is this decoder's own ELU output (see _forward_impl)

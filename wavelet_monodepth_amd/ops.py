@@ -700,13 +700,9 @@ def _tap_partial_pack(w3p, w3n):
     hit = getattr(w3p, "_wmd_pack_t27", None) if _PACK_CACHE else None
     if hit is not None and hit[0] == tag:
         return hit[1]
-    l = _lib.lib()
     cin = w3p.shape[1]
-    n = l.wmd_conv_packed_weight_floats(27, cin, 1)
-    wp = torch.empty(2 * n, device=w3p.device, dtype=torch.float32)
-    for k, w in enumerate((w3p, w3n)):
-        w27 = w.detach().permute(0, 2, 3, 1).reshape(27, cin, 1, 1).contiguous()
-        check(l.wmd_conv_pack_weights(ptr(w27), wp.data_ptr() + 4 * k * n, 27, cin, 1, current_stream()), "wmd_conv_pack_weights")
+    w27s = [w.detach().permute(0, 2, 3, 1).reshape(27, cin, 1, 1).contiguous() for w in (w3p, w3n)]
+    _imgs, wp = pack_many([(w, ("fwd",)) for w in w27s], with_buffer=True)
     if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
         try:
             w3p._wmd_pack_t27 = (tag, wp)
@@ -715,43 +711,89 @@ def _tap_partial_pack(w3p, w3n):
     return wp
 
 
+def _ll_chain_pack(w1l, w3l):
+    """Weight images of the low-pass chain for wmd_head_fused_fwd(chain = 1): the [C/4,C,1,1] filter as it is, and the
+    [1,C/4,3,3] filter as a [27,C/4,1,1] image whose rows 0..8 are its nine taps (rows 9..26 zero).  Memoised on w1l."""
+    tag = (w1l._version, w1l.data_ptr(), w3l._version, w3l.data_ptr(), _pack_generation[0])
+    hit = getattr(w1l, "_wmd_pack_ll", None) if _PACK_CACHE else None
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    cm = w3l.shape[1]
+    w27 = torch.zeros((27, cm, 1, 1), device=w3l.device, dtype=torch.float32)
+    w27[:9, :, 0, 0] = w3l.detach()[0].permute(1, 2, 0).reshape(9, cm)
+    imgs = pack_many([(w1l, ("fwd",)), (w27, ("fwd",))])
+    wp1, wp2 = imgs[0]["fwd"], imgs[1]["fwd"]
+    if _PACK_CACHE and not torch.cuda.is_current_stream_capturing():
+        try:
+            w1l._wmd_pack_ll = (tag, wp1, wp2)
+        except AttributeError:
+            pass
+    return wp1, wp2
+
+
 FUSED_HEAD_WIDTHS = (32, 64, 128, 256)
 _TWO_LAUNCH_HEAD = os.environ.get("WMD_TWO_LAUNCH_HEAD", "0") == "1"   # development switch: A/B the two forms
+_LL_FOLD = os.environ.get("WMD_LL_FOLD", "1") != "0"                   # 0: the low-pass head on its own three launches
 
 
-def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False):
-    """Inference form of one level's high-frequency heads + (optionally) the Haar IDWT in two launches:
-    wmd_head_fused_fwd (1x1 -> LeakyReLU -> 27 tap-partials per side, intermediate stays on chip) and
-    wmd_head_shiftsum_fwd (9-tap gather, bias, sigmoid, combine, IDWT).  head_* = (w1, b1, w3, b3).
-    Returns (yh [B,1,3,H,W], out or None, disp or None)."""
+def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False, head_ll=None, scale_ll=1.0):
+    """Inference form of one level's high-frequency heads + (optionally) the Haar IDWT in one launch (C = 32:
+    wmd_head_level_fwd, every intermediate in LDS) or two: wmd_head_fused_fwd (1x1 -> LeakyReLU -> 27 tap-partials per
+    side, intermediate stays on chip) and wmd_head_shiftsum_fwd (9-tap gather, bias, sigmoid, combine, IDWT).
+    head_* = (w1, b1, w3, b3).  head_ll: the coarsest level's low-pass head (C -> C/4 -> 1, sigmoid * scale_ll); at C = 256
+    it is a small third launch of the same fused kernel (tap-partials into planes 54..62 of the shared buffer) that the
+    shift-sum completes and feeds to the synthesis as its low-pass input (yl must be None); other widths: own operators.
+    Returns (yh [B,1,3,H,W], out or None, disp or None[, yl_ll [B,1,H,W] when head_ll is given])."""
     l = _lib.lib()
     x = _c(x)
     B, Cc, H, W = x.shape
     (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
+    one_launch = bool(l.wmd_head_level_supported(Cc)) and not _TWO_LAUNCH_HEAD
+    yl_ll = None
+    if head_ll is not None:
+        if yl is not None:
+            raise _lib.WmdError("head_fused_level_nograd: head_ll supplies the low-pass input; yl must be None")
+        w1l, b1l, w3l, b3l = head_ll
+        if one_launch or Cc != 256 or not _LL_FOLD:     # the low-pass head on its own operators
+            mid0 = conv2d_fused(x, w1l, b1l, pad="zero", act="leaky", slope=0.1)
+            yl = yl_ll = head3x3(mid0, w3l, b3l, pad="reflect", mode=1, scale=scale_ll)
+            head_ll = None
     wp1, bias1 = stacked_pack([w1p, w1n], [b1p, b1n])
     wp2 = _tap_partial_pack(w3p, w3n)
     s = current_stream()
     yh = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
     out = disp = None
-    if yl is not None:
-        yl = _c(yl)
+    if yl is not None or head_ll is not None:
+        yl = _c(yl) if yl is not None else None
         out = torch.empty((B, 1, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
         disp = torch.empty_like(out) if disp_scale is not None else None
-    if l.wmd_head_level_supported(Cc) and not _TWO_LAUNCH_HEAD:
+    if one_launch:
         # one launch: every intermediate of the level stays in LDS
         a = _lib.HeadLevelArgs(B=B, H=H, W=W, C=Cc, pad_mode=PAD["reflect"], slope=0.1, scale=float(scale), x=ptr(x),
                                wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), bias_p=ptr(b3p), bias_n=ptr(b3n), yh=ptr(yh),
                                yl=ptr(yl), out=ptr(out), disp=ptr(disp), disp_scale=float(disp_scale or 1.0),
                                clamp01=int(clamp01))
         check(l.wmd_head_level_fwd(C.byref(a), s), "wmd_head_level_fwd")
-        return yh.unsqueeze(1), out, disp
-    t = torch.empty((B, 54, H, W), device=x.device, dtype=torch.float32)
-    a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t))
-    check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
-    g = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scale), t=ptr(t), bias_p=ptr(b3p),
-                              bias_n=ptr(b3n), yh=ptr(yh), yl=ptr(yl), out=ptr(out), disp=ptr(disp),
-                              disp_scale=float(disp_scale or 1.0), clamp01=int(clamp01))
-    check(l.wmd_head_shiftsum_fwd(C.byref(g), s), "wmd_head_shiftsum_fwd")
+    else:
+        planes = 81 if head_ll is not None else 54
+        t = torch.empty((B, planes, H, W), device=x.device, dtype=torch.float32)
+        a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t),
+                               chain=0, t_planes=planes)
+        check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
+        if head_ll is not None:     # the low-pass chain: a small second launch over the same x into planes 54..62
+            wpl1, wpl2 = _ll_chain_pack(w1l, w3l)
+            yl_ll = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+            a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wpl1), bias1=ptr(_c(b1l.detach())), wp2=ptr(wpl2),
+                                   t=ptr(t), chain=1, t_planes=planes)
+            check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
+        g = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scale), t=ptr(t), bias_p=ptr(b3p),
+                                  bias_n=ptr(b3n), yh=ptr(yh), yl=ptr(yl), out=ptr(out), disp=ptr(disp),
+                                  disp_scale=float(disp_scale or 1.0), clamp01=int(clamp01),
+                                  bias_ll=ptr(b3l) if head_ll is not None else None, scale_ll=float(scale_ll),
+                                  yl_out=ptr(yl_ll) if head_ll is not None else None)
+        check(l.wmd_head_shiftsum_fwd(C.byref(g), s), "wmd_head_shiftsum_fwd")
+    if yl_ll is not None:
+        return yh.unsqueeze(1), out, disp, yl_ll
     return yh.unsqueeze(1), out, disp
 
 
