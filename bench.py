@@ -328,12 +328,8 @@ def main():
     # nothing but the K forward calls inside.  The per-step spread (p10 / median / p90) comes from one more K-step pass with an
     # event after every step, outside the timed region (the event records cost 0.5-1 %).
     graph_on = os.environ.get("WMD_BENCH_GRAPH", "1") != "0"
-    roof = None
-    if rank == 0:
-        roof = roofline(dec, feats, args.steps)     # leaves the decoder in eager mode
-    dec.enable_graph(graph_on)
-    if world > 1:
-        barrier()   # rank 0's per-launch pass ends before the ranks start together
+    roof = roofline(dec, feats, args.steps)     # every rank runs it (same state on every GPU); rank 0's goes into the line
+    dec.enable_graph(graph_on)                  # (the pass leaves the decoder in eager mode)
     with torch.no_grad():
         for _ in range(args.warmup):
             dec(feats)
