@@ -357,7 +357,10 @@ def main():
     if not args.no_train:
         del out
         dec.enable_graph(False)
-        train = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 3)
+        try:      # an extra of the line: a failure here (e.g. the RCCL exchange cannot be set up) must not cost the headline figure
+            train = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 3)
+        except Exception as e:
+            train = {"error": repr(e)[:400]}
 
     if rank == 0:
         frames = BATCH * args.steps * world
