@@ -42,6 +42,11 @@ def _worker(rank, world, port, out_dir):
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(1.0)
+    from wavelet_monodepth_amd.ddp import _GroupStore
+    st = _GroupStore()                                   # how the RCCL backend's unique id travels when a process group is up
+    if rank == 0:
+        st.set("wmd_comm_uid", b"\x01uid-of-rank-0\x00")
+    assert st.get("wmd_comm_uid") == b"\x01uid-of-rank-0\x00"
     gx = GradientExchange(bucket_groups(net.encoder, net.decoder, bucket_bytes=1200), backend="torch", modules=[net])
     assert [b["name"] for b in gx.buckets][0] == "decoder" and len(gx.buckets) >= 3
     ref = TinyNet()

@@ -32,6 +32,22 @@ import torch.distributed as dist
 BUCKET_BYTES = 25 << 20
 
 
+class _GroupStore:
+    """Hands rank 0's RCCL unique id to the other ranks through the torch.distributed process group that is already up
+    (no second rendezvous, no extra port); the set / get pair of a c10d store, for this one key."""
+
+    def __init__(self, group=None):
+        self.group, self.value = group, None
+
+    def set(self, key, value):
+        self.value = value
+
+    def get(self, key):
+        box = [self.value]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
+
+
 class _RcclBackend:
     def __init__(self, world, rank, store):
         from . import _lib
@@ -137,6 +153,8 @@ class GradientExchange:
             # parameters the loss never reaches (resnet.fc, densenet.norm5/classifier): see finish()
             self.buckets.append({"name": name, "params": params, "flat": flat, "arm": len(params), "count": 0, "sent": False})
         if backend == "rccl":
+            if store is None and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) == self.world:
+                store = _GroupStore(process_group)
             if store is None:
                 store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17,
                                       self.world, self.rank == 0)
