@@ -110,6 +110,10 @@ def _train_setup(kind, args, rank, world, dev):
         from wavelet_monodepth_amd.encoders import ResnetEncoder
         from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
         H, W, B = args.height, args.width, args.batch
+        if args.strong:      # fixed global batch: every rank takes its share ("also report strong scaling")
+            if B % world:
+                raise SystemExit("--strong: --batch %d is the GLOBAL batch and must divide by the %d ranks" % (B, world))
+            B //= world
         enc = ResnetEncoder(args.num_layers).to(dev)
         dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(enc.num_ch_enc), seed=1).to(dev)
         img = torch.from_numpy(synth.uniform((B, 3, H, W), "img%d" % rank, 0, 0.0, 1.0)).to(dev)
@@ -236,7 +240,8 @@ def train_main(kind, args, rank, world, dev, red_dev):
         cfg = st.pop("config")
         line = {"metric": "training frames/sec (encoder + wavelet decoder fwd+bwd + Adam)", "value": st.pop("frames_per_s"),
                 "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": st.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "ms_per_step": st.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+                "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic", "config": cfg}
         line.update({k: v for k, v in st.items() if k not in ("steps", "warmup", "n_gpus")})
         print(json.dumps(line))
@@ -268,6 +273,8 @@ def main():
     ap.add_argument("--train-graph", choices=["auto", "on", "off"], default="auto",
                     help="also time the training step as hipGraph replays (auto: single-GPU --workload train / train-nyu runs)")
     ap.add_argument("--workload", choices=["fwd", "train", "train-nyu"], default="fwd")
+    ap.add_argument("--strong", action="store_true", help="--workload train: --batch is the global batch, split over the ranks "
+                    "(strong scaling); default: --batch per GPU (weak scaling)")
     ap.add_argument("--num-layers", type=int, default=50)
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=1024)
