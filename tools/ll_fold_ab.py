@@ -23,7 +23,7 @@ def run(n):
 for rep in range(3):
     for fold in (False, True):
         ops._LL_FOLD = fold
-        dec._graphs.clear()
+        dec.enable_graph(True)      # drops the captured segments
         print("LL_FOLD=%d  %.4f ms/step (host enqueue %.4f ms/step)" % (fold, run(300), run.enqueue_ms), flush=True)
 dec.enable_graph(False)
 for fold in (False, True):
