@@ -1025,6 +1025,7 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     const int t_planes = g->t_planes ? g->t_planes : 54;
     if (g->chain == 1 && (g->C != 256 || t_planes != 81))
         return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: the low-pass chain needs C = 256 and an 81-plane t (C=%d, t_planes=%d)", g->C, t_planes);
+    if (g->chain == 0 && head_chain_launch(g, t_planes, (hipStream_t)stream)) return check_launch("head_chain_kernel");
     const int rows = g->chain == 1 ? g->C / 4 : 2 * g->C;   // stacked mid channels of this launch
     ConvKArgs a;
     memset(&a, 0, sizeof(a));

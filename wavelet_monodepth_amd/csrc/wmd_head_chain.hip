@@ -1,0 +1,261 @@
+// Two chained GEMMs per pixel for the wide levels of the inference wavelet heads (C = 64, 128, 256;
+// KITTI/networks/decoders/depth_decoder.py:108-136):
+//
+//   mid_s = LeakyReLU(W1_s x + b1_s)                    s in {+,-},  1x1, C -> C
+//   t_s   = W3'_s mid_s                                 the 3x3 regrouped as 27 tap-partial 1x1 outputs (row co*9+tap)
+//
+// (wmd_head_shiftsum_fwd then gathers the nine shifted taps, applies bias / sigmoid / combine and the Haar synthesis.)
+// Same contract, same weight images and the same 54- (81-) plane output as the FUSE form of conv_fwd_kernel it replaces;
+// what changes is the orientation of the products.  There the pixels were the MFMA rows: the first product left a lane with
+// 4 pixels of ONE channel, the wrong shape for the second product's operand, so `mid` made a round trip through LDS, the
+// out-channel rows were split over the waves and only two of them ran the second GEMM.  Here the WEIGHTS are the A operand:
+//
+//   GEMM 1   D[row = out channel][col = pixel] += W1[row][k] * x[k][col]
+//            lane l ends up with mid[16m + 4(l>>4) + i][pixel l&15], i = 0..3, for every row tile m of its slice
+//   GEMM 2   that register IS the B operand of the second product for the K-step whose four K-lanes are the channels
+//            16m + 4g + i (g = 0..3): the sum over channels is order-free, so the K-steps simply run over (m, i) and the A
+//            operand is W3'[tap row][16m + 4g + i] -- a gather from the ordinary packed image (fragment 4m + g, lane
+//            16 i + (l & 15)).  No LDS traffic, no barrier, every wave takes part.
+//
+// A wave owns 16*NT pixels and C/RS mid channels of one side (blockIdx.y); RS > 1 (C = 256, whose level has only 5 760
+// pixels) splits the channels -- i.e. the second product's reduction -- over RS waves, whose 32 x 16 partial tiles meet in
+// LDS.  W1 and x are staged through LDS in K-chunks (register-prefetched double buffer, one barrier per chunk): the PG pixel
+// groups of a block share the weight chunk.  x rows are padded to a stride == 16 (mod 32) floats: the four K-lanes of a
+// fragment read hit disjoint banks.
+#include <algorithm>
+#include <cstdlib>
+#include "wmd_internal.h"
+
+namespace wmd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct HeadChainArgs {
+    const float* x;      // [B, C, plane]
+    const float* wp1;    // packed [2C, C, 1, 1]
+    const float* bias1;  // [2C] or null
+    const float* wp2;    // two packed [27, C, 1, 1] images
+    float* t;            // [B, t_planes, plane]
+    int plane, tiles, t_planes;
+    float slope;
+};
+
+template <int C, int RS, int PG, int NT, int KC>
+struct HeadChainTile {
+    static constexpr int NW = RS * PG, NTH = NW * 64;
+    static constexpr int PXB = PG * NT * 16;     // pixels of a block
+    static constexpr int MTS = C / 16;           // row tiles of one side
+    static constexpr int MT = MTS / RS;          // ... of one wave
+    static constexpr int KS = C / 4;             // K-steps of GEMM 1
+    static constexpr int NCH = KS / KC;          // staged chunks
+    static constexpr int XS = PXB + 16;          // x row stride in LDS: == 16 (mod 32) for PXB = 32, 64, 128
+    static constexpr int WF = MTS * KC * 64;     // floats of a weight chunk
+    static constexpr int XF = KC * 4 * XS;       // floats of an x chunk
+    static constexpr int NBUF = NCH > 1 ? 2 : 1;
+    static constexpr int WV = WF / 4 / NTH;                      // float4 per thread and weight chunk
+    static constexpr int XV = (KC * PXB + NTH - 1) / NTH;        // float4 per thread and x chunk (last one may be partial)
+    static constexpr int RED = RS > 1 ? NW * 2 * NT * 256 : 0;   // floats of the cross-wave reduction (aliases the chunks)
+    static constexpr int STAGE = NBUF * (WF + XF);
+    static constexpr int LDS_FLOATS = STAGE > RED ? STAGE : RED;
+    static_assert(C % 16 == 0 && MTS % RS == 0 && KS % KC == 0, "whole tiles");
+    static_assert(WF % (4 * NTH) == 0, "weight chunk = whole float4 per thread");
+    static_assert(XS % 32 == 16 && PXB % 4 == 0, "bank-conflict-free x rows");
+};
+
+template <class T, int KC>
+__device__ __forceinline__ void chain_fetch(float4 (&wreg)[T::WV], float4 (&xreg)[T::XV], const float* __restrict__ w1,
+                                            const float* __restrict__ xb, int c, int tid, int pix0, int plane) {
+#pragma unroll
+    for (int v = 0; v < T::WV; ++v) {
+        const int f = (v * T::NTH + tid) * 4;                     // float index inside the chunk: [row tile][KC*64]
+        const int m = f / (KC * 64), rem = f % (KC * 64);
+        wreg[v] = *reinterpret_cast<const float4*>(w1 + ((size_t)m * T::KS + c * KC) * 64 + rem);
+    }
+#pragma unroll
+    for (int v = 0; v < T::XV; ++v) {
+        const int q = v * T::NTH + tid;                           // float4 index: [channel of the chunk][PXB / 4]
+        const int chl = q / (T::PXB / 4), px = pix0 + (q % (T::PXB / 4)) * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < KC * T::PXB && px < plane)                        // plane % 4 == 0 (host check): a float4 never straddles the end
+            val = *reinterpret_cast<const float4*>(xb + (size_t)(c * KC * 4 + chl) * plane + px);
+        xreg[v] = val;
+    }
+}
+
+template <class T, int KC>
+__device__ __forceinline__ void chain_commit(const float4 (&wreg)[T::WV], const float4 (&xreg)[T::XV], float* ws, int tid) {
+    float* xs = ws + T::WF;
+#pragma unroll
+    for (int v = 0; v < T::WV; ++v) *reinterpret_cast<float4*>(ws + (v * T::NTH + tid) * 4) = wreg[v];
+#pragma unroll
+    for (int v = 0; v < T::XV; ++v) {
+        const int q = v * T::NTH + tid;
+        if (q < KC * T::PXB) *reinterpret_cast<float4*>(xs + (q / (T::PXB / 4)) * T::XS + (q % (T::PXB / 4)) * 4) = xreg[v];
+    }
+}
+
+template <int C, int RS, int PG, int NT, int KC>
+__global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChainArgs a) {
+    using T = HeadChainTile<C, RS, PG, NT, KC>;
+    constexpr int MT = T::MT, KS = T::KS, XS = T::XS, PXB = T::PXB, NTH = T::NTH;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = wave % RS, pg = wave / RS;   // channel slice, pixel group
+    const int g = lane >> 4, lc = lane & 15;
+    const int side = blockIdx.y;
+    const int tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const int pix0 = tile * PXB, plane = a.plane;
+    const float* xb = a.x + (size_t)b * C * plane;
+    const float* w1 = a.wp1 + (size_t)side * T::MTS * KS * 64;   // fragments [row tile][K-step][64 lanes]
+    const float* w2 = a.wp2 + (size_t)side * 2 * KS * 64;        // fragments [tap-row tile 0..1][K-step][64 lanes]
+
+    // ---- staging: chunk c = K-steps [c*KC, (c+1)*KC) of every row tile of W1_side, and channels [c*KC*4, +KC*4) of x ----
+    float4 wreg[T::WV], xreg[T::XV];
+
+    // ---- GEMM 1: acc[m][n] = rows 16(r*MT+m) .. +15 of W1_side x, pixels of group pg*NT + n ----------------------------
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    chain_fetch<T, KC>(wreg, xreg, w1, xb, 0, tid, pix0, plane);
+    chain_commit<T, KC>(wreg, xreg, lds, tid);
+    __syncthreads();
+    for (int c = 0; c < T::NCH; ++c) {
+        if (c + 1 < T::NCH) chain_fetch<T, KC>(wreg, xreg, w1, xb, c + 1, tid, pix0, plane);
+        const float* ws = lds + (c & (T::NBUF - 1)) * (T::WF + T::XF);
+        const float* xs = ws + T::WF;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            float xf[NT], wf[MT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) xf[n] = xs[(kk * 4 + g) * XS + (pg * NT + n) * 16 + lc];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) wf[m] = ws[((r * MT + m) * KC + kk) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[m], xf[n], acc[m][n], 0, 0, 0);
+        }
+        if (c + 1 < T::NCH) {
+            chain_commit<T, KC>(wreg, xreg, lds + ((c + 1) & (T::NBUF - 1)) * (T::WF + T::XF), tid);
+            __syncthreads();
+        }
+    }
+
+    // ---- bias + LeakyReLU in registers, then GEMM 2 straight from them ---------------------------------------------------
+    f32x4 acc2[2][NT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc2[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mg = r * MT + m;                                   // row tile within the side
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias1) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias1 + side * C + mg * 16 + g * 4);
+            bv[0] = b4.x, bv[1] = b4.y, bv[2] = b4.z, bv[3] = b4.w;
+        }
+        float w2f[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w2f[j][i] = w2[((size_t)j * KS + 4 * mg + g) * 64 + i * 16 + lc];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float mid = act_apply(acc[m][n][i] + bv[i], WMD_ACT_LEAKY, a.slope);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc2[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][i], mid, acc2[j][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- the channel slices of a pixel group meet in LDS (RS > 1), fixed order r = 0 .. RS-1 ------------------------------
+    if constexpr (RS > 1) {
+        __syncthreads();   // every wave is done with the staged chunks
+        float* red = lds + (size_t)wave * 2 * NT * 256;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                *reinterpret_cast<float4*>(red + ((j * NT + n) * 64 + lane) * 4) =
+                    make_float4(acc2[j][n][0], acc2[j][n][1], acc2[j][n][2], acc2[j][n][3]);
+        __syncthreads();
+        if (r != 0) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float4 s = *reinterpret_cast<const float4*>(lds + (size_t)(pg * RS) * 2 * NT * 256 + ((j * NT + n) * 64 + lane) * 4);
+#pragma unroll
+                for (int rr = 1; rr < RS; ++rr) {
+                    const float4 p = *reinterpret_cast<const float4*>(lds + (size_t)(pg * RS + rr) * 2 * NT * 256 + ((j * NT + n) * 64 + lane) * 4);
+                    s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;
+                }
+                acc2[j][n] = f32x4{s.x, s.y, s.z, s.w};
+            }
+    }
+
+    // ---- store: lane = (tap rows 16 j + 4 g + i, pixel lc of group n) -----------------------------------------------------
+    float* tb = a.t + ((size_t)b * a.t_planes + side * 27) * plane;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int px = pix0 + (pg * NT + n) * 16 + lc;
+        if (px >= plane) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = j * 16 + g * 4 + i;
+                if (row < 27) tb[(size_t)row * plane + px] = acc2[j][n][i];
+            }
+    }
+}
+
+template <int C, int RS, int PG, int NT, int KC>
+static void launch_chain(const HeadChainArgs& a, int B, hipStream_t s) {
+    using T = HeadChainTile<C, RS, PG, NT, KC>;
+    HeadChainArgs k = a;
+    k.tiles = (a.plane + T::PXB - 1) / T::PXB;
+    hipLaunchKernelGGL((head_chain_kernel<C, RS, PG, NT, KC>), dim3((unsigned)(B * k.tiles), 2), dim3(T::NTH), 0, s, k);
+}
+
+// -> true when the chained form took the launch (C = 64 / 128 / 256, image planes of a multiple of 4 pixels; WMD_HEAD_CHAIN=0
+// keeps the FUSE form of conv_fwd_kernel)
+bool head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s) {
+    static const bool on = [] {
+        const char* e = getenv("WMD_HEAD_CHAIN");
+        return !(e && atoi(e) == 0);
+    }();
+    const long plane = (long)g->H * g->W;
+    if (!on || (plane & 3) || plane > (1L << 28) || (g->C != 64 && g->C != 128 && g->C != 256)) return false;
+    HeadChainArgs a;
+    a.x = g->x;
+    a.wp1 = g->wp1;
+    a.bias1 = g->bias1;
+    a.wp2 = g->wp2;
+    a.t = g->t;
+    a.plane = (int)plane;
+    a.tiles = 0;
+    a.t_planes = t_planes;
+    a.slope = g->slope;
+    const double pix = (double)g->B * plane;
+    ProfScope prof("head_chain_kernel", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C), 4.0 * pix * (g->C + 54), s);
+    // (pixel-tile / wave-count / chunk variants -- 64 to 256 pixels, 2 to 16 waves, channel split 1 / 2 / 4 / 8 -- all measured
+    //  within +-2 us of these)
+    if (g->C == 64)
+        launch_chain<64, 1, 4, 2, 16>(a, g->B, s);    // 128 pixels x all 64 channels per wave quartet, one chunk
+    else if (g->C == 128)
+        launch_chain<128, 1, 4, 1, 8>(a, g->B, s);    // 64 pixels, 4 chunks of 32 channels
+    else
+        launch_chain<256, 4, 2, 1, 4>(a, g->B, s);    // 32 pixels, 4 waves share a pixel group's 256 channels, 16 chunks
+    return true;
+}
+
+}  // namespace wmd
