@@ -269,8 +269,10 @@ int wmd_head3x3_fwd(const wmd_head_args* args, void* stream);
 size_t wmd_head3x3_workspace_floats(const wmd_head_args* args);
 
 /* Fused inference form of a level's two high-frequency heads (depth_decoder.py:108-136):
- *   mid_s = LeakyReLU(W1_s x + b1_s)            s in {+,-}, both C -> C     (MFMA GEMM, result stays in LDS)
- *   t[s*27 + co*9 + tap] = sum_c W3_s[co,c,tap] * mid_s[c]                  (second MFMA GEMM of the same block)
+ *   mid_s = LeakyReLU(W1_s x + b1_s)            s in {+,-}, both C -> C     (MFMA GEMM, result stays on chip: for C = 64,
+ *                                                                            128, 256 in the accumulator registers, which are
+ *                                                                            the next product's operand -- head_chain_kernel)
+ *   t[s*27 + co*9 + tap] = sum_c W3_s[co,c,tap] * mid_s[c]                  (second MFMA GEMM of the same wave)
  * i.e. the 3x3 convolution regrouped as 27 tap-partial 1x1 outputs; wmd_head_shiftsum_fwd then gathers the
  * nine shifted taps, adds the bias, applies sigmoid / 2^(s-1)(sig+ - sig-) and (optionally) the Haar IDWT.
  * wp1: wmd_conv_pack_weights image of the stacked [2C, C, 1, 1] filter (+ rows first); bias1 [2C];
