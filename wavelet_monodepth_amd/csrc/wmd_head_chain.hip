@@ -97,7 +97,7 @@ __device__ __forceinline__ void chain_commit(const float4 (&wreg)[T::WV], const 
 template <int C, int RS, int PG, int NT, int KC>
 __global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChainArgs a) {
     using T = HeadChainTile<C, RS, PG, NT, KC>;
-    constexpr int MT = T::MT, KS = T::KS, XS = T::XS, PXB = T::PXB, NTH = T::NTH;
+    constexpr int MT = T::MT, KS = T::KS, XS = T::XS, PXB = T::PXB;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63;
