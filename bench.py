@@ -420,7 +420,7 @@ def roofline(dec, feats, steps):
     tot_ms = sum(r["ms"] for r in recs)
     conv_ms = sum(r["ms"] for r in convs)
     conv_fl = sum(r["flops"] for r in convs)
-    executed = lambda r: r["flops"] / (2.25 if is_wino(r) else 1.0)
+    executed = lambda r: r.get("mfma_flops", r["flops"])   # what the matrix pipe executes (the library reports it per launch)
     alg = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     ach = executed(dom) / (dom["ms"] * 1e-3) / 1e12
     traffic, traffic_src = None, None   # HBM bytes per launch: rocprofv3 --pmc passes of this same command (tools/profile_session.sh)

@@ -54,7 +54,8 @@ const char* wmd_status_string(int status);
 /* Opt-in kernel timing (the only process-global state in the library; not thread-safe).
  * Between begin and end every kernel launch of this library is bracketed by a hipEvent pair on
  * its launch stream.  wmd_profile_end synchronises and writes a JSON array
- *   [{"kernel": name, "calls": n, "ms": total, "flops": algorithmic FLOPs, "bytes": algorithmic bytes}, ...]
+ *   [{"kernel": name, "calls": n, "ms": total, "flops": algorithmic FLOPs, "bytes": algorithmic bytes,
+ *     "mfma_flops": FLOPs the matrix pipe executes (Winograd kernels: fewer than algorithmic)}, ...]
  * into buf (truncated to cap); returns the number of bytes needed, or a negative wmd_status.    */
 int wmd_profile_begin(void);
 long wmd_profile_end(char* buf, size_t cap);

@@ -107,6 +107,12 @@ CONV_CASES = [
     (1, 138, 0, 1, 3, 9, 11, 3, "zero", "none"),         # tiny Cout through the MFMA path
     (3, 8, 0, 1, 16, 2, 2, 3, "reflect", "sigmoid"),     # smallest legal reflect size
     (1, 5, 0, 1, 4, 1, 9, 3, "zero", "none"),            # H = 1
+    # upsampled operand under every pad mode, whole chunks of 8 channels (the low-resolution Winograd path of
+    # conv_wino32_kernel: the pad ring maps onto the border source pixel / onto zero), tile overhang in both directions
+    (2, 16, 16, 2, 20, 12, 24, 3, "zero", "elu"),
+    (1, 8, 24, 2, 33, 10, 20, 3, "replicate", "leaky"),
+    (1, 16, 16, 2, 40, 18, 44, 3, "reflect", "none"),
+    (2, 24, 0, 2, 32, 8, 16, 3, "reflect", "elu"),       # upsample without a skip tensor
 ]
 
 
@@ -151,9 +157,9 @@ def test_conv_every_tile_configuration_and_split(dev):
         l = _lib.lib()
         tested = 0
         for i, name in enumerate(names):
-            if name.startswith("conv_wino_kernel") and ww is None:   # family switched off (WMD_WINOGRAD=0)
+            if name.startswith("conv_wino") and ww is None:   # family switched off (WMD_WINOGRAD=0)
                 continue
-            if not (name.endswith(",%d>" % (9 if k == 3 else 1)) or (k == 3 and name.startswith("conv_wino_kernel"))):
+            if not (name.endswith(",%d>" % (9 if k == 3 else 1)) or (k == 3 and name.startswith("conv_wino"))):
                 continue
             for ks in (1, 2, 3):
                 y = torch.full((B, Cout, H, W), float("nan"), device=dev)
@@ -196,7 +202,7 @@ def test_conv_winograd_configurations(dev, case):
     l = _lib.lib()
     tested = 0
     for i, name in enumerate(tuner.config_names()):
-        if not name.startswith("conv_wino_kernel"):
+        if not name.startswith("conv_wino"):
             continue
         for ks in (1, 2):
             y = torch.full((B, Cout, H, W), float("nan"), device=dev)

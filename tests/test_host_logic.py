@@ -103,7 +103,7 @@ def test_tuner_picks_the_fastest_valid_candidate(monkeypatch):
     import torch
     from wavelet_monodepth_amd import tuner
     names = tuner.config_names()
-    cands = [i + 1 for i, n in enumerate(names) if n.endswith(",9>") or n.startswith("conv_wino_kernel")]
+    cands = [i + 1 for i, n in enumerate(names) if n.endswith(",9>") or n.startswith("conv_wino")]
     fast, refused, hopeless = cands[3], cands[1], cands[5]
     calls = []
 

@@ -21,7 +21,7 @@ namespace {
 struct ProfRec {
     std::string name;
     hipEvent_t e0, e1;
-    double flops, bytes;
+    double flops, bytes, mfma_flops;
 };
 std::vector<ProfRec> g_prof;
 }  // namespace
@@ -31,6 +31,7 @@ int prof_open(const char* name, double flops, double bytes, hipStream_t s) {
     r.name = name;
     r.flops = flops;
     r.bytes = bytes;
+    r.mfma_flops = flops;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
     hipEventRecord(r.e0, s);
     g_prof.push_back(r);
@@ -38,6 +39,8 @@ int prof_open(const char* name, double flops, double bytes, hipStream_t s) {
 }
 
 void prof_close(int idx, hipStream_t s) { hipEventRecord(g_prof[idx].e1, s); }
+
+void prof_set_mfma(int idx, double mfma_flops) { g_prof[idx].mfma_flops = mfma_flops; }
 
 }  // namespace wmd
 
@@ -55,7 +58,7 @@ extern "C" long wmd_profile_end(char* buf, size_t cap) {
     wmd::g_prof_on = false;
     struct Agg {
         long calls = 0;
-        double ms = 0, flops = 0, bytes = 0;
+        double ms = 0, flops = 0, bytes = 0, mfma = 0;
     };
     std::map<std::string, Agg> agg;
     std::vector<std::string> order;
@@ -69,6 +72,7 @@ extern "C" long wmd_profile_end(char* buf, size_t cap) {
         a.ms += ms;
         a.flops += r.flops;
         a.bytes += r.bytes;
+        a.mfma += r.mfma_flops;
         hipEventDestroy(r.e0);
         hipEventDestroy(r.e1);
     }
@@ -77,8 +81,8 @@ extern "C" long wmd_profile_end(char* buf, size_t cap) {
     for (size_t i = 0; i < order.size(); ++i) {
         const Agg& a = agg[order[i]];
         char line[512];
-        snprintf(line, sizeof(line), "%s{\"kernel\": \"%s\", \"calls\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
-                 i ? ", " : "", order[i].c_str(), a.calls, a.ms, a.flops, a.bytes);
+        snprintf(line, sizeof(line), "%s{\"kernel\": \"%s\", \"calls\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, \"mfma_flops\": %.6e}",
+                 i ? ", " : "", order[i].c_str(), a.calls, a.ms, a.flops, a.bytes, a.mfma);
         out += line;
     }
     out += "]";

@@ -1,0 +1,99 @@
+// Shared by the dense-decoder convolution kernels (wmd_conv_fwd.hip: direct implicit GEMM + Winograd on 16x16x4 MFMAs;
+// wmd_conv_wino32.hip: Winograd on 32x32x2 MFMAs): kernel argument block, XCD-aware work order, LDS-DMA wrappers.
+#pragma once
+#include "wmd_internal.h"
+
+namespace wmd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvKArgs {
+    const float* x1;
+    const float* x2;
+    const float* wp;
+    const float* bias;
+    float* y;        // final output (ksplit == 1) or split-K partials [ksplit][B,Cout,H,W]
+    int B, H, W, H1, W1;
+    int C1, C2, Cin, Cout, up1;
+    int shift1;      // x1 is read at (y - shift1, x - shift1), zero outside its H1 x W1 extent (dgrad: the
+                     // "full" correlation is a zero-padded one over a 1-pixel-extended gradient image)
+    int pad_mode, act;
+    float slope;
+    int tiles_x, tiles_y;
+    int nci4;        // padded number of 4-channel K groups in wp
+    int ncot;        // number of 16-out-channel tiles in wp
+    int nchunks;     // ceil(Cin / CK)
+    int ksplit, chunks_per_split;
+    // fused wavelet head (FUSE kernels only): second GEMM over the LeakyReLU'd block result
+    const float* wp2;   // per side: packed [27 -> 32 rows, CO_T] image
+    float* t;           // [B, sides*27, H*W]
+    int t_ctot;
+    int t_row0;   // first plane of t this launch writes
+    // optional multiplicative gate of the final output (data-gradient path): y *= gate_act'(gate), gate laid out like y
+    const float* gate;
+    int gate_act;
+    float gate_slope;
+    // block-sparse execution (threshold-gated sparse decoder on the dense kernels): a block whose TH x TW pixel tile holds
+    // no pixel of out_mask [B,H,W] returns at once (it tests the tile's mask bytes itself: no tile list, no counter, no
+    // extra launch); a padded input position outside in_mask [B,H,W] reads 0 (the mask test follows the coordinate padding,
+    // layers.py:439-453) and outputs outside out_mask are written as 0
+    const uint8_t* in_mask;
+    const uint8_t* out_mask;
+    // out-channel slabs per pixel tile when the grid is 1-D (0: the slab is blockIdx.y -- the fused-head launches)
+    int cob;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and every XCD has its own L2.  Spatially adjacent
+// tiles share halo rows and 128-byte lines, so give each XCD one contiguous run of the tile sequence instead of every
+// eighth tile (speed only: correctness never depends on the placement).
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// LDS-DMA wrappers.  They are deliberately NOT templates: inside a dependent context hipcc's host pass rejects
+// the 16-byte form (a gfx950 feature check against the host target) and silently drops the kernel's host stub.
+__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+}
+
+// conv_wino32_kernel (wmd_conv_wino32.hip): tile geometry, shared with the configuration table in wmd_conv_fwd.hip.
+// Block = WN tile groups (32 Winograd tiles = 128 pixels each) x 2 position halves, one 32-out-channel slab.
+template <int TH, int TW, int WN, int CK>
+struct W32Tile {
+    static constexpr int NW = WN * 2, NT = NW * 64;
+    static constexpr int TXB = TW / 2, TYB = TH / 2, NTILES = TXB * TYB;
+    static constexpr int PH = TH + 2, PWS = TW + 2;          // full-resolution patch: rows x row stride (even: 8-byte reads)
+    static constexpr int PSF = PH * PWS;
+    static constexpr int PHL = TH / 2 + 2, PWL = TW / 2 + 2, PSL = PHL * PWL;   // low-resolution patch of the upsampled operand
+    static constexpr int NPOSF = (PSF + NT - 1) / NT, NPOSL = (PSL + NT - 1) / NT;
+    static constexpr int RUN = CK * 256;       // one 16-out-channel run of a chunk: (CK/4) K-steps x 16 positions x 64 floats
+    static constexpr int RUN_LDS = RUN + 16;   // the two runs a 32-lane read group touches fall on disjoint bank halves
+    static constexpr int A_FLOATS = 2 * RUN_LDS;
+    static constexpr int B_FLOATS = ((CK * PSF + 63) / 64) * 64;   // whole 64-dword LDS-DMA runs (tail = padding)
+    static constexpr int NAV = (2 * CK * 64 + NT - 1) / NT;   // 16-byte weight pieces per thread and chunk
+    static constexpr int BUF_FLOATS = B_FLOATS + A_FLOATS;
+    static constexpr int KW = CK / 2;          // 2-channel K-steps per chunk
+    static constexpr int XCH_FLOATS = WN * 2 * 32 * 64;   // the two halves of a group trade 32 partial outputs per lane
+    static constexpr int LDS_FLOATS = 2 * BUF_FLOATS > XCH_FLOATS ? 2 * BUF_FLOATS : XCH_FLOATS;
+    static_assert(TH % 2 == 0 && TW % 8 == 0, "whole 2x2 tiles; a lane's four consecutive tiles stay in one tile row");
+    static_assert(WN * 32 >= NTILES, "more tiles than MFMA rows");
+    static_assert(CK % 4 == 0, "chunks are whole 4-channel weight fragments");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+};
+
+// conv_wino32_kernel's flattened-staging instantiation needs every chunk inside one source tensor, one full-resolution
+// geometry and no masks; everything else runs the GENERIC instantiation
+inline bool wino32_pure(const ConvKArgs& a, int CK) {
+    return !a.in_mask && !a.out_mask && (a.Cin % CK) == 0 && (a.C2 == 0 || (a.C1 % CK) == 0) && (a.C2 == 0 || a.shift1 == 0);
+}
+
+template <int TH, int TW, int WN, int CK>
+void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s);   // explicit instantiations: wmd_conv_wino32_table.inc
+
+}  // namespace wmd

@@ -25,47 +25,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
-#include "wmd_internal.h"
+#include "wmd_conv_common.h"
 
 namespace wmd {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvKArgs {
-    const float* x1;
-    const float* x2;
-    const float* wp;
-    const float* bias;
-    float* y;        // final output (ksplit == 1) or split-K partials [ksplit][B,Cout,H,W]
-    int B, H, W, H1, W1;
-    int C1, C2, Cin, Cout, up1;
-    int shift1;      // x1 is read at (y - shift1, x - shift1), zero outside its H1 x W1 extent (dgrad: the
-                     // "full" correlation is a zero-padded one over a 1-pixel-extended gradient image)
-    int pad_mode, act;
-    float slope;
-    int tiles_x, tiles_y;
-    int nci4;        // padded number of 4-channel K groups in wp
-    int ncot;        // number of 16-out-channel tiles in wp
-    int nchunks;     // ceil(Cin / CK)
-    int ksplit, chunks_per_split;
-    // fused wavelet head (FUSE kernels only): second GEMM over the LeakyReLU'd block result
-    const float* wp2;   // per side: packed [27 -> 32 rows, CO_T] image
-    float* t;           // [B, sides*27, H*W]
-    int t_ctot;
-    int t_row0;   // first plane of t this launch writes
-    // optional multiplicative gate of the final output (data-gradient path): y *= gate_act'(gate), gate laid out like y
-    const float* gate;
-    int gate_act;
-    float gate_slope;
-    // block-sparse execution (threshold-gated sparse decoder on the dense kernels): a block whose TH x TW pixel tile holds
-    // no pixel of out_mask [B,H,W] returns at once (it tests the tile's mask bytes itself: no tile list, no counter, no
-    // extra launch); a padded input position outside in_mask [B,H,W] reads 0 (the mask test follows the coordinate padding,
-    // layers.py:439-453) and outputs outside out_mask are written as 0
-    const uint8_t* in_mask;
-    const uint8_t* out_mask;
-    // out-channel slabs per pixel tile when the grid is 1-D (0: the slab is blockIdx.y -- the fused-head launches)
-    int cob;
-};
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, int NBUF = 2>
 struct ConvTile {
@@ -91,25 +53,6 @@ struct ConvTile {
     static_assert(A_FLOATS % 4 == 0, "the weight tile is moved in 16-byte pieces (a partial last wave is exec-masked)");
     static_assert(TW % 4 == 0, "four consecutive pixels of an accumulator row must not straddle image rows");
 };
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and every XCD has its own L2.  Spatially adjacent
-// tiles share halo rows and 128-byte lines, so give each XCD one contiguous run of the tile sequence instead of every
-// eighth tile (speed only: correctness never depends on the placement).
-__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
-    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// LDS-DMA wrappers.  They are deliberately NOT templates: inside a dependent context hipcc's host pass rejects
-// the 16-byte form (a gfx950 feature check against the host target) and silently drops the kernel's host stub.
-__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 4, voff, soff, 0, 0);
-}
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
-}
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, bool FUSE = false, int NBUF = 2>
 __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a) {
@@ -866,6 +809,12 @@ static void launch_wino(const ConvKArgs& a, dim3 grid, hipStream_t s) {
             &launch_wino<TH, TW, MRW, WM, WN, CK>, "conv_wino_kernel<" #TH "," #TW "," #MRW "," #WM "," #WN "," #CK ">" \
     }
 
+// conv_wino32_kernel (wmd_conv_wino32.hip) entries: TAPS = 17 marks the family (Winograd weight image, 3x3 semantics);
+// MR = 2 (a block's slab = 32 out channels), NR = 1 and WN = waves / WM so that the planner's block-shape arithmetic holds
+#define WMD_W32_INST(TH, TW, WN, CK)                                                                                   \
+    ConvCfg{TH, TW, 2, 1, 1, (WN) * 2, CK, 17, (int)sizeof(float) * W32Tile<TH, TW, WN, CK>::LDS_FLOATS,              \
+            &launch_wino32<TH, TW, WN, CK>, "conv_wino32_kernel<" #TH "," #TW "," #WN "," #CK ">"},
+
 static const ConvCfg kCfgs[] = {
     // 3x3, 32-wide rows (W % 32 == 0: 160/320, 1024-wide pyramids)
     WMD_CFG(16, 32, 2, 8, 1, 4, 8, 9),  // co32  x 512px
@@ -930,6 +879,8 @@ static const ConvCfg kCfgs[] = {
     WMD_WINO(8, 16, 1, 1, 2, 8),    // co16 x 128px, 2 waves
     WMD_WINO(16, 32, 1, 1, 8, 8),   // co16 x 512px, 8 waves
     WMD_WINO(16, 32, 1, 2, 8, 8),   // co32 x 512px, 16 waves
+    // Winograd on 32x32x2 MFMAs, two position halves per tile group
+#include "wmd_conv_wino32_table.inc"
     // 1x1 on the flattened image (TH = 1)
     WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
     WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px
@@ -962,7 +913,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
     bool found = false;
     for (int i = 0; i < kNumCfgs; ++i) {
         const ConvCfg& c = kCfgs[i];
-        const bool wino = c.TAPS == 16;
+        const bool wino = c.TAPS >= 16;
         if (wino ? (taps != 9 || !g->wp_wino) : c.TAPS != taps) continue;
         if ((g->in_mask || g->out_mask) && !wino) continue;   // block-sparse execution lives in the Winograd kernels
         if (force >= 0 && force != i) continue;
@@ -990,7 +941,8 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             double per_cu_blocks = (double)rounds * std::min<double>(bpc, std::max(1.0, (double)nblk / kNumCU / rounds));
             double cycles = per_cu_blocks * block_macs_per_chunk * cps / std::max(rate, 1.0);
             cycles += 3000.0 * rounds;            // prologue/epilogue per block round
-            if (wino) cycles *= 1.3;              // transforms + 1.5 LDS reads per MFMA: measured, not modelled
+            if (c.TAPS == 16) cycles *= 1.3;      // transforms + 1.5 LDS reads per MFMA: measured, not modelled
+            if (c.TAPS == 17) cycles *= 0.8;      // 32x32x2 form: fewer MFMAs on upsampled operands, lighter issue stream
             if (ks_eff > 1) cycles += 6000.0;     // reduce pass launch
             if (cycles < best) {
                 best = cycles;
@@ -1288,7 +1240,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     ConvPlan plan;
     if (!plan_conv(g, &plan, g->workspace != nullptr, g->workspace_floats)) return fail(WMD_ERR_UNSUPPORTED, "wmd_conv_fwd: no kernel configuration");
     const ConvCfg& c = *plan.cfg;
-    const bool wino = c.TAPS == 16;           // Winograd configuration: transformed weight image, 3x3 semantics
+    const bool wino = c.TAPS >= 16;           // Winograd configuration (16: 16x16x4 kernels, 17: 32x32x2 kernels): transformed weight image, 3x3 semantics
     const int taps = wino ? 9 : c.TAPS;
     ConvKArgs a;
     a.x1 = g->x1;
@@ -1343,6 +1295,11 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
         ProfScope prof(c.name, 2.0 * a.Cin * taps * g->Cout * pix,
                        4.0 * (pix * g->C1 / (a.up1 * a.up1) + pix * g->C2 + (double)a.Cin * taps * g->Cout + pix * g->Cout),
                        (hipStream_t)stream);
+        if (c.TAPS == 16) prof.mfma(2.0 * a.Cin * 9 * g->Cout * pix / 2.25);
+        if (c.TAPS == 17) {   // 32x32x2 MFMAs of 4096 FLOP: per block (waves / 2) tile groups x chunks x K-steps x positions
+            const int n_up = (wino32_pure(a, c.CK) && a.up1 == 2) ? a.C1 / c.CK : 0;
+            prof.mfma(4096.0 * grid.x * grid.y * (c.WN / 2) * (c.CK / 2) * (9.0 * n_up + 16.0 * (plan.nchunks - n_up)));
+        }
         c.launch(a, grid, (hipStream_t)stream);
     }
     st = check_launch("conv_fwd_kernel");

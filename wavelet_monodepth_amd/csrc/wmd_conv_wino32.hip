@@ -1,0 +1,498 @@
+// Winograd F(2x2,3x3) trunk convolution on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Same operator as conv_wino_kernel (wmd_conv_fwd.hip): ConvBlock / Conv3x3 + nearest upsample + skip concat + pad of the
+// reference (KITTI/layers.py:120-161,233-236; depth_decoder.py:145-150), Y = A^T [(G g G^T) (.) (B^T d B)] A, the same
+// fragment-ordered Winograd weight image (wmd_conv_pack_weights_wino) and the same LDS-DMA gather of the virtual padded /
+// upsampled / concatenated input.  What changes is the shape of the work around the matrix pipe -- round 2's counters showed
+// the 16x16x4 kernel issue-bound at 11.7 instructions per 32-cycle MFMA (profiles/r02_wino_counters.md):
+//
+//   * MFMA 32x32x2: a wave owns 32 tiles (MFMA rows) x 32 out channels (columns) x 8 of the 16 transformed positions = 8 x 16
+//     accumulator registers; the two waves of a tile group ("halves") share a SIMD's matrix pipe.  A lane holds ONE tile and
+//     ONE of the K-step's two channels: 6 ds_read_b64 of its patch + 18 adds (its half of B^T d B) + 8 ds_read_b32 (weight
+//     fragments) feed 8 MFMAs of 64 cycles each -- 4 instructions per 64-cycle MFMA instead of 11.7 per 32.
+//   * The 2x-nearest-upsampled operand (upconv(i,1): decoder channels first, depth_decoder.py:146) is staged at its OWN
+//     resolution.  A 4x4 patch of an upsampled map has rows 1,2 and columns 1,2 pairwise equal (the same source pixel), so
+//     B^T d B vanishes identically on transformed row 2 and column 2: 9 of the 16 positions remain, computed from the 3x3
+//     low-resolution neighbourhood -- 7/16 of the MFMAs of those channels, 3/4 of their LDS-DMA traffic and the >>1 gather
+//     disappear.  Exact: d1 + d2 = 2 s1 and d2 - d1 = 0 hold bitwise.  The halves own 5 and 4 of the 9 (8 and 8 of the 16).
+//   * Y = A^T M A is linear in M, so each half transforms the positions it owns into a partial 2x2 output; the halves trade
+//     one output row through LDS and each finishes (bias, activation, 16-byte stores) the row it keeps.
+// Weight fragments come from the ordinary 16x16x4 image: the B operand of K-step k2 (channels 2 k2, 2 k2 + 1) for column
+// j = l & 31 is element (co16 = j & 15, ci4 = 2 (k2 & 1) + (l >> 5)) of fragment [j >> 4][k2 >> 1][xi] -- a per-lane base plus
+// immediates; the two 16-channel runs are staged 16 floats apart (mod 32) so a 32-lane read group covers all 32 banks.
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+#include "wmd_conv_common.h"
+
+namespace wmd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// compile-time loop: f(integral_constant<int, I>) for I = 0 .. N-1, expanded by the front end (a `#pragma unroll` loop over
+// the MFMA groups with the piece test inside exceeds the optimizer's full-unroll budget, and a rolled loop would index the
+// accumulators at run time)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Which half owns transformed position xi = 4 r + c.  Half 0: row 0 and the left 2x2 of rows 1-2; half 1: the rest.  Of the
+// nine positions an upsampled operand reaches (rows / columns 0, 1, 3) half 0 holds five, half 1 four.
+__host__ __device__ constexpr bool w32_owns(int hf, int xi) {
+    const int r = xi / 4, c = xi % 4;
+    const bool h0 = r == 0 || ((r == 1 || r == 2) && c < 2);
+    return hf == 0 ? h0 : !h0;
+}
+__host__ __device__ constexpr bool w32_up_reaches(int xi) { return xi / 4 != 2 && xi % 4 != 2; }
+// the p-th owned position (ascending); UP: only the positions an upsampled operand reaches
+__host__ __device__ constexpr int w32_nth(int hf, bool up, int p) {
+    int n = 0;
+    for (int xi = 0; xi < 16; ++xi)
+        if (w32_owns(hf, xi) && (!up || w32_up_reaches(xi))) {
+            if (n == p) return xi;
+            ++n;
+        }
+    return -1;
+}
+__host__ __device__ constexpr int w32_count(int hf, bool up) {
+    int n = 0;
+    for (int xi = 0; xi < 16; ++xi) n += (w32_owns(hf, xi) && (!up || w32_up_reaches(xi))) ? 1 : 0;
+    return n;
+}
+__host__ __device__ constexpr int w32_slot(int hf, int xi) {   // accumulator index of an owned position
+    int n = 0;
+    for (int x = 0; x < xi; ++x) n += w32_owns(hf, x) ? 1 : 0;
+    return n;
+}
+// A^T = [[1,1,1,0],[0,1,-1,-1]]
+__host__ __device__ constexpr int w32_at(int a, int r) { return a == 0 ? (r < 3 ? 1 : 0) : (r == 0 ? 0 : (r == 1 ? 1 : -1)); }
+
+__device__ __forceinline__ float elu_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
+__device__ __forceinline__ float act_apply_fast(float v, int act, float slope) {
+    // ELU through v_exp_f32: |error| <= 1.2e-7 absolute (the cancellation in e^v - 1 near 0 costs RELATIVE accuracy of
+    // values that are themselves < 1e-3; the trunk's tolerance is relative to the tensor's scale)
+    return act == WMD_ACT_ELU ? elu_fast(v) : act_apply(v, act, slope);
+}
+
+// GENERIC = false: every chunk of CK channels lies inside one source tensor, no masks (every trunk layer of the decoders).
+//   The chunk's patch is staged as ONE flattened [channel][position] run: every LDS-DMA instruction moves 64 consecutive
+//   dwords of it from per-lane offsets that are fixed for the whole layer (channel x plane + gathered position), the chunk is
+//   a scalar base -- no per-piece predication, channel arithmetic or branches in the MFMA stream; the upsampled operand takes
+//   the structured low-resolution path.
+// GENERIC = true: ragged channel counts, chunks that straddle the concat boundary, block-sparse masks (in_mask / out_mask of
+//   the sparse decoders): per-channel pieces with a per-piece source choice, upsampling through the >>1 gather.
+template <int TH, int TW, int WN, int CK, bool GENERIC>
+__global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArgs a) {
+    using T = W32Tile<TH, TW, WN, CK>;
+    constexpr int NT = T::NT, PWS = T::PWS, PSF = T::PSF, PWL = T::PWL, PSL = T::PSL;
+    constexpr int KW = T::KW, TXB = T::TXB;
+    constexpr bool MASKED = GENERIC;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves w and w + WN are the two halves of tile group w % WN; a workgroup's waves are dealt to the four SIMDs cyclically,
+    // so for WN = 4 the halves of a group share a SIMD (their MFMA counts on an upsampled chunk, 5 + 4, add up evenly)
+    const int wn = wave % WN;
+    const int hf = wave / WN;
+
+    int t, by;
+    if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD (see conv_fwd_kernel)
+        const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+        t = item / a.cob;
+        by = item - t * a.cob;
+    } else {
+        t = xcd_contiguous(blockIdx.x, gridDim.x);
+        by = blockIdx.y;
+    }
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ks = blockIdx.z;
+    const int H = a.H, W = a.W;
+    if (MASKED && a.out_mask) {   // block-sparse: a tile without active output pixels keeps its zeros
+        int any = 0;
+        for (int i = tid; i < TH * TW; i += NT) {
+            const int yy = y0 + i / TW, xx = x0 + i % TW;
+            if (yy < H && xx < W) any |= a.out_mask[(size_t)b * H * W + (size_t)yy * W + xx];
+        }
+        if (!__syncthreads_or(any)) return;
+    }
+    const bool upl = !GENERIC && a.up1 == 2;   // structured low-resolution path of the upsampled operand
+
+    // ---- staging geometry ---------------------------------------------------------------------------------------
+    constexpr unsigned kOOB = 0x80000000u;   // >= any num_records: the descriptor's range check returns 0
+    const size_t plane1 = (size_t)a.H1 * a.W1, plane2 = (size_t)H * W;
+    const unsigned pb1 = (unsigned)(plane1 * 4), pb2 = (unsigned)(plane2 * 4);
+    // byte offset of full-resolution patch position p inside one channel plane of x2 (o2) / of x1 (o1)
+    auto full_pos = [&](int p, unsigned& o1, unsigned& o2) {
+        const int py = p / PWS, px = p % PWS;
+        int gy = y0 + py - 1, gx = x0 + px - 1;
+        bool ok = p < PSF;
+        ok = pad_coord(gy, H, a.pad_mode) && ok;
+        ok = pad_coord(gx, W, a.pad_mode) && ok;
+        ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
+        gy = min(max(gy, 0), H - 1);
+        gx = min(max(gx, 0), W - 1);
+        if (MASKED && a.in_mask) ok = ok && a.in_mask[(size_t)b * H * W + gy * W + gx] != 0;
+        o2 = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
+        int sy = gy - a.shift1, sx = gx - a.shift1;
+        if (a.up1 == 2) {
+            sy = gy >> 1;
+            sx = gx >> 1;
+        }
+        const bool ok1 = ok && sy >= 0 && sx >= 0 && sy < a.H1 && sx < a.W1;
+        o1 = ok1 ? (unsigned)(sy * a.W1 + sx) * 4u : kOOB;
+    };
+    // low-resolution halo patch of the upsampled operand: position (py, px) is source pixel (y0/2 - 1 + py, x0/2 - 1 + px).
+    // The full-resolution pad ring (row -1 / row H) maps onto it as: reflect (-1 -> 1, H -> H-2) and replicate both land in the
+    // border source pixel, zero padding stays zero; rows beyond the ring (tile overhang) are never used by a stored output.
+    auto low_pos = [&](int p) {
+        const int py = p / PWL, px = p % PWL;
+        int sy = (y0 >> 1) - 1 + py, sx = (x0 >> 1) - 1 + px;
+        bool ok = p < PSL && sy <= a.H1 && sx <= a.W1;
+        if (sy < 0 || sy >= a.H1) ok = ok && a.pad_mode != WMD_PAD_ZERO;
+        if (sx < 0 || sx >= a.W1) ok = ok && a.pad_mode != WMD_PAD_ZERO;
+        sy = min(max(sy, 0), a.H1 - 1);
+        sx = min(max(sx, 0), a.W1 - 1);
+        return ok ? (unsigned)(sy * a.W1 + sx) * 4u : kOOB;
+    };
+    // pure layers: flattened [channel][position] runs of a chunk, element tid + i * NT
+    constexpr int NPF = GENERIC ? 1 : (CK * PSF + NT - 1) / NT, NPL = GENERIC ? 1 : (CK * PSL + NT - 1) / NT;
+    // generic layers: positions tid + i * NT of one channel
+    constexpr int NPOSF = GENERIC ? T::NPOSF : 1;
+    unsigned obF[NPF], obL[NPL], ob1[NPOSF], ob2[NPOSF];
+    if constexpr (!GENERIC) {
+        // the full-resolution chunks of a pure layer all have one geometry: the skip tensor's when x1 is upsampled (x1 then
+        // takes the low-resolution path), else x1's own (a skip tensor beside a non-upsampled x1 has the same H x W)
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + i * NT, ch = e / PSF;
+            unsigned o1, o2;
+            full_pos(e % PSF, o1, o2);
+            const unsigned o = a.up1 == 2 ? o2 : o1, pb = a.up1 == 2 ? pb2 : pb1;
+            obF[i] = (ch < CK && o != kOOB) ? (unsigned)ch * pb + o : kOOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int e = tid + i * NT, ch = e / PSL;
+            const unsigned o = low_pos(e % PSL);
+            obL[i] = (ch < CK && o != kOOB) ? (unsigned)ch * pb1 + o : kOOB;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NPOSF; ++i) full_pos(tid + i * NT, ob1[i], ob2[i]);
+    }
+    const float* x1b = a.x1 + (size_t)b * a.C1 * plane1;
+    const float* x2b = a.x2 ? a.x2 + (size_t)b * a.C2 * plane2 : a.x1;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x1b), 0, (int)(a.C1 * plane1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x2b), 0, (int)(a.C2 * plane2 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wp), 0, (int)((size_t)a.ncot * a.nci4 * 16 * 64 * 4), 0x00020000);
+    // weights: the slab's two 16-channel runs of a chunk as 16-byte pieces; piece e -> run e / (CK*64), slot e % (CK*64)
+    unsigned aoff[T::NAV];
+#pragma unroll
+    for (int v = 0; v < T::NAV; ++v) {
+        const int e = tid + v * NT;
+        const int run = e / (CK * 64), rem = e % (CK * 64);
+        const int cot = min(by * 2 + run, a.ncot - 1);
+        aoff[v] = e < 2 * CK * 64 ? (unsigned)(((size_t)cot * a.nci4 * 16 * 64 + (size_t)rem * 4) * 4) : kOOB;
+    }
+
+    // Chunk kinds: UP = CK channels of the upsampled x1, staged at low resolution (pure layers only); FULL = anything else.
+    auto is_up = [&](int chunk) { return upl && (chunk + 1) * CK <= a.C1; };
+    // wave-instructions per chunk and wave: pure layers move whole 64-dword runs (the tail lanes of the last one carry the
+    // out-of-range offset and write zeros into the buffer's padding), generic layers one channel's positions at a time
+    constexpr int NPB_F = GENERIC ? CK * NPOSF : NPF, NPB_L = NPL;
+    struct ChunkSrc {   // pure layers: the chunk's descriptor and scalar byte base, resolved once per chunk
+        __amdgpu_buffer_rsrc_t r;
+        unsigned base;
+    };
+    auto chunk_src = [&](int chunk) {
+        ChunkSrc cs;
+        const int ci0 = chunk * CK;
+        const bool in1 = ci0 < a.C1;
+        cs.r = in1 ? r1 : r2;
+        cs.base = in1 ? (unsigned)ci0 * pb1 : (unsigned)(ci0 - a.C1) * pb2;
+        return cs;
+    };
+    auto stage_weight_piece = [&](int chunk, float* bufp, int v) {
+        const unsigned soffA = (unsigned)chunk * (unsigned)(T::RUN * 4);
+        const int e0 = wave * 64 + v * NT;   // first piece of this wave-instruction (a multiple of 64: inside one run)
+        if (T::NAV * NT == 2 * CK * 64 || e0 < 2 * CK * 64)   // wave-uniform: whole wave-instructions only
+            lds_dma16(rw, (lds_ptr_t)(bufp + T::B_FLOATS + (e0 / (CK * 64)) * T::RUN_LDS + (e0 % (CK * 64)) * 4), aoff[v], soffA);
+    };
+    auto stage_full_piece = [&](int chunk, float* bufp, int q, const ChunkSrc& cs) {
+        if (q < NPB_F) {
+            if constexpr (!GENERIC) {
+                if ((q + 1) * NT <= CK * PSF || wave * 64 + q * NT < CK * PSF)   // wave-uniform: skip wholly empty runs
+                    lds_dma4(cs.r, (lds_ptr_t)(bufp + wave * 64 + q * NT), obF[q], cs.base);
+            } else {
+                const int j = q / NPOSF, i = q % NPOSF;
+                if ((i + 1) * NT <= PSF || tid + i * NT < PSF) {
+                    lds_ptr_t d = (lds_ptr_t)(bufp + wave * 64 + j * PSF + i * NT);
+                    const int ci = chunk * CK + j;
+                    const bool from_x1 = ci < a.C1;
+                    const bool chan_ok = ci < a.Cin;
+                    const unsigned soff = from_x1 ? (unsigned)ci * pb1 : (unsigned)max(ci - a.C1, 0) * pb2;
+                    const unsigned vo = chan_ok ? (from_x1 ? ob1[i] : ob2[i]) : kOOB;
+                    if (from_x1) lds_dma4(r1, d, vo, soff);
+                    else lds_dma4(r2, d, vo, soff);
+                }
+            }
+        } else {
+            stage_weight_piece(chunk, bufp, q - NPB_F);
+        }
+    };
+    auto stage_up_piece = [&](int chunk, float* bufp, int q) {
+        if (q < NPB_L) {
+            if ((q + 1) * NT <= CK * PSL || wave * 64 + q * NT < CK * PSL)
+                lds_dma4(r1, (lds_ptr_t)(bufp + wave * 64 + q * NT), obL[q], (unsigned)(chunk * CK) * pb1);
+        } else {
+            stage_weight_piece(chunk, bufp, q - NPB_L);
+        }
+    };
+
+    const int c_begin = ks * a.chunks_per_split;
+    const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
+    if (c_begin < c_end) {
+        if (is_up(c_begin)) {
+            static_for<NPB_L + T::NAV>([&](auto qc) { stage_up_piece(c_begin, lds, decltype(qc)::value); });
+        } else {
+            const ChunkSrc cs0 = chunk_src(c_begin);
+            static_for<NPB_F + T::NAV>([&](auto qc) { stage_full_piece(c_begin, lds, decltype(qc)::value, cs0); });
+        }
+    }
+    const int co = by * 32 + (lane & 31);
+    const float bias_v = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;   // requested now, used in the epilogue
+
+    // ---- operand addressing -------------------------------------------------------------------------------------
+    const int tslot = min(wn * 32 + (lane & 31), T::NTILES - 1);
+    const int tyy = tslot / TXB, txx = tslot % TXB;
+    const int pbF = tyy * 2 * PWS + txx * 2 + (lane >> 5) * PSF;
+    const int pbL = tyy * PWL + txx + (lane >> 5) * PSL;
+    const int wbase = T::B_FLOATS + ((lane & 31) >> 4) * T::RUN_LDS + (lane & 15) + 16 * (lane >> 5);
+    __syncthreads();
+
+    // Everything from here on is compiled once per half (the set of owned positions is a compile-time property).
+    auto run = [&](auto hf_tag) {
+        constexpr int HF = decltype(hf_tag)::value;
+        f32x16 acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[o][r] = 0.f;
+
+        // One chunk of this wave: KW K-steps x NP owned positions, one MFMA each.  Software pipeline pinned with sched_barrier:
+        // the weight fragment of MFMA s + D, the next K-step's patch (first gap), its transform (third and fourth gap) and the
+        // next chunk's DMA pieces (dealt over the first two thirds) are issued in the shadow of earlier MFMAs -- this wave's
+        // and those of the other wave on the SIMD.
+        //   UP: 0 = full-resolution chunk, 1 = low-resolution chunk of the upsampled operand
+        //   NEXT: 0 = last chunk, 1 = the next chunk is FULL, 2 = the next chunk is UP
+        auto chunk_body = [&](int c, auto up_tag, auto next_tag) {
+            constexpr bool UP = decltype(up_tag)::value;
+            constexpr int NEXT = decltype(next_tag)::value;
+            constexpr int NP = w32_count(HF, UP);
+            constexpr int S = KW * NP, D = 3, RS = D + 1;
+            constexpr int SP = (S * 2) / 3 > 0 ? (S * 2) / 3 : 1;
+            constexpr int NPIECES = NEXT == 0 ? 0 : (NEXT == 2 ? NPB_L : NPB_F) + T::NAV;
+            const int buf = (c - c_begin) & 1;
+            const float* bufp = lds + buf * T::BUF_FLOATS;
+            float* nbufp = lds + (buf ^ 1) * T::BUF_FLOATS;
+            const float* psrc = bufp + (UP ? pbL : pbF);
+            const float* wsrc = bufp + wbase;
+            ChunkSrc csn;
+            if constexpr (NEXT == 1) csn = chunk_src(c + 1);
+            float d[16], tr[16], v[2][16], wf[RS];
+            auto fetch_patch = [&](int kk) {   // elements no owned position depends on are dropped by the compiler
+                if constexpr (UP) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) d[e] = psrc[kk * 2 * PSL + (e / 3) * PWL + (e % 3)];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const f32x2 pr = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + (e >> 1) * PWS + (e & 1) * 2);
+                        d[2 * e] = pr[0];
+                        d[2 * e + 1] = pr[1];
+                    }
+                }
+            };
+            auto transform_rows = [&]() {   // tr = B^T d  (UP: the three non-zero rows from the 3x3 source pixels)
+                if constexpr (UP) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        tr[0 * 4 + j] = d[0 * 3 + j] - d[1 * 3 + j];
+                        tr[1 * 4 + j] = d[1 * 3 + j] + d[1 * 3 + j];
+                        tr[3 * 4 + j] = d[1 * 3 + j] - d[2 * 3 + j];
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        tr[0 * 4 + cc] = d[0 * 4 + cc] - d[2 * 4 + cc];
+                        tr[1 * 4 + cc] = d[1 * 4 + cc] + d[2 * 4 + cc];
+                        tr[2 * 4 + cc] = d[2 * 4 + cc] - d[1 * 4 + cc];
+                        tr[3 * 4 + cc] = d[1 * 4 + cc] - d[3 * 4 + cc];
+                    }
+                }
+            };
+            auto transform_cols = [&](int kk) {   // V = tr B, owned positions only
+                float* vv = v[kk & 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (UP && r == 2) continue;
+                    if constexpr (UP) {   // tr columns 0,1,2 hold source columns 0,1,2 (patch columns 0, 1 = 2, 3)
+                        if (w32_owns(HF, r * 4 + 0)) vv[r * 4 + 0] = tr[r * 4 + 0] - tr[r * 4 + 1];
+                        if (w32_owns(HF, r * 4 + 1)) vv[r * 4 + 1] = tr[r * 4 + 1] + tr[r * 4 + 1];
+                        if (w32_owns(HF, r * 4 + 3)) vv[r * 4 + 3] = tr[r * 4 + 1] - tr[r * 4 + 2];
+                    } else {
+                        if (w32_owns(HF, r * 4 + 0)) vv[r * 4 + 0] = tr[r * 4 + 0] - tr[r * 4 + 2];
+                        if (w32_owns(HF, r * 4 + 1)) vv[r * 4 + 1] = tr[r * 4 + 1] + tr[r * 4 + 2];
+                        if (w32_owns(HF, r * 4 + 2)) vv[r * 4 + 2] = tr[r * 4 + 2] - tr[r * 4 + 1];
+                        if (w32_owns(HF, r * 4 + 3)) vv[r * 4 + 3] = tr[r * 4 + 1] - tr[r * 4 + 3];
+                    }
+                }
+            };
+            auto fetch_u = [&](int s2) {
+                const int kk = s2 / NP, xi = w32_nth(HF, UP, s2 % NP);
+                wf[s2 % RS] = wsrc[((kk >> 1) * 16 + xi) * 64 + (kk & 1) * 32];
+            };
+            // cold start of the chunk: first patch, first fragments, first transform
+            fetch_patch(0);
+#pragma unroll
+            for (int s2 = 0; s2 < D && s2 < S; ++s2) fetch_u(s2);
+            transform_rows();
+            transform_cols(0);
+            static_for<S>([&](auto s2c) {
+                constexpr int s2 = decltype(s2c)::value;
+                constexpr int kk = s2 / NP, p = s2 % NP;
+                constexpr int xi = w32_nth(HF, UP, p);
+                if constexpr (s2 + D < S) fetch_u(s2 + D);
+                if constexpr (kk + 1 < KW) {
+                    if constexpr (p == 0) fetch_patch(kk + 1);
+                    if constexpr (p == 2) transform_rows();
+                    if constexpr (p == 3) transform_cols(kk + 1);
+                }
+                if constexpr (NEXT != 0) {
+                    // pieces q with q * SP / NPIECES == s2, i.e. q in [ceil(s2 * NPIECES / SP), ceil((s2 + 1) * NPIECES / SP))
+                    constexpr int q0 = (s2 * NPIECES + SP - 1) / SP, q1 = ((s2 + 1) * NPIECES + SP - 1) / SP;
+                    constexpr int qb = q0 < NPIECES ? q0 : NPIECES, qe = q1 < NPIECES ? q1 : NPIECES;
+                    static_for<qe - qb>([&](auto qc) {
+                        constexpr int q = qb + decltype(qc)::value;
+                        if constexpr (NEXT == 2) stage_up_piece(c + 1, nbufp, q);
+                        else stage_full_piece(c + 1, nbufp, q, csn);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[w32_slot(HF, xi)] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[kk & 1][xi], wf[s2 % RS], acc[w32_slot(HF, xi)], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();   // next buffer landed (vmcnt(0) precedes the barrier), this one is released
+        };
+        // Two plain loops (upsampled chunks first, then the rest) with peeled last iterations: one body per loop keeps the
+        // accumulators in place across the back edge (a single loop that switches between body variants makes the register
+        // allocator rotate the 128 accumulator registers through copies and spills).
+        const int up_end = min(c_end, max(c_begin, upl ? a.C1 / CK : 0));
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        int c = c_begin;
+        if constexpr (!GENERIC) {
+            for (; c + 1 < up_end; ++c) chunk_body(c, std::true_type{}, I2{});
+            if (c < up_end) {
+                if (up_end < c_end) chunk_body(c, std::true_type{}, I1{});
+                else chunk_body(c, std::true_type{}, I0{});
+                ++c;
+            }
+        }
+        for (; c + 1 < c_end; ++c) chunk_body(c, std::false_type{}, I1{});
+        if (c < c_end) chunk_body(c, std::false_type{}, I0{});
+
+        // ---- epilogue -------------------------------------------------------------------------------------------------
+        // Accumulator register g = 4q + r of lane l belongs to tile slot wn*32 + 8q + 4(l >> 5) + r and out channel l & 31.
+        // Partial outputs of this half: Y[a][b] += A^T[a][r] A^T[b][c] M[r][c] over the owned (r, c).  Half hf keeps output
+        // row a = hf and hands row 1 - hf to the other half: 32 values per lane through LDS (the staging buffers are free).
+        float keep[16][2], give[16][2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float y[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                if (!w32_owns(HF, xi)) continue;
+                const float m = acc[w32_slot(HF, xi)][g];
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int cf = w32_at(aa, xi / 4) * w32_at(bb, xi % 4);
+                        if (cf > 0) y[aa][bb] += m;
+                        if (cf < 0) y[aa][bb] -= m;
+                    }
+            }
+            keep[g][0] = y[HF][0];
+            keep[g][1] = y[HF][1];
+            give[g][0] = y[1 - HF][0];
+            give[g][1] = y[1 - HF][1];
+        }
+        float* xch = lds + (size_t)wn * (2 * 32 * 64) + lane;   // [wn][sender half][value][lane]
+#pragma unroll
+        for (int e = 0; e < 32; ++e) xch[(HF * 32 + e) * 64] = give[e >> 1][e & 1];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 32; ++e) keep[e >> 1][e & 1] += xch[((1 - HF) * 32 + e) * 64];
+
+        const bool final_out = (a.ksplit == 1);
+        float* ybase = a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
+        const bool vec_ok = (W & 3) == 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tfirst = wn * 32 + 8 * q + 4 * (lane >> 5);
+            const int oy = y0 + (tfirst / TXB) * 2 + HF, ox = x0 + (tfirst % TXB) * 2;
+            if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W) continue;
+            float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float yv = keep[4 * q + (e >> 1)][e & 1];
+                o[e] = final_out ? act_apply_fast(yv + bias_v, a.act, a.slope) : yv;
+            }
+            if (MASKED && a.out_mask) {
+                const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W + ox;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ox + e < W && mp[e] == 0) o[e] = 0.f;
+            }
+            if (vec_ok && ox + 7 < W) {
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ox + e < W) dst[e] = o[e];
+            }
+        }
+    };
+    if (hf == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+// ---- launchers (the configuration table lives in wmd_conv_fwd.hip) -----------------------------------------------
+template <int TH, int TW, int WN, int CK>
+void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s) {
+    if (wino32_pure(a, CK)) hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, false>), grid, dim3(WN * 128), 0, s, a);
+    else hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, true>), grid, dim3(WN * 128), 0, s, a);
+}
+
+#define WMD_W32_INST(TH, TW, WN, CK) template void launch_wino32<TH, TW, WN, CK>(const ConvKArgs&, dim3, hipStream_t);
+#include "wmd_conv_wino32_table.inc"
+#undef WMD_W32_INST
+
+}  // namespace wmd

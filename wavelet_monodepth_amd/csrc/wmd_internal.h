@@ -31,11 +31,15 @@ constexpr int kNumCU = 256;  // MI355X
 extern bool g_prof_on;
 int prof_open(const char* name, double flops, double bytes, hipStream_t s);
 void prof_close(int idx, hipStream_t s);
+void prof_set_mfma(int idx, double mfma_flops);   // FLOPs the matrix pipe executes for this launch (default: the algorithmic count)
 struct ProfScope {
     int idx;
     hipStream_t s;
     ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : idx(-1), s(stream) {
         if (g_prof_on) idx = prof_open(name, flops, bytes, stream);
+    }
+    void mfma(double f) {
+        if (idx >= 0) prof_set_mfma(idx, f);
     }
     ~ProfScope() {
         if (idx >= 0) prof_close(idx, s);

@@ -86,7 +86,7 @@ def tune(key, taps, launch):
     """launch(cfg1, ks) -> status int (0 ok). Returns (cfg1, ks) with the smallest GPU time:
     a coarse sweep (min of 2 runs each) followed by a 6-run play-off between the five best."""
     names = config_names()
-    cands = [i + 1 for i, n in enumerate(names) if n.endswith(",%d>" % taps) or (taps == 9 and n.startswith("conv_wino_kernel"))]
+    cands = [i + 1 for i, n in enumerate(names) if n.endswith(",%d>" % taps) or (taps == 9 and n.startswith("conv_wino"))]
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     results = []
