@@ -443,14 +443,35 @@ def test_lazy_ops_dict_resolves_on_first_access_only():
 
     d = LazyOpsDict({("disp", 0): "map"})
     d.set_lazy(["total_ops", ("total_ops", 0)], resolver)
-    assert set(d) == {("disp", 0), "total_ops", ("total_ops", 0)} and len(d) == 3
-    assert d[("disp", 0)] == "map" and ("total_ops" in d) and not calls           # keys / plain reads: no resolution
+    assert len(d) == 3 and d[("disp", 0)] == "map" and ("total_ops" in d) and not calls   # membership / plain reads: no resolution
     assert d["total_ops"] == 42 and d[("total_ops", 0)] == 7 and len(calls) == 1
     assert dict(d.items())["total_ops"] == 42 and d.get("total_ops") == 42 and d.get("nope", 5) == 5 and len(calls) == 1
     e = LazyOpsDict({("disp", 0): "map"})
     e.set_lazy(["total_ops", ("total_ops", 0)], resolver)
     assert e == d and len(calls) == 2                                              # comparison resolves the other side once
     assert sorted(map(str, e.values())) == sorted(map(str, d.values())) and e.copy() == dict(d)
+
+
+def test_lazy_ops_dict_copies_never_expose_the_placeholders():
+    """Round-2 ADVICE: CPython copies a dict subclass through its raw storage unless __iter__ is overridden, so `dict(out)`,
+    `{**out}`, `out | x`, pop / setdefault and pickle used to hand out the None placeholders of the lazy entries."""
+    import copy
+    import pickle
+    from wavelet_monodepth_amd.sparse_ops import LazyOpsDict
+
+    def fresh():
+        d = LazyOpsDict({("disp", 0): "map"})
+        d.set_lazy(["total_ops", ("total_ops", 0)], lambda: {"total_ops": 42, ("total_ops", 0): 7})
+        return d
+    want = {("disp", 0): "map", "total_ops": 42, ("total_ops", 0): 7}
+    assert dict(fresh()) == want and {**fresh()} == want and (fresh() | {}) == want and ({} | fresh()) == want
+    u = {}
+    u.update(fresh())
+    assert u == want
+    assert set(fresh()) == set(want) and list(fresh().keys()) == list(want)
+    assert fresh().pop("total_ops") == 42 and fresh().setdefault(("total_ops", 0), -1) == 7
+    assert pickle.loads(pickle.dumps(fresh())) == want and copy.copy(fresh()) == want and copy.deepcopy(fresh()) == want
+    assert "None" not in repr(fresh())
 
 
 def test_bucket_groups_cover_every_parameter_once_in_backward_order():

@@ -27,6 +27,8 @@ ap.add_argument("--iters", type=int, default=15)
 ap.add_argument("--batch", type=int, default=12)
 ap.add_argument("--size", default="r18")
 ap.add_argument("--ksplits", default="1,2,4")
+ap.add_argument("--cfgs", default="", help="semicolon-separated template argument lists of the wino32 configurations to run (default: all)")
+ap.add_argument("--no-old", action="store_true", help="skip the sweep over the existing configurations")
 args = ap.parse_args()
 LAYERS = R18 if args.size == "r18" else R50
 dev = torch.device("cuda:0")
@@ -89,6 +91,8 @@ for name in args.layers:
     # best existing configuration (everything but the wino32 family), a quick sweep
     best = None
     for i, n in enumerate(names):
+        if args.no_old:
+            break
         if n.startswith("conv_wino32") or not (n.endswith(",9>") or n.startswith("conv_wino_kernel")):
             continue
         for ks in (1, 2, 4, 8):
@@ -98,10 +102,13 @@ for name in args.layers:
             r = timeit(a, 3)
             if r and (best is None or r[0] < best[0]):
                 best = (r[0], n, ks, i + 1)
-    r = timeit(mk(best[3], best[2]), args.iters)
-    print("   old best  %-40s ks%d : min %7.1f med %7.1f us  %6.1f TFLOP/s(alg)" % (best[1], best[2], r[0], r[1], fl / r[1] / 1e6))
+    if best is not None:
+      r = timeit(mk(best[3], best[2]), args.iters)
+      print("   old best  %-40s ks%d : min %7.1f med %7.1f us  %6.1f TFLOP/s(alg)" % (best[1], best[2], r[0], r[1], fl / r[1] / 1e6))
     for i, n in enumerate(names):
         if not n.startswith("conv_wino32"):
+            continue
+        if args.cfgs and n.split("<")[1].rstrip(">") not in args.cfgs.split(";"):
             continue
         for ks in [int(k) for k in args.ksplits.split(",")]:
             y.fill_(float("nan"))

@@ -81,10 +81,11 @@ struct W32Tile {
     static constexpr int KW = CK / 2;          // 2-channel K-steps per chunk
     static constexpr int XCH_FLOATS = WN * 2 * 32 * 64;   // the two halves of a group trade 32 partial outputs per lane
     static constexpr int LDS_FLOATS = 2 * BUF_FLOATS > XCH_FLOATS ? 2 * BUF_FLOATS : XCH_FLOATS;
+    static constexpr int TAB_FLOATS = ((PH + PWS + PHL + PWL + 3) / 4) * 4;   // folded row / column offsets of the patch
     static_assert(TH % 2 == 0 && TW % 8 == 0, "whole 2x2 tiles; a lane's four consecutive tiles stay in one tile row");
     static_assert(WN * 32 >= NTILES, "more tiles than MFMA rows");
     static_assert(CK % 4 == 0, "chunks are whole 4-channel weight fragments");
-    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+    static_assert((LDS_FLOATS + TAB_FLOATS) * 4 <= 160 * 1024, "LDS");
 };
 
 // conv_wino32_kernel's flattened-staging instantiation needs every chunk inside one source tensor, one full-resolution

@@ -812,7 +812,8 @@ static void launch_wino(const ConvKArgs& a, dim3 grid, hipStream_t s) {
 // conv_wino32_kernel (wmd_conv_wino32.hip) entries: TAPS = 17 marks the family (Winograd weight image, 3x3 semantics);
 // MR = 2 (a block's slab = 32 out channels), NR = 1 and WN = waves / WM so that the planner's block-shape arithmetic holds
 #define WMD_W32_INST(TH, TW, WN, CK)                                                                                   \
-    ConvCfg{TH, TW, 2, 1, 1, (WN) * 2, CK, 17, (int)sizeof(float) * W32Tile<TH, TW, WN, CK>::LDS_FLOATS,              \
+    ConvCfg{TH, TW, 2, 1, 1, (WN) * 2, CK, 17,                                                                         \
+            (int)sizeof(float) * (W32Tile<TH, TW, WN, CK>::LDS_FLOATS + W32Tile<TH, TW, WN, CK>::TAB_FLOATS),          \
             &launch_wino32<TH, TW, WN, CK>, "conv_wino32_kernel<" #TH "," #TW "," #WN "," #CK ">"},
 
 static const ConvCfg kCfgs[] = {

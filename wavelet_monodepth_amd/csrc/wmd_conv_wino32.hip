@@ -73,11 +73,16 @@ __host__ __device__ constexpr int w32_slot(int hf, int xi) {   // accumulator in
 // A^T = [[1,1,1,0],[0,1,-1,-1]]
 __host__ __device__ constexpr int w32_at(int a, int r) { return a == 0 ? (r < 3 ? 1 : 0) : (r == 0 ? 0 : (r == 1 ? 1 : -1)); }
 
-__device__ __forceinline__ float elu_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
-__device__ __forceinline__ float act_apply_fast(float v, int act, float slope) {
-    // ELU through v_exp_f32: |error| <= 1.2e-7 absolute (the cancellation in e^v - 1 near 0 costs RELATIVE accuracy of
-    // values that are themselves < 1e-3; the trunk's tolerance is relative to the tensor's scale)
-    return act == WMD_ACT_ELU ? elu_fast(v) : act_apply(v, act, slope);
+// Activation with the kind as a compile-time constant: the epilogue selects ONE instantiation of its store loop per launch (a
+// run-time switch per element put ~100 scalar branches into every wave's epilogue: 12 k -> 5.5 k cycles on L14).  ELU goes
+// through v_exp_f32: |error| <= 1.2e-7 absolute (the cancellation in e^v - 1 near 0 costs RELATIVE accuracy of values that are
+// themselves < 1e-3; the trunk's tolerance is relative to the tensor's scale).
+template <int ACT>
+__device__ __forceinline__ float act_const(float v, float slope) {
+    if constexpr (ACT == WMD_ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
+    else if constexpr (ACT == WMD_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == WMD_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    else return v;
 }
 
 // GENERIC = false: every chunk of CK channels lies inside one source tensor, no masks (every trunk layer of the decoders).
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     constexpr int NT = T::NT, PWS = T::PWS, PSF = T::PSF, PWL = T::PWL, PSL = T::PSL;
     constexpr int KW = T::KW, TXB = T::TXB;
     constexpr bool MASKED = GENERIC;
-    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS + T::TAB_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -133,38 +138,27 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     constexpr unsigned kOOB = 0x80000000u;   // >= any num_records: the descriptor's range check returns 0
     const size_t plane1 = (size_t)a.H1 * a.W1, plane2 = (size_t)H * W;
     const unsigned pb1 = (unsigned)(plane1 * 4), pb2 = (unsigned)(plane2 * 4);
-    // byte offset of full-resolution patch position p inside one channel plane of x2 (o2) / of x1 (o1)
-    auto full_pos = [&](int p, unsigned& o1, unsigned& o2) {
-        const int py = p / PWS, px = p % PWS;
-        int gy = y0 + py - 1, gx = x0 + px - 1;
-        bool ok = p < PSF;
-        ok = pad_coord(gy, H, a.pad_mode) && ok;
-        ok = pad_coord(gx, W, a.pad_mode) && ok;
-        ok = ok && gy < H && gx < W && gy >= 0 && gx >= 0;
-        gy = min(max(gy, 0), H - 1);
-        gx = min(max(gx, 0), W - 1);
-        if (MASKED && a.in_mask) ok = ok && a.in_mask[(size_t)b * H * W + gy * W + gx] != 0;
-        o2 = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
-        int sy = gy - a.shift1, sx = gx - a.shift1;
-        if (a.up1 == 2) {
-            sy = gy >> 1;
-            sx = gx >> 1;
-        }
-        const bool ok1 = ok && sy >= 0 && sx >= 0 && sy < a.H1 && sx < a.W1;
-        o1 = ok1 ? (unsigned)(sy * a.W1 + sx) * 4u : kOOB;
+    // Padded coordinate g in [-1, n] -> source coordinate, branch-free (the pad mode is uniform, everything is a select): every
+    // block of a launch computes its offsets at the same moment, so this prologue is not hidden by anything, and the branchy
+    // form (pad_coord's switch per coordinate, short-circuit tests) cost 16 k cycles per block on L14 (cycle stamps)
+    auto fold = [&](int g, int n, int& ok) {
+        const int refl = g < 0 ? -g : (g >= n ? 2 * n - 2 - g : g);
+        const int clam = min(max(g, 0), n - 1);
+        ok &= (int)(a.pad_mode != WMD_PAD_ZERO) | (int)(g == clam);
+        const int r = a.pad_mode == WMD_PAD_REFLECT ? refl : clam;
+        return min(max(r, 0), n - 1);      // tile overhang beyond the pad ring: any in-range pixel (never stored)
     };
-    // low-resolution halo patch of the upsampled operand: position (py, px) is source pixel (y0/2 - 1 + py, x0/2 - 1 + px).
-    // The full-resolution pad ring (row -1 / row H) maps onto it as: reflect (-1 -> 1, H -> H-2) and replicate both land in the
-    // border source pixel, zero padding stays zero; rows beyond the ring (tile overhang) are never used by a stored output.
-    auto low_pos = [&](int p) {
-        const int py = p / PWL, px = p % PWL;
-        int sy = (y0 >> 1) - 1 + py, sx = (x0 >> 1) - 1 + px;
-        bool ok = p < PSL && sy <= a.H1 && sx <= a.W1;
-        if (sy < 0 || sy >= a.H1) ok = ok && a.pad_mode != WMD_PAD_ZERO;
-        if (sx < 0 || sx >= a.W1) ok = ok && a.pad_mode != WMD_PAD_ZERO;
-        sy = min(max(sy, 0), a.H1 - 1);
-        sx = min(max(sx, 0), a.W1 - 1);
-        return ok ? (unsigned)(sy * a.W1 + sx) * 4u : kOOB;
+    // byte offset of full-resolution patch position p inside one channel plane of x2 (o2) / of x1 (o1): generic layers
+    auto full_pos = [&](int p, unsigned& o1, unsigned& o2) {
+        const int py = p / PWS, px = p - py * PWS;
+        const int gy0 = y0 + py - 1, gx0 = x0 + px - 1;
+        int ok = (int)(p < PSF) & (int)(gy0 <= H) & (int)(gx0 <= W);
+        const int gy = fold(gy0, H, ok), gx = fold(gx0, W, ok);
+        if (MASKED && a.in_mask) ok &= (int)(a.in_mask[(size_t)b * H * W + gy * W + gx] != 0);
+        o2 = ok ? (unsigned)(gy * W + gx) * 4u : kOOB;
+        const int sy = a.up1 == 2 ? gy >> 1 : gy - a.shift1, sx = a.up1 == 2 ? gx >> 1 : gx - a.shift1;
+        const int ok1 = ok & (int)(sy >= 0) & (int)(sx >= 0) & (int)(sy < a.H1) & (int)(sx < a.W1);
+        o1 = ok1 ? (unsigned)(sy * a.W1 + sx) * 4u : kOOB;
     };
     // pure layers: flattened [channel][position] runs of a chunk, element tid + i * NT
     constexpr int NPF = GENERIC ? 1 : (CK * PSF + NT - 1) / NT, NPL = GENERIC ? 1 : (CK * PSL + NT - 1) / NT;
@@ -172,21 +166,51 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     constexpr int NPOSF = GENERIC ? T::NPOSF : 1;
     unsigned obF[NPF], obL[NPL], ob1[NPOSF], ob2[NPOSF];
     if constexpr (!GENERIC) {
-        // the full-resolution chunks of a pure layer all have one geometry: the skip tensor's when x1 is upsampled (x1 then
-        // takes the low-resolution path), else x1's own (a skip tensor beside a non-upsampled x1 has the same H x W)
+        // The full-resolution chunks of a pure layer all have one geometry: the skip tensor's when x1 is upsampled (x1 then
+        // takes the low-resolution path), else x1's own (a skip tensor beside a non-upsampled x1 has the same H x W).  The
+        // pad / bounds logic is separable: PH + PWS (+ PHL + PWL) threads fold one patch row or column each into a byte
+        // offset (or -1: reads zero) in a corner of LDS, and every flattened element is then channel * plane + row + column:
+        // ~20 instructions per element instead of ~80.
+        // Low-resolution halo patch of the upsampled operand: position (py, px) is source pixel (y0/2 - 1 + py, x0/2 - 1 + px).
+        // The full-resolution pad ring (row -1 / row H) maps onto it as: reflect (-1 -> 1, H -> H-2) and replicate both land in
+        // the border source pixel, zero padding stays zero; rows beyond the ring (tile overhang) are never used by a stored output.
+        int* tab = reinterpret_cast<int*>(lds + T::LDS_FLOATS);
+        constexpr int PH = T::PH, PHL = T::PHL;
+        {
+            const bool up = a.up1 == 2;
+            const int Hs = up ? H : a.H1, Ws = up ? W : a.W1, sh = up ? 0 : a.shift1;
+            int t = tid;
+            if (t < PH + PWS) {
+                const bool row = t < PH;
+                const int g0 = row ? y0 + t - 1 : x0 + (t - PH) - 1, n = row ? H : W, ns = row ? Hs : Ws;
+                int ok = (int)(g0 <= n);
+                const int g = fold(g0, n, ok) - sh;
+                ok &= (int)(g >= 0) & (int)(g < ns);
+                tab[t] = ok ? (row ? g * Ws * 4 : g * 4) : -1;
+            } else if (t < PH + PWS + PHL + PWL) {
+                t -= PH + PWS;
+                const bool row = t < PHL;
+                const int s0 = row ? (y0 >> 1) - 1 + t : (x0 >> 1) - 1 + (t - PHL), n = row ? a.H1 : a.W1;
+                const int sc = min(max(s0, 0), n - 1);
+                const int ok = (int)(s0 <= n) & ((int)(a.pad_mode != WMD_PAD_ZERO) | (int)(sc == s0));
+                tab[PH + PWS + t] = ok ? (row ? sc * a.W1 * 4 : sc * 4) : -1;
+            }
+        }
+        __syncthreads();
+        const unsigned pbs = a.up1 == 2 ? pb2 : pb1;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int e = tid + i * NT, ch = e / PSF;
-            unsigned o1, o2;
-            full_pos(e % PSF, o1, o2);
-            const unsigned o = a.up1 == 2 ? o2 : o1, pb = a.up1 == 2 ? pb2 : pb1;
-            obF[i] = (ch < CK && o != kOOB) ? (unsigned)ch * pb + o : kOOB;
+            const unsigned e = tid + i * NT, ch = e / PSF, pos = e - __umul24(ch, PSF);
+            const unsigned py = pos / PWS, px = pos - __umul24(py, PWS);
+            const int r = tab[py], c = tab[PH + px];
+            obF[i] = (ch < CK && (r | c) >= 0) ? ch * pbs + (unsigned)(r + c) : kOOB;
         }
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
-            const int e = tid + i * NT, ch = e / PSL;
-            const unsigned o = low_pos(e % PSL);
-            obL[i] = (ch < CK && o != kOOB) ? (unsigned)ch * pb1 + o : kOOB;
+            const unsigned e = tid + i * NT, ch = e / PSL, pos = e - __umul24(ch, PSL);
+            const unsigned py = pos / PWL, px = pos - __umul24(py, PWL);
+            const int r = tab[PH + PWS + py], c = tab[PH + PWS + PHL + px];
+            obL[i] = (ch < CK && (r | c) >= 0) ? ch * pb1 + (unsigned)(r + c) : kOOB;
         }
     } else {
 #pragma unroll
@@ -452,33 +476,41 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         const bool final_out = (a.ksplit == 1);
         float* ybase = a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
         const bool vec_ok = (W & 3) == 0;
+        auto store_rows = [&](auto act_tag) {   // ACT < 0: split-K partial sums (no bias, no activation)
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int tfirst = wn * 32 + 8 * q + 4 * (lane >> 5);
-            const int oy = y0 + (tfirst / TXB) * 2 + HF, ox = x0 + (tfirst % TXB) * 2;
-            if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W) continue;
-            float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
-            float o[8];
+            for (int q = 0; q < 4; ++q) {
+                const int tfirst = wn * 32 + 8 * q + 4 * (lane >> 5);
+                const int oy = y0 + (tfirst / TXB) * 2 + HF, ox = x0 + (tfirst % TXB) * 2;
+                if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W) continue;
+                float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
+                float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float yv = keep[4 * q + (e >> 1)][e & 1];
-                o[e] = final_out ? act_apply_fast(yv + bias_v, a.act, a.slope) : yv;
+                for (int e = 0; e < 8; ++e) {
+                    const float yv = keep[4 * q + (e >> 1)][e & 1];
+                    o[e] = ACT < 0 ? yv : act_const<(ACT < 0 ? 0 : ACT)>(yv + bias_v, a.slope);
+                }
+                if (MASKED && a.out_mask) {
+                    const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W + ox;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (ox + e < W && mp[e] == 0) o[e] = 0.f;
+                }
+                if (vec_ok && ox + 7 < W) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (ox + e < W) dst[e] = o[e];
+                }
             }
-            if (MASKED && a.out_mask) {
-                const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W + ox;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (ox + e < W && mp[e] == 0) o[e] = 0.f;
-            }
-            if (vec_ok && ox + 7 < W) {
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (ox + e < W) dst[e] = o[e];
-            }
-        }
+        };
+        if (!final_out) store_rows(std::integral_constant<int, -1>{});
+        else if (a.act == WMD_ACT_ELU) store_rows(std::integral_constant<int, WMD_ACT_ELU>{});
+        else if (a.act == WMD_ACT_LEAKY) store_rows(std::integral_constant<int, WMD_ACT_LEAKY>{});
+        else if (a.act == WMD_ACT_SIGMOID) store_rows(std::integral_constant<int, WMD_ACT_SIGMOID>{});
+        else store_rows(std::integral_constant<int, WMD_ACT_NONE>{});
     };
     if (hf == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});

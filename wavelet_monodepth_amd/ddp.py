@@ -132,10 +132,17 @@ class GradientExchange:
     (decoder first; `bucket_groups` builds it).  Call `finish()` between `loss.backward()` and `optimizer.step()`.
 
     modules: the nn.Modules whose parameters AND buffers rank 0 broadcasts at construction (default: only the
-    parameters of `groups` are broadcast)."""
+    parameters of `groups` are broadcast).
+
+    static_graph (default True, torch DDP's `static_graph` made explicit): every step reaches the same parameters on every
+    rank.  A bucket that holds parameters the loss never reaches (resnet.fc, densenet.norm5 / classifier) then learns on the
+    first step not to wait for them and leaves as soon as its used parameters are in -- AFTER the ranks have agreed on the
+    per-bucket arrival counts (one tiny all-reduce on that step; a mismatch raises on every rank instead of letting the
+    ranks issue their collectives in different orders).  static_graph=False never learns: incomplete buckets always leave
+    in finish(), in bucket order, on every rank."""
 
     def __init__(self, groups, world=None, rank=None, backend="torch", store=None, process_group=None, modules=(),
-                 broadcast_from_rank0=True):
+                 broadcast_from_rank0=True, static_graph=True):
         self.world = dist.get_world_size() if world is None else world
         self.rank = dist.get_rank() if rank is None else rank
         self.buckets = []
@@ -163,6 +170,8 @@ class GradientExchange:
             self.backend = _NullBackend()
         else:
             self.backend = _TorchBackend(process_group)
+        self.static_graph = bool(static_graph)
+        self._arms_agreed = False
         self.enabled = True        # False: the all-reduces are skipped (local gradients; used to time the exposed cost)
         self._accumulating = False
         self._modules = list(modules)
@@ -247,13 +256,35 @@ class GradientExchange:
                     raise RuntimeError("parameter gradient of bucket %s was re-allocated; use GradientExchange.zero_grad() "
                                        "or optimizer.zero_grad(set_to_none=False)" % b["name"])
 
+    def _agree_on_arms(self):
+        """First step of a static graph: every rank must have seen the same number of gradient arrivals per bucket before
+        any bucket's arm is lowered (ranks with different arms would launch their all-reduces in different orders: a hang,
+        or sums over mismatched buffers).  Sum and sum of squares of the counts over the ranks: equal counts <=> W * sum(c^2)
+        == (sum c)^2 per bucket (small integers, exact in fp32)."""
+        counts = [float(b["count"]) for b in self.buckets]
+        dev = self.buckets[0]["flat"].device
+        v = torch.tensor(counts + [c * c for c in counts], device=dev, dtype=torch.float32)
+        self.backend.allreduce(v, 1.0)
+        self.backend.wait()
+        tot = v.tolist()
+        n = len(counts)
+        bad = [self.buckets[i]["name"] for i in range(n) if abs(self.world * tot[n + i] - tot[i] * tot[i]) > 0.5]
+        if bad:
+            raise RuntimeError("GradientExchange(static_graph=True): the ranks reached different parameter sets in buckets %s "
+                               "(rank %d saw %s arrivals); use static_graph=False for data-dependent graphs"
+                               % (bad, self.rank, [int(c) for c in counts]))
+        self._arms_agreed = True
+
     def finish(self):
+        if self.static_graph and not self._arms_agreed and self.enabled and self.world > 1 and self.buckets \
+                and not self._accumulating:
+            self._agree_on_arms()
         for b in self.buckets:
             if not b["sent"]:
-                # some parameters of this bucket received no gradient (their slice stays zero): send it now, and from the
-                # next step on do not wait for them -- the bucket then leaves as soon as its used parameters are in
-                # (the static-graph assumption of torch DDP; a parameter that turns up later raises in the hook)
-                if 0 < b["count"] < b["arm"]:
+                # some parameters of this bucket received no gradient (their slice stays zero): send it now, and -- static
+                # graphs only, after the ranks agreed on the counts -- from the next step on do not wait for them: the
+                # bucket then leaves as soon as its used parameters are in (a parameter that turns up later raises in the hook)
+                if self.static_graph and (self._arms_agreed or self.world == 1) and 0 < b["count"] < b["arm"]:
                     b["arm"] = b["count"]
                 self._send(b)
         self.backend.wait()

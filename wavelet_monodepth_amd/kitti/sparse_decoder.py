@@ -149,8 +149,9 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             out, counters, static_ops = dict(res[0]), res[1], res[2]
         else:
             out, counters, static_ops = self._device_chain(input_features, thresh_ratio, sparse_scales, _force_masks)
-        self.outputs = out
-        return self._host_op_model(out, counters, static_ops)
+        res = self._host_op_model(out, counters, static_ops)
+        self.outputs = res      # depth_decoder.py:293,379,423,427: the op counts live in self.outputs too
+        return res
 
     def _device_chain(self, input_features, thresh_ratio, sparse_scales, _force_masks):
         out = {}

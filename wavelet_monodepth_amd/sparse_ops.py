@@ -147,6 +147,30 @@ class LazyOpsDict(dict):
     def copy(self):
         return dict(self.resolve())
 
+    # CPython copies a dict subclass through the raw hash table -- `dict(out)`, `{**out}`, `out | x`, dict.update(x, out) --
+    # unless the subclass overrides __iter__: then it goes through keys() + __getitem__, i.e. through the resolver.  The
+    # remaining readers of the raw storage resolve first.
+    def __iter__(self):
+        return dict.__iter__(self.resolve())
+
+    def keys(self):
+        return dict.keys(self.resolve())
+
+    def pop(self, *a):
+        return dict.pop(self.resolve(), *a)
+
+    def popitem(self):
+        return dict.popitem(self.resolve())
+
+    def setdefault(self, key, default=None):
+        return dict.setdefault(self.resolve(), key, default)
+
+    def __repr__(self):
+        return dict.__repr__(self.resolve())
+
+    def __reduce__(self):      # pickle / copy.copy / copy.deepcopy: a plain dict with the integers filled in
+        return (dict, (dict(self.resolve()),))
+
     def __eq__(self, other):
         return dict.__eq__(self.resolve(), other.resolve() if isinstance(other, LazyOpsDict) else other)
 
