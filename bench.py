@@ -31,7 +31,7 @@ R18 = [64, 64, 128, 256, 512]
 HEIGHT, WIDTH, BATCH = 192, 640, 12
 FLOP_PER_FRAME = 6.947e9     # conv MACs x2, SURVEY.md §8(d) / BASELINE.md §2
 PEAK_F32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
-TUNE_CACHE = "r02_tune_cache.json"   # committed tile / split-K choices (profiles/)
+TUNE_CACHE = "r03_tune_cache.json"   # committed tile / split-K choices (profiles/)
 
 
 def build_model(dev):

@@ -84,17 +84,21 @@ def test_nyu_sparse_op_model_full_size_known_answer():
 
 # ---- autotuner (host logic; the configuration table comes from the library, no GPU needed) ---------------------------------
 def test_committed_tune_cache_names_exist_in_the_library_table():
-    """bench.py preloads profiles/r01_tune_cache_config2.json; an entry whose kernel name left the table would be
-    ignored silently (and the shape re-tuned inside the warm-up)."""
-    import json, os
+    """bench.py preloads profiles/<bench.TUNE_CACHE>; an entry whose kernel name left the table would be ignored silently
+    (and the shape re-tuned inside the warm-up).  The forward / data-gradient entries name convolution configurations."""
+    import importlib.util, json, os
     from wavelet_monodepth_amd import tuner
+    root = os.path.dirname(os.path.dirname(__file__))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
     names = tuner.config_names()
     assert len(names) >= 10 and len(set(names)) == len(names)
-    path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "r01_tune_cache_config2.json")
-    with open(path) as f:
+    with open(os.path.join(root, "profiles", bench.TUNE_CACHE)) as f:
         cache = json.load(f)
-    assert len(cache) >= 8
-    for key, (name, ks) in cache.items():
+    conv = {k: v for k, v in cache.items() if k.startswith("conv|") or k.startswith("dgrad|")}
+    assert len(conv) >= 8 and any("|12|96|320|32|2|64|32|3" in k for k in conv)      # the headline workload's dominant layer
+    for key, (name, ks) in conv.items():
         assert name in names, "%s -> %s is not a kernel configuration of this build" % (key, name)
         assert ks in tuner.KSPLITS
 

@@ -1244,6 +1244,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     const bool wino = c.TAPS >= 16;           // Winograd configuration (16: 16x16x4 kernels, 17: 32x32x2 kernels): transformed weight image, 3x3 semantics
     const int taps = wino ? 9 : c.TAPS;
     ConvKArgs a;
+    memset(&a, 0, sizeof(a));
     a.x1 = g->x1;
     a.x2 = g->C2 > 0 ? g->x2 : nullptr;
     a.wp = wino ? g->wp_wino : g->wp;
