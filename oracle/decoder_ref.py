@@ -166,16 +166,21 @@ def kitti_wave_coefficients(x, sd, keys, i, with_ll, branch=None, trace=None):
     return yl, yh
 
 
-def kitti_wave_decoder(feats, sd, branch=None, trace=None):
-    """DepthWaveProgressiveDecoder.forward (depth_decoder.py:138-168).  branch / trace: see `leaky` (keys ("waveconv", i, j))."""
+def kitti_wave_decoder(feats, sd, branch=None, trace=None, activations=None):
+    """DepthWaveProgressiveDecoder.forward (depth_decoder.py:138-168).  branch / trace: see `leaky` (keys ("waveconv", i, j)).
+    activations: optional dict that receives the trunk ConvBlock outputs under their `convs` keys ("upconv", i, 0 | 1)."""
     keys = kitti_wave_keys()
     out = {}
     x = feats[-1]
     yl = None
     for i in range(4, 0, -1):
         x = conv_block(x, sd, "decoder.%d" % keys[("upconv", i, 0)], "reflect")
+        if activations is not None:
+            activations[("upconv", i, 0)] = x
         x = torch.cat([up2(x), feats[i - 1]], 1)
         x = conv_block(x, sd, "decoder.%d" % keys[("upconv", i, 1)], "reflect")
+        if activations is not None:
+            activations[("upconv", i, 1)] = x
         ll_new, yh = kitti_wave_coefficients(x, sd, keys, i, with_ll=(i == 4), branch=branch, trace=trace)
         if i == 4:
             yl = ll_new

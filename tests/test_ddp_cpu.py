@@ -96,6 +96,48 @@ def test_bucketed_allreduce_equals_full_batch_gradient(tmp_path):
         assert torch.allclose(g0[n], p.grad, atol=1e-6, rtol=1e-5), n
 
 
+def _mismatch_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wavelet_monodepth_amd.ddp import GradientExchange, bucket_groups
+    net = TinyNet()
+    x = torch.randn(2, 3, 8, 8)
+
+    def loss_of(net, use_fc):       # rank 1 reaches `encoder.fc`, rank 0 does not: a data-dependent graph
+        y = net(x).pow(2).mean()
+        return y + net.encoder.fc(torch.ones(1, 8)).sum() if use_fc else y
+    res = []
+    for static in (True, False):
+        gx = GradientExchange(bucket_groups(net.encoder, net.decoder, bucket_bytes=1200), backend="torch", modules=[net],
+                              static_graph=static)
+        gx.zero_grad()
+        loss_of(net, rank == 1).backward()
+        try:
+            gx.finish()
+            res.append("ok")
+        except RuntimeError as e:
+            res.append("raised" if "different parameter sets" in str(e) else "other: %s" % e)
+        arms = [b["arm"] for b in gx.buckets]
+        full = [len(b["params"]) for b in gx.buckets]
+        res.append(arms == full)
+        gx.close()
+        for p in net.parameters():
+            p.grad = None
+    torch.save(res, os.path.join(out_dir, "m%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_ranks_that_reach_different_parameters_are_caught_before_any_arm_is_lowered(tmp_path):
+    """Round-2 ADVICE: a bucket's arm used to be learned from the LOCAL arrival count; ranks with different used-parameter
+    sets then issued their all-reduces in different orders.  static_graph=True: the first finish() compares the counts over
+    the ranks and raises on every rank, arms untouched; static_graph=False: no arm is ever lowered and the step completes."""
+    world, port = 2, _free_port()
+    mp.spawn(_mismatch_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, "m%d.pt" % r))
+        assert got == ["raised", True, "ok", True], (r, got)
+
+
 def test_message_sizes_match_survey():
     """R18 encoder + wavelet decoder: 11.2 M + 3.36 M parameters -> ~58 MB of gradients."""
     import numpy as np

@@ -388,6 +388,33 @@ def test_kitti_decoder_per_head_training_path_still_matches_reference_gradients(
         assert_close(sample(p.grad.cpu().numpy()), g["d|" + name], 1e-4, name)
 
 
+def test_a_hook_that_consumes_a_trunk_activation_gets_ungated_gradients(dev):
+    """Round-2 ADVICE: the decoders gate every trunk activation's derivative in its consumers and hand the producer dz.  A
+    forward hook that uses such an activation in its own loss term is a consumer that does not gate: with a hook registered
+    the hints are dropped (layers.gated_backward_allowed), and the gradients equal autograd through the oracle."""
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    from wavelet_monodepth_amd.layers import gated_backward_allowed
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=1).to(dev)
+    assert gated_backward_allowed(dec)
+    taken = {}
+    h = dec.convs[("upconv", 2, 1)].register_forward_hook(lambda m, i, o: taken.__setitem__("x", o))
+    assert not gated_backward_allowed(dec)
+    feats = kitti_feats(2, 64, 64)
+    gf = [f.to(dev).requires_grad_(True) for f in feats]
+    out = dec(gf)
+    (sum(out[("disp", s)].mean() for s in range(4)) + 0.01 * (taken["x"] ** 2).mean()).backward()
+    h.remove()
+    assert gated_backward_allowed(dec)
+    # oracle: the same loss through torch.autograd on the CPU restatement
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    cf = [f.clone().requires_grad_(True) for f in feats]
+    acts = {}
+    ref = R.kitti_wave_decoder(cf, sd, activations=acts)
+    (sum(ref[("disp", s)].mean() for s in range(4)) + 0.01 * (acts[("upconv", 2, 1)] ** 2).mean()).backward()
+    for k in range(5):
+        assert_close(gf[k].grad, cf[k].grad, 1e-4, "dfeat%d with a hooked activation" % k)
+
+
 @pytest.mark.parametrize("shapes", [
     [(32, 48, 3), (16, 16, 1), (7, 5, 3), (40, 21, 1), (3, 64, 3)],
     [(64, 96, 3)] * 3 + [(17, 33, 3), (33, 17, 1)] + [(16, 32, 1)] * 45,      # more filters than one launch holds

@@ -554,3 +554,25 @@ def test_train_step_graph_refuses_an_optimizer_that_cannot_be_captured():
     p = torch.nn.Parameter(torch.zeros(3))
     with pytest.raises(ValueError, match="capturable=True"):
         TrainStepGraph(lambda: p.sum(), torch.optim.Adam([p], lr=1e-3))
+
+
+def test_mobilenetv2_encoder_starts_from_the_reference_initialisation_and_honours_custom_relu6():
+    """Round-2 ADVICE: weights_init='scratch' must start where the reference does (mobilenetv2_encoder.py:136,160-173: conv
+    weights ~ N(0, sqrt(2 / (k k Cout))), BatchNorm 1 / 0), and `use_custom_relu6` (the composed ReLU6, :18-30) is honoured."""
+    import torch
+    from wavelet_monodepth_amd.encoders import MobileNetV2Encoder
+    torch.manual_seed(0)
+    enc = MobileNetV2Encoder()
+    conv = enc.features[-1][0]                     # 1x1 -> 1280: many weights, a tight estimate of the spread
+    want = (2.0 / (1 * 1 * conv.out_channels)) ** 0.5
+    assert abs(float(conv.weight.std()) / want - 1) < 0.02 and abs(float(conv.weight.mean())) < 0.01 * want
+    bn = enc.features[-1][1]
+    assert bool((bn.weight == 1).all()) and bool((bn.bias == 0).all())
+    custom = MobileNetV2Encoder(use_custom_relu6=True)
+    assert list(custom.state_dict()) == list(enc.state_dict())
+    custom.load_state_dict(enc.state_dict())
+    enc.eval(), custom.eval()
+    x = torch.randn(1, 3, 64, 96)
+    with torch.no_grad():
+        for a, b in zip(enc(x), custom(x)):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))

@@ -10,7 +10,8 @@ ranks, and ONE exchange step per iteration sums the gradients:
     (no gather copy);
   * a post-accumulate hook counts a bucket down; when it is full the bucket is all-reduced (sum, then 1/world)
     on a SIDE stream after an event recorded on the compute stream — the collective overlaps the rest of the
-    backward pass (xGMI rings are per-link bound: a handful of 25 MB messages keeps every link busy without
+    backward pass (from the second step on: the first step sends everything in `finish()`, after the ranks have
+    agreed that they saw the same gradient arrivals per bucket — see `static_graph`) (xGMI rings are per-link bound: a handful of 25 MB messages keeps every link busy without
     paying the per-collective latency 160 times);
   * `finish()` launches whatever is left (buckets holding unused parameters such as `encoder.fc`, whose
     gradient stays zero), makes the compute stream wait for the side stream before `optimizer.step()`, and re-arms
@@ -227,7 +228,10 @@ class GradientExchange:
                 raise RuntimeError("gradient bucket %s received a gradient after it was all-reduced: call finish() once per "
                                    "backward pass, or wrap extra backward passes in no_sync()" % bucket["name"])
             bucket["count"] += 1
-            if bucket["count"] == bucket["arm"]:
+            # a full bucket leaves at once (overlapping the rest of the backward pass) only once the ranks are known to see
+            # the same arrivals: from the second step of a static graph on.  On the first step, and always with
+            # static_graph=False, every bucket leaves in finish(), in bucket order, on every rank.
+            if bucket["count"] == bucket["arm"] and self.static_graph and (self._arms_agreed or self.world == 1):
                 self._send(bucket)
         return hook
 

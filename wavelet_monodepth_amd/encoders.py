@@ -210,18 +210,26 @@ class DenseEncoder(nn.Module):
         return f0, f1, f2, f3, f4
 
 
-def _cbr6(cin, cout, k=3, stride=1, groups=1):
+class _ComposedReLU6(nn.Module):
+    """`use_custom_relu6` of the reference (mobilenetv2_encoder.py:18-30, its ONNX-export form): min(relu(x), 6) written as
+    6 - relu(6 - relu(x)); no parameters, no buffers (the state_dict is the same either way)."""
+
+    def forward(self, x):
+        return 6.0 - torch.relu(6.0 - torch.relu(x))
+
+
+def _cbr6(cin, cout, k=3, stride=1, groups=1, custom=False):
     return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout),
-                         nn.ReLU6(inplace=True))
+                         _ComposedReLU6() if custom else nn.ReLU6(inplace=True))
 
 
 class _InvertedResidual(nn.Module):
-    def __init__(self, cin, cout, stride, expand):
+    def __init__(self, cin, cout, stride, expand, custom=False):
         super().__init__()
         hid = int(round(cin * expand))
         self.skip = stride == 1 and cin == cout
-        seq = [] if expand == 1 else [_cbr6(cin, hid, 1)]
-        seq += [_cbr6(hid, hid, 3, stride, groups=hid), nn.Conv2d(hid, cout, 1, bias=False), nn.BatchNorm2d(cout)]
+        seq = [] if expand == 1 else [_cbr6(cin, hid, 1, custom=custom)]
+        seq += [_cbr6(hid, hid, 3, stride, groups=hid, custom=custom), nn.Conv2d(hid, cout, 1, bias=False), nn.BatchNorm2d(cout)]
         self.conv = nn.Sequential(*seq)
 
     def forward(self, x):
@@ -244,21 +252,35 @@ class MobileNetV2Encoder(nn.Module):
         self.normalize_input = normalize_input   # the reference's normalisation loop has no effect (result discarded)
         c = int(32 * width_mult)
         chans, taps = [c], []
-        feats = [_cbr6(3, c, 3, 2)]
+        feats = [_cbr6(3, c, 3, 2, custom=use_custom_relu6)]
         for t_, co, n, s in self._STAGES:
             co = int(co * width_mult)
             for r in range(n):
-                feats.append(_InvertedResidual(c, co, s if r == 0 else 1, t_))
+                feats.append(_InvertedResidual(c, co, s if r == 0 else 1, t_, custom=use_custom_relu6))
                 c = co
                 if s == 2 and r == 0:
                     chans.append(co)
                     taps.append(len(feats) - 1)
         if use_last_layer:
-            feats.append(_cbr6(c, 1280, 1))
+            feats.append(_cbr6(c, 1280, 1, custom=use_custom_relu6))
             chans[-1] = 1280
         self.features = nn.ModuleList(feats)
         self._taps = set(taps)
         self.num_ch_enc = np.asarray(chans)
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        """The reference's starting point for training from scratch (mobilenetv2_encoder.py:136,160-173): convolution weights
+        ~ N(0, sqrt(2 / (k * k * Cout))), BatchNorm weight 1 / bias 0 (torch's own Conv2d default is Kaiming-uniform)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                nn.init.normal_(m.weight, 0.0, (2.0 / n) ** 0.5)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
 
     def forward(self, input_image):
         x = self.features[0](input_image)

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..layers import Conv1x1, Conv3x3, ConvBlock
+from ..layers import Conv1x1, Conv3x3, ConvBlock, gated_backward_allowed
 from ..wavelets import IDWT
 from ..graphs import GraphCache
 
@@ -69,11 +69,12 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self._segments = {}
 
     # -- pieces ------------------------------------------------------------------------------
-    def _head_mid(self, x, key, x_gate=None):
+    def _head_mid(self, x, key, x_gate=None, gated=True):
         # the 1x1's LeakyReLU output `mid` is consumed by the head's 3x3 only, whose backward returns d mid * leaky'(mid)
-        # (x_gate on that side): the 1x1's backward takes its incoming gradient as dz
+        # (x_gate on that side): the 1x1's backward takes its incoming gradient as dz -- unless a hook could hand `mid` to
+        # somebody else (gated_backward_allowed)
         head = self.convs[key]
-        return head[0](x, act="leaky", slope=0.1, x1_gate=x_gate, grad_is_dz=True)
+        return head[0](x, act="leaky", slope=0.1, x1_gate=x_gate, grad_is_dz=gated)
 
     def get_coefficients(self, input_features, scale=1, return_ll=False, _x_gate=None):
         """(LL, [LH, HL, HH]) from the features of level `scale` (reference :126-136).
@@ -93,13 +94,14 @@ class DepthWaveProgressiveDecoder(nn.Module):
                     o += c
             return yl, yh.unsqueeze(1)
         yl = None
-        leaky = ("leaky", 0.1)
+        gated = gated_backward_allowed(self)
+        leaky = ("leaky", 0.1) if gated else None
         if return_ll:
-            mid = self._head_mid(input_features, ("waveconv", scale, 0), _x_gate)
+            mid = self._head_mid(input_features, ("waveconv", scale, 0), _x_gate, gated)
             c3 = self.convs[("waveconv", scale, 0)][2].conv
             yl = ops.head3x3(mid, c3.weight, c3.bias, pad="reflect", mode=1, scale=2.0 ** scale, x_gate=leaky)
-        mp = self._head_mid(input_features, ("waveconv", scale, 1), _x_gate)
-        mn = self._head_mid(input_features, ("waveconv", scale, -1), _x_gate)
+        mp = self._head_mid(input_features, ("waveconv", scale, 1), _x_gate, gated)
+        mn = self._head_mid(input_features, ("waveconv", scale, -1), _x_gate, gated)
         cp = self.convs[("waveconv", scale, 1)][2].conv
         cn = self.convs[("waveconv", scale, -1)][2].conv
         yh = ops.head3x3(mp, cp.weight, cp.bias, mn, cn.weight, cn.bias, pad="reflect", mode=2,
@@ -223,7 +225,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
         # training: every consumer of a trunk activation (the next trunk convolution, the heads' 1x1 convolutions) returns its
         # data gradient already multiplied by ELU'(activation), so no trunk convolution runs a separate activation-backward
         # pass (ops.conv2d_fused: x1_gate / grad_is_dz)
-        elu = ("elu", 0.0) if torch.is_grad_enabled() else None
+        elu = ("elu", 0.0) if (torch.is_grad_enabled() and gated_backward_allowed(self)) else None
+        self._gated = elu is not None
         for i in range(4, 0, -1):
             x = self.convs[("upconv", i, 0)](x, x1_gate=elu if i < 4 else None, grad_is_dz=elu is not None)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
@@ -261,7 +264,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
                 yl_in = res[3]
             self.outputs[("wavelets", i - 1, "LL")] = yl_in
         else:
-            gate = ("elu", 0.0) if torch.is_grad_enabled() else None   # x is this decoder's own ELU output (see _forward_impl)
+            gate = ("elu", 0.0) if (torch.is_grad_enabled() and getattr(self, "_gated", False)) else None   # x is this decoder's own ELU output, its producer expects dz (see _forward_impl)
             if i == 4:
                 yl, yh = self.get_coefficients(x, scale=i, return_ll=True, _x_gate=gate)
             else:

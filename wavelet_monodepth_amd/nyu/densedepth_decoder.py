@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops, sparse_ops as S
-from ..layers import NyuConv3x3, UpSampleBlock
+from ..layers import NyuConv3x3, UpSampleBlock, gated_backward_allowed
 from ..wavelets import IDWT
 from ..graphs import GraphCache
 
@@ -31,20 +31,31 @@ class _OutConv3x3(nn.Conv2d):
         return ops.head3x3(x, self.weight, self.bias, pad="zero", mode=0, scale=1.0)
 
 
+def _add_levels(dec, features, enc_features, n_up, padding, dw_up=False, wave_pad=None, dw_wave=False):
+    """Registers up1..up<n_up> (densedepth_decoder.py:23-31,103-114,166-182: level k joins the decoder width halved k - 1
+    times with the encoder block k + 1 from the end and halves the width again) and, for the wavelet decoders, wave1_ll
+    after up1 and wave<k> after up<k> -- in the reference's registration order, so `state_dict()` lists the same keys."""
+    for k in range(1, n_up + 1):
+        setattr(dec, "up%d" % k, UpSampleBlock(skip_input=features // 2 ** (k - 1) + enc_features[-1 - k],
+                                               output_features=features // 2 ** k, padding=padding, is_depthwise=dw_up))
+        if wave_pad is not None:
+            if k == 1:
+                dec.wave1_ll = NyuConv3x3(features // 2, 1, padding="replicate")
+            setattr(dec, "wave%d" % k, NyuConv3x3(features // 2 ** k, 3, padding=wave_pad, is_depthwise=dw_wave))
+
+
+def _log_highs(outputs, scale, h):
+    for j, band in enumerate(("LH", "HL", "HH")):
+        outputs[("wavelets", scale, band)] = h[:, :, j]
+
+
 class Decoder(nn.Module):
     def __init__(self, enc_features=[96, 96, 192, 384, 2208], decoder_width=0.5, is_depthwise=False):
         super().__init__()
         features = int(enc_features[-1] * decoder_width)
         padding = "zero"
         self.conv2 = NyuConv3x3(enc_features[-1], features, padding="zero")
-        self.up1 = UpSampleBlock(skip_input=features // 1 + enc_features[-2], output_features=features // 2, padding=padding,
-                                 is_depthwise=is_depthwise)
-        self.up2 = UpSampleBlock(skip_input=features // 2 + enc_features[-3], output_features=features // 4, padding=padding,
-                                 is_depthwise=is_depthwise)
-        self.up3 = UpSampleBlock(skip_input=features // 4 + enc_features[-4], output_features=features // 8, padding=padding,
-                                 is_depthwise=is_depthwise)
-        self.up4 = UpSampleBlock(skip_input=features // 8 + enc_features[-5], output_features=features // 16, padding=padding,
-                                 is_depthwise=is_depthwise)
+        _add_levels(self, features, enc_features, 4, padding, dw_up=is_depthwise)
         # (:32-35) a bare nn.Conv2d unless the depthwise option is on
         self.conv3 = NyuConv3x3(features // 16, 1, is_depthwise=True) if is_depthwise else _OutConv3x3(features // 16, 1)
 
@@ -84,16 +95,7 @@ class DecoderWave(nn.Module):
         self.iwt = IDWT(wave="haar", mode=wave_pad)
         self.iwt_LL = IDWT(wave="haar", mode="zero")
         self.conv2 = NyuConv3x3(enc_features[-1], features, padding="replicate")
-        self.up1 = UpSampleBlock(skip_input=features // 1 + enc_features[-2], output_features=features // 2,
-                                 padding=padding, is_depthwise=dw_upconv)
-        self.wave1_ll = NyuConv3x3(features // 2, 1, padding="replicate")
-        self.wave1 = NyuConv3x3(features // 2, 3, padding=wave_pad, is_depthwise=dw_waveconv)
-        self.up2 = UpSampleBlock(skip_input=features // 2 + enc_features[-3], output_features=features // 4,
-                                 padding=padding, is_depthwise=dw_upconv)
-        self.wave2 = NyuConv3x3(features // 4, 3, padding=wave_pad, is_depthwise=dw_waveconv)
-        self.up3 = UpSampleBlock(skip_input=features // 4 + enc_features[-4], output_features=features // 8,
-                                 padding=padding, is_depthwise=dw_upconv)
-        self.wave3 = NyuConv3x3(features // 8, 3, padding=wave_pad, is_depthwise=dw_waveconv)
+        _add_levels(self, features, enc_features, 3, padding, dw_up=dw_upconv, wave_pad=wave_pad, dw_wave=dw_waveconv)
         self._graph_mode = False
         self._graphs = GraphCache()
 
@@ -119,35 +121,24 @@ class DecoderWave(nn.Module):
         # returns its data gradient multiplied by LeakyReLU(0.2)'(output), so no block runs a separate activation-backward
         # pass (ops.conv2d_fused: x1_gate / grad_is_dz)
         plain = not (self.up1.convA.is_depthwise or self.wave1.is_depthwise)
-        g = ("leaky", 0.2) if (torch.is_grad_enabled() and plain) else None
+        g = ("leaky", 0.2) if (torch.is_grad_enabled() and plain and gated_backward_allowed(self)) else None
         dz = g is not None
-        x_d0 = self.conv2(x_blocks[-1])
-        x_d1 = self.up1(x_d0, x_blocks[-2], grad_is_dz=dz)
-        ll = self.wave1_ll.head(x_d1, 2.0 ** 3, x_gate=g)
+        x = self.up1(self.conv2(x_blocks[-1]), x_blocks[-2], grad_is_dz=dz)
+        ll = self.wave1_ll.head(x, 2.0 ** 3, x_gate=g)
         outputs[("disp", 3)] = ll / (2 ** 3)
-        h = self.wave1.head(x_d1, 2.0 ** 2, x_gate=g).unsqueeze(1)
-        outputs[("wavelets", 2, "LL")] = ll
-        outputs[("wavelets", 2, "LH")] = h[:, :, 0]
-        outputs[("wavelets", 2, "HL")] = h[:, :, 1]
-        outputs[("wavelets", 2, "HH")] = h[:, :, 2]
-        ll, disp = ops.idwt_haar(ll, h, disp_scale=1.0 / 2 ** 2, clamp01=False)
-        outputs[("disp", 2)] = disp
-
-        x_d2 = self.up2(x_d1, x_blocks[-3], x1_gate=g, grad_is_dz=dz)
-        h = self.wave2.head(x_d2, 2.0 ** 1, x_gate=g).unsqueeze(1)
-        outputs[("wavelets", 1, "LH")] = h[:, :, 0]
-        outputs[("wavelets", 1, "HL")] = h[:, :, 1]
-        outputs[("wavelets", 1, "HH")] = h[:, :, 2]
-        ll, disp = ops.idwt_haar(ll, h, disp_scale=1.0 / 2 ** 1, clamp01=False)
-        outputs[("disp", 1)] = disp
-
-        x_d3 = self.up3(x_d2, x_blocks[-4], x1_gate=g, grad_is_dz=dz)
-        h = self.wave3.head(x_d3, 1.0, x_gate=g).unsqueeze(1)
-        outputs[("wavelets", 0, "LH")] = h[:, :, 0]
-        outputs[("wavelets", 0, "HL")] = h[:, :, 1]
-        outputs[("wavelets", 0, "HH")] = h[:, :, 2]
-        ll, _ = ops.idwt_haar(ll, h)
-        outputs[("disp", 0)] = ll
+        for k in (1, 2, 3):           # level k: highs of scale s = 3 - k, scaled 2^s (:122-147); no sigmoid, no clamp
+            s = 3 - k
+            if k > 1:
+                x = getattr(self, "up%d" % k)(x, x_blocks[-1 - k], x1_gate=g, grad_is_dz=dz)
+            h = getattr(self, "wave%d" % k).head(x, 2.0 ** s, x_gate=g).unsqueeze(1)
+            if k == 1:
+                outputs[("wavelets", 2, "LL")] = ll
+            _log_highs(outputs, s, h)
+            if s:
+                ll, outputs[("disp", s)] = ops.idwt_haar(ll, h, disp_scale=1.0 / 2 ** s, clamp01=False)
+            else:
+                ll, _ = ops.idwt_haar(ll, h)
+                outputs[("disp", 0)] = ll
         return outputs
 
 
@@ -163,19 +154,7 @@ class DecoderWave224(nn.Module):
         self.iwt = IDWT(wave="haar", mode=wave_pad)
         self.iwt_LL = IDWT(wave="haar", mode="zero")
         self.conv2 = NyuConv3x3(enc_features[-1], features, padding="replicate")
-        self.up1 = UpSampleBlock(skip_input=features // 1 + enc_features[-2], output_features=features // 2,
-                                 padding=padding, is_depthwise=dw_upconv)
-        self.wave1_ll = NyuConv3x3(features // 2, 1, padding="replicate")
-        self.wave1 = NyuConv3x3(features // 2, 3, padding=wave_pad, is_depthwise=dw_waveconv)
-        self.up2 = UpSampleBlock(skip_input=features // 2 + enc_features[-3], output_features=features // 4,
-                                 padding=padding, is_depthwise=dw_upconv)
-        self.wave2 = NyuConv3x3(features // 4, 3, padding=wave_pad, is_depthwise=dw_waveconv)
-        self.up3 = UpSampleBlock(skip_input=features // 4 + enc_features[-4], output_features=features // 8,
-                                 padding=padding, is_depthwise=dw_upconv)
-        self.wave3 = NyuConv3x3(features // 8, 3, padding=wave_pad, is_depthwise=dw_waveconv)
-        self.up4 = UpSampleBlock(skip_input=features // 8 + enc_features[-5], output_features=features // 16,
-                                 padding=padding, is_depthwise=dw_upconv)
-        self.wave4 = NyuConv3x3(features // 16, 3, padding=wave_pad, is_depthwise=dw_waveconv)
+        _add_levels(self, features, enc_features, 4, padding, dw_up=dw_upconv, wave_pad=wave_pad, dw_wave=dw_waveconv)
         self.sigmoid = nn.Sigmoid()
 
     _wave = staticmethod(DecoderWave._wave)
@@ -191,9 +170,7 @@ class DecoderWave224(nn.Module):
             h = self._wave(wave, x, 2.0 ** s).unsqueeze(1)
             if level == 0:
                 outputs[("wavelets", 3, "LL")] = ll
-            outputs[("wavelets", s, "LH")] = h[:, :, 0]
-            outputs[("wavelets", s, "HL")] = h[:, :, 1]
-            outputs[("wavelets", s, "HH")] = h[:, :, 2]
+            _log_highs(outputs, s, h)
             if s == 1:
                 ll, _ = ops.idwt_haar(ll, h)
                 outputs[("disp", 1)] = ll // (2 ** 1)     # sic (floor_divide: not differentiable, as in the reference)
@@ -257,7 +234,7 @@ class SparseDecoderWave(DecoderWave):
         h = self._wave(self.wave1, x_d1, 2.0 ** 2).unsqueeze(1)
         out[("wavelet_mask", 2)] = torch.ones_like(h[:, 0])
         out[("wavelets", 2, "LL")] = ll
-        out[("wavelets", 2, "LH")], out[("wavelets", 2, "HL")], out[("wavelets", 2, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+        _log_highs(out, 2, h)
         ll, disp = ops.idwt_haar(ll, h, disp_scale=0.25, clamp01=False)
         out[("disp", 2)] = disp
 
@@ -287,7 +264,7 @@ class SparseDecoderWave(DecoderWave):
             S.sparse_conv(hd[0], xa, ops.pack_weights(cw.weight), cw.bias, 3, 3, co_wl, nnz.data_ptr() + 4, H2 * W2,
                           in_mask=wave_mask, pad="zero", act="none", out_scale=scale)
             h = hd.unsqueeze(1)
-            out[("wavelets", s, "LH")], out[("wavelets", s, "HL")], out[("wavelets", s, "HH")] = h[:, :, 0], h[:, :, 1], h[:, :, 2]
+            _log_highs(out, s, h)
             ll, disp = ops.idwt_haar(ll, h, disp_scale=0.5 if level == 0 else 1.0, clamp01=False)
             out[("disp", s)] = disp if level == 0 else ll
             pending.append((nnz, ca.weight.shape[1], Ca, cw.weight.shape[1]))
