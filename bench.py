@@ -23,6 +23,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC: RCCL (and CUDA-tensor sharing across processes) needs it on this driver.  Set before the first HIP call so that it
+# also holds when an external launcher (the driver's torch.distributed.run) starts the ranks.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -44,15 +47,32 @@ def build_model(dev):
     return dec, feats
 
 
-def cpu_baseline(dec, feats, budget_s=20.0):
+def cpu_baseline(dec, feats, gpu_out=None, budget_s=20.0):
     """The CPU oracle (PyTorch-CPU/oneDNN restatement of the reference decoder) on the host cores,
     on a bounded sample of the same workload.  oneDNN does not scale to every hardware thread of a big
     host, so one full-batch pass per candidate thread count picks the best first (the baseline gets its
-    best case), then whole 12-frame batches are timed until ~budget_s elapsed."""
+    best case), then whole 12-frame batches are timed until ~budget_s elapsed.
+
+    gpu_out: the output dict of the LAST timed step (graph replay, committed tile choices): the oracle, as the checker, is
+    held against two of its frames first -- every disparity map and coefficient plane within 1e-4 of the tensor's scale
+    (north_star's tolerance) or the run aborts."""
     from oracle import decoder_ref as R
 
     sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
     cf = [f.cpu() for f in feats]
+    parity = None
+    if gpu_out is not None:
+        worst = 0.0
+        with torch.no_grad():
+            for fr in (0, BATCH - 1):
+                ref = R.kitti_wave_decoder([f[fr:fr + 1] for f in cf], sd)
+                for k, v in ref.items():
+                    got = gpu_out[k][fr:fr + 1].float().cpu()
+                    err = float((got - v).abs().max() / max(float(v.abs().max()), 1e-30))
+                    worst = max(worst, err)
+                    if not err <= 1e-4:
+                        raise SystemExit("bench.py: the timed execution mode disagrees with the oracle on %s frame %d: %.3e" % (k, fr, err))
+        parity = {"frames_checked": [0, BATCH - 1], "outputs_checked": len(ref), "max_rel_err": worst, "tolerance": 1e-4}
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -81,14 +101,14 @@ def cpu_baseline(dec, feats, budget_s=20.0):
             R.kitti_wave_decoder(cf, sd)
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": round(BATCH / med, 2), "unit": "frames/s", "cores": best, "kind": "port",
+    return {"value": round(BATCH / med, 2), "unit": "frames/s", "cores": best, "kind": "port", "parity_of_timed_mode": parity,
             "probe_frames_per_s_by_threads": probe_fps,   # one full batch each; 8 threads is SURVEY.md's probe setting
             "sample": "%d timed passes of the same 12x640x192 batch (median %.3f s/pass) after 1 warm-up; torch %s CPU; "
                       "%d threads = best of %s on one full-batch pass each; host exposes %d hardware threads"
                       % (len(times), med, torch.__version__, best, cands, avail)}
 
 
-def _train_setup(kind, args, rank, world, dev):
+def _train_setup(kind, args, rank, world, dev, strong=False):
     """-> (step, gx, describe) for one data-parallel training workload.
 
     kitti: BASELINE.json configs[2] -- ResNet encoder (PyTorch/MIOpen) + HIP wavelet decoder forward/backward, loss =
@@ -110,7 +130,7 @@ def _train_setup(kind, args, rank, world, dev):
         from wavelet_monodepth_amd.encoders import ResnetEncoder
         from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
         H, W, B = args.height, args.width, args.batch
-        if args.strong:      # fixed global batch: every rank takes its share ("also report strong scaling")
+        if strong:           # fixed global batch: every rank takes its share ("also report strong scaling")
             if B % world:
                 raise SystemExit("--strong: --batch %d is the GLOBAL batch and must divide by the %d ranks" % (B, world))
             B //= world
@@ -168,9 +188,32 @@ def _train_setup(kind, args, rank, world, dev):
             gx.finish()
         opt.step()
         return loss
+    def part_ms(which, n=5):
+        """Stand-alone forward + backward time of one half of the network on the step's shapes (hipEvents, mean of n after
+        2 warm-ups): what the 8-GPU curve is made of -- the encoder is PyTorch / MIOpen (out of scope), the decoder is this library."""
+        if which == "encoder":
+            run = lambda: sum(f.mean() for f in enc(img)).backward()
+        else:
+            with torch.no_grad():
+                fs = [f.detach() for f in enc(img)]
+            run = lambda: sum(v.mean() for k, v in dec(fs).items() if k[0] == "disp").backward()
+        import contextlib
+        with (gx.no_sync() if gx is not None else contextlib.nullcontext()):    # local passes: no bucket may leave
+            for _ in range(2):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            e1.synchronize()
+        if gx is None:
+            for p in params:
+                p.grad = None
+        return e0.elapsed_time(e1) / n
     return step, gx, {"workload": what, "batch_per_gpu": B, "global_batch": B * world,
                       "parallelism": "dp%d, %s bucketed all-reduce overlapped with the encoder backward" % (world, args.exchange_backend)}, \
-        (loss_fn, opt, [enc, dec])
+        (loss_fn, opt, [enc, dec], part_ms)
 
 
 def _timed(step, steps, warmup, world, red_dev):
@@ -196,16 +239,30 @@ def _timed(step, steps, warmup, world, red_dev):
     return elapsed, last
 
 
-def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup):
+def _per_step_ms(step, steps):
+    """One more pass of `steps` steps with an event after every step: the per-step spread (outside any timed region)."""
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
+    for k in range(steps):
+        step()
+        marks[k + 1].record()
+    torch.cuda.synchronize()
+    return sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
+
+
+def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup, strong=False):
     """Time the data-parallel training step with the gradient exchange on, then (world > 1) with the all-reduces switched
     off: the difference is the all-reduce time the overlap did NOT hide.  -> dict (same on every rank)."""
-    step, gx, cfg, (loss_fn, opt, nets) = _train_setup(kind, args, rank, world, dev)
+    step, gx, cfg, (loss_fn, opt, nets, part_ms) = _train_setup(kind, args, rank, world, dev, strong)
     elapsed, loss = _timed(step, steps, warmup, world, red_dev)
     assert torch.isfinite(loss)
     del loss      # nothing may keep the eager autograd graph (and its default-stream AccumulateGrad nodes) alive into the capture
+    spread = _per_step_ms(step, steps)
+    pct = lambda q: round(spread[int(q * (len(spread) - 1))], 3)
     B = cfg["batch_per_gpu"]
     res = {"frames_per_s": round(B * steps * world / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
-           "steps": steps, "warmup": warmup, "n_gpus": world, "config": cfg}
+           "ms_per_step_p10_median_p90": [pct(0.1), pct(0.5), pct(0.9)],
+           "steps": steps, "warmup": warmup, "n_gpus": world, "scaling": "strong" if strong else "weak", "config": cfg}
     if gx is not None:
         sizes = gx.message_bytes()
         gx.enabled = False            # local gradients only from here on (timing only; nothing after this needs the replicas in sync)
@@ -215,6 +272,11 @@ def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup):
                     "ms_per_step_without_exchange": round(local / steps * 1e3, 3),
                     "exposed_allreduce_ms_per_step": round((elapsed - local) / steps * 1e3, 3),
                     "exchange_backend": args.exchange_backend, "exchange_world_size": gx.world})
+    try:      # what the step is made of: the MIOpen encoder (out of scope) decides most of an 8-GPU curve
+        res["encoder_ms"] = round(part_ms("encoder"), 3)
+        res["decoder_ms"] = round(part_ms("decoder"), 3)
+    except Exception as e:
+        res["parts_error"] = repr(e)[:200]
     if args.train_graph == "on" or (args.train_graph == "auto" and world == 1 and args.workload != "fwd"):
         # the same step replayed from hipGraphs (graphs.TrainStepGraph).  At these sizes the eager step is NOT bound by its
         # python launches (the replay takes as long): reported beside the eager figure, which stays the headline
@@ -235,12 +297,12 @@ def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup):
 
 def train_main(kind, args, rank, world, dev, red_dev):
     """--workload train / train-nyu: the training step alone, as the one JSON line."""
-    st = train_stats(kind, args, rank, world, dev, red_dev, args.steps, args.warmup)
+    st = train_stats(kind, args, rank, world, dev, red_dev, args.steps, args.warmup, strong=args.strong)
     if rank == 0:
         cfg = st.pop("config")
         line = {"metric": "training frames/sec (encoder + wavelet decoder fwd+bwd + Adam)", "value": st.pop("frames_per_s"),
                 "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": st.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+                "ms_per_step": st.pop("ms_per_step"), "higher_is_better": True, "scaling": st.pop("scaling"),
                 "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic", "config": cfg}
         line.update({k: v for k, v in st.items() if k not in ("steps", "warmup", "n_gpus")})
@@ -280,7 +342,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--nyu-batch", type=int, default=4)
-    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--exchange-backend", choices=["rccl", "torch"], default=os.environ.get("WMD_BENCH_EXCHANGE", "rccl"))
     args = ap.parse_args()
 
@@ -358,16 +420,48 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert all(torch.isfinite(v).all() for v in out.values())
+    checked = {k: v.detach().clone() for k, v in out.items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    # Beside the headline (replay keyed on the identity of the resident feature tensors): the eager wall-clock per step (python
+    # launches, no graph) and the static-input entry -- a caller whose encoder hands over FRESH tensors every step copies them into
+    # decoder-owned buffers (decoder.bind_inputs) and replays the one capture; the copies (167.7 MB per batch) are inside the figure.
+    with torch.no_grad():
+        dec.enable_graph(False)
+        for _ in range(3):
+            dec(feats)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = dec(feats)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        fresh = [[f.clone() for f in feats] for _ in range(2)]
+        dec.bind_inputs(feats)
+        caps = dec.capture_count
+        for k in range(3):
+            dec(fresh[k & 1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            out = dec(fresh[k & 1])
+        torch.cuda.synchronize()
+        bound_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        recaptures = dec.capture_count - caps
+        del fresh
 
     # data-parallel training step (BASELINE.json configs[2]) through the gradient exchange: every rank takes part
-    train = None
+    train = train_strong = None
     if not args.no_train:
         del out
         dec.enable_graph(False)
         try:      # an extra of the line: a failure here (e.g. the RCCL exchange cannot be set up) must not cost the headline figure
-            train = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 3)
+            train = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 5)
         except Exception as e:
             train = {"error": repr(e)[:400]}
+        if world > 1 and args.batch % world == 0:      # "also report strong scaling of a fixed global batch"
+            try:
+                train_strong = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 5, strong=True)
+            except Exception as e:
+                train_strong = {"error": repr(e)[:400]}
 
     if rank == 0:
         frames = BATCH * args.steps * world
@@ -380,6 +474,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "ms_per_step_p10_median_p90": [round(step_ms[int(q * (len(step_ms) - 1))], 4) for q in (0.1, 0.5, 0.9)],
+            "eager_ms_per_step": round(eager_ms, 4),
+            "static_input_ms_per_step": {"value": round(bound_ms, 4), "recaptures": recaptures,
+                                         "what": "decoder.bind_inputs: fresh feature tensors every step, copied into decoder-owned buffers, one capture replayed"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -389,8 +486,9 @@ def main():
                                    "(BASELINE.json configs[1]); encoder features resident in HBM",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": "dp%d (independent shards)" % world},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dec, feats),   # rank 0, N=1 only
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(dec, feats, checked),   # rank 0, N=1 only
             "train": train,
+            "train_strong": train_strong,
         }
         print(json.dumps(res))
     if world > 1:

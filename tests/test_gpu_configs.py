@@ -210,23 +210,41 @@ def test_config4_sparse_640x192_vs_reference_with_reference_masks(dev, thr):
 @pytest.mark.parametrize("thr", [0.01, 0.05, 0.1])
 def test_config4_sparse_640x192_free_running_vs_oracle(dev, thr):
     """No injected masks: the GPU's own thresholding.  A coefficient within rounding distance of the threshold may flip, so
-    masks are allowed to differ in at most 1e-4 of the pixels (none observed), and where a run produced identical masks
-    everything else must match the oracle to 1e-4 and the op count exactly."""
+    masks are allowed to differ in at most 1e-4 of the pixels (none observed).  With identical masks everything must match the
+    oracle to 1e-4 and the op count exactly; with k > 0 flips the disparities are still compared everywhere outside a
+    16-pixel neighbourhood (per level, propagated to the finer levels) of the flipped pixels."""
     sp = _sparse(dev)
     feats = kitti_feats(1, 192, 640, seed=1)
     sd = {k: v.cpu() for k, v in sp.state_dict().items()}
     with torch.no_grad():
         ref = R.kitti_sparse_decoder(feats, sd, thr)
     out = sp([f.to(dev) for f in feats], thr)
-    flips = 0
-    for s in range(3):
+    flips, taint = 0, None
+    tainted = {}
+    for s in (2, 1, 0):          # coarse to fine: a flipped pixel perturbs its own level locally and everything finer below it
         a, b = out[("wavelet_mask", s)].cpu(), ref[("wavelet_mask", s)]
-        flips += int((a != b).sum())
-        assert float((a != b).float().mean()) <= 1e-4, "scale %d: %d mask pixels differ" % (s, int((a != b).sum()))
+        diff = (a != b).float()
+        flips += int(diff.sum())
+        assert float(diff.mean()) <= 1e-4, "scale %d: %d mask pixels differ" % (s, int(diff.sum()))
+        if taint is not None:
+            taint = torch.nn.functional.interpolate(taint, scale_factor=2, mode="nearest")
+        taint = diff if taint is None else torch.maximum(taint, diff)
+        # 5x5 / 3x3 mask dilations, two 3x3 trunk convolutions, the 3x3 head and the IDWT: < 16 pixels at this level
+        taint = torch.nn.functional.max_pool2d(taint, 33, 1, 16)
+        tainted[s] = taint
+    print("config 4 thr %g: %d flipped mask pixels" % (thr, flips))
     if flips == 0:
         assert out["total_ops"] == ref["total_ops"]
-        for s in range(4):
-            assert_close(out[("disp", s)], ref[("disp", s)], NET_TOL, "disp%d" % s)
+    for s in range(4):
+        got, want = out[("disp", s)].cpu(), ref[("disp", s)]
+        if flips == 0 or s == 3:             # scale 3 is the dense level: no mask upstream of it
+            assert_close(got, want, NET_TOL, "disp%d" % s)
+            continue
+        # ("wavelet_mask", s) lives at the resolution of the coefficients of scale s: half that of ("disp", s)
+        clean = torch.nn.functional.interpolate(tainted[s], scale_factor=2, mode="nearest") == 0
+        assert float(clean.float().mean()) > 0.5, "too few pixels outside the neighbourhood of %d flips" % flips
+        err = float(((got - want).abs() * clean).max() / want.abs().max())
+        assert err <= NET_TOL, "disp%d outside the flips' neighbourhood: %.3e" % (s, err)
 
 
 @pytest.mark.parametrize("scales", [[0, 1], [1, 2], [0]])
@@ -266,3 +284,29 @@ def test_config1_test_simple_script_writes_its_outputs(dev, tmp_path):
             assert ll.shape == (1, 1, 96 >> s_, 320 >> s_) and np.isfinite(ll).all()
         if sub == "sparse":
             assert "total_ops" in r.stdout
+
+
+# ---- multi-GPU launch contract, rehearsed on one GPU ---------------------------------------------------------------------------
+def test_bench_two_rank_launch_contract_rehearsal(dev):
+    """`python bench.py --gpus 2` re-executes itself under torch.distributed.run (one process per rank, rendezvous on 127.0.0.1).
+    On a 1-GPU box the ranks share the device and every collective goes through gloo (WMD_BENCH_BACKEND=gloo,
+    WMD_BENCH_SHARE_DEVICES=1, --exchange-backend torch): not a measurement, but the whole N > 1 path -- respawn, process group,
+    barriers, max-over-ranks timing, the data-parallel `train` and `train_strong` objects with their exchange statistics, one
+    JSON line from rank 0 -- runs end to end."""
+    import json
+    env = dict(os.environ, WMD_BENCH_BACKEND="gloo", WMD_BENCH_SHARE_DEVICES="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--train-steps", "3",
+           "--exchange-backend", "torch", "--num-layers", "18", "--height", "96", "--width", "320", "--batch", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 24 and res["cpu_baseline"] is None
+    for key, per_gpu in (("train", 2), ("train_strong", 1)):
+        tr = res[key]
+        assert "error" not in tr, tr
+        assert tr["n_gpus"] == 2 and tr["exchange_world_size"] == 2 and tr["config"]["batch_per_gpu"] == per_gpu
+        assert tr["gradient_bytes"] > 40e6 and len(tr["ms_per_step_p10_median_p90"]) == 3
+        assert tr["encoder_ms"] > 0 and tr["decoder_ms"] > 0

@@ -27,6 +27,10 @@ import contextlib
 import ctypes as C
 import os
 
+# dmabuf IPC: without it RCCL's communicator set-up fails on this driver (hipIpcGetMemHandle: invalid argument).  Read by the
+# HIP runtime when it initialises, so import this module (or set the variable) before the first HIP call of the process.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 

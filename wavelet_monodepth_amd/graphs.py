@@ -12,6 +12,7 @@ class GraphCache:
     def __init__(self, max_entries=8):
         self._entries = {}
         self._max = max_entries
+        self.captures = 0
 
     def clear(self):
         self._entries.clear()
@@ -33,6 +34,7 @@ class GraphCache:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = fn(inputs)
+            self.captures += 1
             ent = (g, out, list(inputs))  # keep the inputs alive: the graph reads their storage
             self._entries[key] = ent
         ent[0].replay()
