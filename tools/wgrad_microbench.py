@@ -39,7 +39,7 @@ for name, (C1, up, C2, Cout, H, W, k) in L.items():
     res = []
     ref = None
     db_ref = None
-    runs = [("direct", 0)] + [("direct", c) for c in (cfgs or [])] + [("wino", c) for c in range(0, 13)]
+    runs = [("direct", 0)] + [("direct", c) for c in (cfgs or [])] + [("wino", c) for c in range(0, l.wmd_conv_wgrad_num_configs() + 1)]
     for kind, cfg in runs:
         os.environ.pop("WMD_WGRAD_CFG", None)
         os.environ.pop("WMD_WGRAD_WINO_CFG", None)

@@ -15,11 +15,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
-#include "wmd_internal.h"
+#include "wmd_conv_common.h"
 
 namespace wmd {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stream);
 
@@ -117,21 +116,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_fold_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 // wgrad
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ void wg_dma4(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 4, voff, soff, 0, 0);
 }
-
-struct WgradKArgs {
-    const float* x1;
-    const float* x2;
-    const float* dz;
-    float* partial;  // [nsplit][Cout*Cin*taps + Cout]  (weights, then the bias partial sums)
-    int B, H, W, H1, W1, C1, C2, Cin, Cout, up1, pad_mode;
-    int tiles_x, tiles_y, ntiles;  // pixel tiles per image / total (B * tiles_x * tiles_y)
-    int nsplit;
-    int want_bias;
-};
 
 // Block = WM x WN waves. Wave (wm, wn) owns MR out-channel tiles (16 each) x NC 16-input-channel groups x TAPS.
 // Pixel tile = TH x TW (TW % 4 == 0): the MFMA K index walks 4 consecutive pixels of a row.
@@ -807,6 +794,7 @@ struct WgradWinoCfg {
     int TH, TW, MR, NC, WM, WN;
     void (*launch)(const WgradKArgs&, dim3, hipStream_t);
     const char* name;
+    int bpc;      // blocks that share a CU (the pixel split aims at this many rounds-free blocks per CU)
 };
 template <int TH, int TW, int MR, int NC, int WM, int WN>
 static void launch_wgrad_wino(const WgradKArgs& a, dim3 grid, hipStream_t s) {
@@ -815,8 +803,13 @@ static void launch_wgrad_wino(const WgradKArgs& a, dim3 grid, hipStream_t s) {
 #define WMD_WWCFG(TH, TW, MR, NC, WM, WN)                                                  \
     WgradWinoCfg {                                                                         \
         TH, TW, MR, NC, WM, WN, &launch_wgrad_wino<TH, TW, MR, NC, WM, WN>,                \
-            "conv_wgrad_wino_kernel<" #TH "," #TW "," #MR "," #NC "," #WM "," #WN ">"      \
+            "conv_wgrad_wino_kernel<" #TH "," #TW "," #MR "," #NC "," #WM "," #WN ">", 2   \
     }
+// conv_wgrad_wino32_kernel (wmd_conv_wgrad32.hip): WCO x WCI slabs of 32 channels; the table's tile arithmetic sees them as
+// MR = NC = 2 sixteen-channel tiles per "wave row / column"
+#define WMD_WG32_INST(TH, TW, WCO, WCI)                                                                           \
+    WgradWinoCfg{TH, TW, 2, 2, WCO, WCI, &launch_wgrad_wino32<TH, TW, WCO, WCI>,                                  \
+                 "conv_wgrad_wino32_kernel<" #TH "," #TW "," #WCO "," #WCI ">", (WCO) * (WCI) >= 4 ? 1 : 2},
 static const WgradWinoCfg kWWCfgs[] = {
     WMD_WWCFG(2, 32, 1, 1, 4, 1),   // co64 x ci16, 64-pixel tiles (55 KB: 2 blocks / CU)
     WMD_WWCFG(2, 32, 1, 1, 2, 2),   // co32 x ci32
@@ -830,6 +823,7 @@ static const WgradWinoCfg kWWCfgs[] = {
     WMD_WWCFG(2, 32, 1, 1, 1, 4),   // co16 x ci64: the heads' Cout <= 4 filters (3/16 of the MFMA rows carry data)
     WMD_WWCFG(2, 40, 1, 1, 1, 4),
     WMD_WWCFG(2, 32, 1, 2, 1, 2),   // co16 x ci64 in 2 waves
+#include "wmd_conv_wgrad32_table.inc"
 };
 constexpr int kNumWWCfgs = sizeof(kWWCfgs) / sizeof(kWWCfgs[0]);
 
@@ -864,15 +858,16 @@ static bool plan_wgrad_wino(const wmd_conv_wgrad_args* g, WgradWinoPlan* p) {
         const double pix_waste = (double)tx * c.TW * ty * c.TH / ((double)H * W);
         if (force < 0 && pix_waste > 1.6) continue;
         const double waste = ((double)gx * cit / Cin) * ((double)gy * cot / g->Cout) * pix_waste;
-        long nsplit = std::max<long>(1, (2L * kNumCU + (long)gx * gy - 1) / ((long)gx * gy));
+        long nsplit = std::max<long>(1, ((long)c.bpc * kNumCU + (long)gx * gy - 1) / ((long)gx * gy));
         nsplit = std::min<long>(nsplit, std::max<long>(1, ntiles / 4));
         nsplit = std::min<long>(nsplit, 128);
         if (e_ns && atoi(e_ns) > 0) nsplit = std::min<long>(atoi(e_ns), std::max<long>(1, ntiles));
         if (g->tune_nsplit > 0) nsplit = std::min<long>(g->tune_nsplit, std::max<long>(1, ntiles));
-        const double rounds = std::ceil((double)gx * gy * nsplit / (2.0 * kNumCU));
-        // two ci tiles / two co tiles per wave amortise the transforms: small bonus
-        const double eff = (c.MR * c.NC > 1) ? 0.93 : 1.0;
-        const double cost = eff * waste * rounds * 2.0 * kNumCU / ((double)gx * gy * nsplit);
+        const double rounds = std::ceil((double)gx * gy * nsplit / ((double)c.bpc * kNumCU));
+        // two ci tiles / two co tiles per wave amortise the transforms: small bonus; the 32x32x2 family runs ~2x the rate
+        const bool w32 = c.launch != nullptr && c.name[16] == '3';     // "conv_wgrad_wino32_kernel<..."
+        const double eff = w32 ? 0.5 : ((c.MR * c.NC > 1) ? 0.93 : 1.0);
+        const double cost = eff * waste * rounds * (double)c.bpc * kNumCU / ((double)gx * gy * nsplit);
         if (cost < best) {
             best = cost;
             found = true;

@@ -97,4 +97,20 @@ inline bool wino32_pure(const ConvKArgs& a, int CK) {
 template <int TH, int TW, int WN, int CK>
 void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s);   // explicit instantiations: wmd_conv_wino32_table.inc
 
+// weight-gradient kernels (wmd_conv_bwd.hip, wmd_conv_wgrad32.hip)
+struct WgradKArgs {
+    const float* x1;
+    const float* x2;
+    const float* dz;
+    float* partial;  // [nsplit][Cout*Cin*taps + Cout]  (weights, then the bias partial sums)
+    int B, H, W, H1, W1, C1, C2, Cin, Cout, up1, pad_mode;
+    int tiles_x, tiles_y, ntiles;  // pixel tiles per image / total (B * tiles_x * tiles_y)
+    int nsplit;
+    int want_bias;
+};
+
+// conv_wgrad_wino32_kernel (wmd_conv_wgrad32.hip): block = WCO x WCI slabs of 32 out / 32 in channels, two position halves each
+template <int TH, int TW, int WCO, int WCI>
+void launch_wgrad_wino32(const WgradKArgs& a, dim3 grid, hipStream_t s);
+
 }  // namespace wmd
