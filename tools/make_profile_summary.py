@@ -1,6 +1,12 @@
-"""Turn the raw rocprofv3 outputs of one profiling session (gpurun_out/) into the committed profiles/ artefacts:
-    python tools/make_profile_summary.py <tag> <bench.json> <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <pmc_mfma_dir> [tune_cache.json]
-writes profiles/<tag>_bench_fwd.json, <tag>_kernel_stats.csv, <tag>_pmc_fwd.json, pmc_traffic.json."""
+"""Turn the raw outputs of one profiling session (tools/profile_session.sh -> gpurun_out/<dir>/) into the committed profiles/ artefacts:
+    python tools/make_profile_summary.py <tag> <gpurun_out/dir>
+writes profiles/<tag>_bench_fwd.json, <tag>_kernel_stats.csv, <tag>_pmc_{fwd,bwd,sparse}.json, pmc_traffic.json and copies the
+text reports (training profiles, sparse workloads, GPU test log) under the same tag.
+
+PMC conventions (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE / SQ counters come from SEPARATE rocprofv3 --pmc passes of the same
+command (never combined with a trace domain); FETCH_SIZE reports half of the fetched bytes on gfx950, so HBM-side bytes per
+launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; GRBM_GUI_ACTIVE is summed over the 8 XCDs and SQ_VALU_MFMA_BUSY_CYCLES over the
+1024 SIMDs, so MFMA-busy = busy / (gui_active / 8 * 1024); SQ_WAIT_* / SQ_ACTIVE_* are fractions of SQ_WAVE_CYCLES."""
 import collections
 import csv
 import glob
@@ -10,49 +16,95 @@ import re
 import shutil
 import sys
 
-tag, bench, stats, fetch, write, mfma = sys.argv[1:7]      # mfma may be "-" (no SQ pass in this session)
+tag, src = sys.argv[1:3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 
 
-def per_kernel(d, counter):
-    a = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0])):
-        if r["Counter_Name"] == counter:
-            a[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return a
+def short(name):
+    """'void wmd::conv_wino32_kernel<8, 32, 2, 8, false>(wmd::ConvKArgs)' -> 'conv_wino32_kernel<8,32,2,8>' (bench.py's names)."""
+    m = re.search(r"(?:wmd::)?([A-Za-z0-9_]+)(<[^>]*>)?\(", name)
+    if not m:
+        return name[:80]
+    args = (m.group(2) or "").replace(" ", "")
+    args = re.sub(r",false(,2)?>$", ">", args)      # dense / pure instantiations; NBUF = 2 default of conv_fwd_kernel
+    args = args.replace(",false,2>", ">")
+    return m.group(1) + args
 
 
-shutil.copy(bench, os.path.join(P, tag + "_bench_fwd.json"))
-shutil.copy(glob.glob(os.path.join(stats, "*", "*kernel_stats.csv"))[0], os.path.join(P, tag + "_kernel_stats.csv"))
-if len(sys.argv) > 7:
-    shutil.copy(sys.argv[7], os.path.join(P, tag.split("_")[0] + "_tune_cache.json"))
-f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-mb, ga = (per_kernel(mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(mfma, "GRBM_GUI_ACTIVE")) if mfma != "-" else ({}, {})
-out, traffic = {}, {}
-for k in f:
-    if "wmd" not in k:
+def counters(kind, which):
+    """reads the reduced pmc_<kind>_<which>.csv of tools/pmc_reduce.py: (kernel, grid) -> counter -> (launches, mean)"""
+    f = os.path.join(src, "pmc_%s_%s.csv" % (kind, which))
+    rows = collections.defaultdict(dict)
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            rows[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]] = (int(r["launches"]), float(r["mean"]))
+    return rows
+
+
+def summarise(kind):
+    f, w, s = counters(kind, "fetch"), counters(kind, "write"), counters(kind, "mfma")
+    out = {}
+    avg = lambda x: x[1] if x else 0.0
+    for key in sorted(set(f) | set(w) | set(s)):
+        name, grid = key
+        row = {"launches_seen": (f[key].get("FETCH_SIZE") or s[key].get("GRBM_GUI_ACTIVE") or (0, 0))[0]}
+        fk, wk = avg(f[key].get("FETCH_SIZE")), avg(w[key].get("WRITE_SIZE"))
+        row["fetch_kib_raw"], row["write_kib"] = round(fk, 1), round(wk, 1)
+        row["hbm_bytes_per_launch"] = int((2 * fk + wk) * 1024)
+        c = s[key]
+        if avg(c.get("GRBM_GUI_ACTIVE")) > 0:
+            simd_cycles = avg(c["GRBM_GUI_ACTIVE"]) / 8 * 1024
+            row["gpu_cycles"] = int(avg(c["GRBM_GUI_ACTIVE"]) / 8)
+            row["mfma_busy_frac"] = round(avg(c.get("SQ_VALU_MFMA_BUSY_CYCLES")) / simd_cycles, 3)
+            wc = avg(c.get("SQ_WAVE_CYCLES"))
+            if wc:
+                row["waves_per_simd"] = round(4 * wc / simd_cycles, 2)
+                for k, label in (("SQ_WAIT_ANY", "wait_frac"), ("SQ_WAIT_INST_ANY", "issue_stall_frac"), ("SQ_ACTIVE_INST_ANY", "issuing_frac")):
+                    row[label] = round(avg(c.get(k)) / wc, 3)
+            row["mfma_insts"] = int(avg(c.get("SQ_INSTS_MFMA")))
+        out.setdefault(name, {})[grid] = row
+    return out
+
+
+def merged(per_grid):
+    """launch-weighted average over the grids of one kernel name (what bench.py's per-name records average over)."""
+    n = sum(max(r["launches_seen"], 1) for r in per_grid.values())
+    tot = lambda k: sum(r.get(k, 0) * max(r["launches_seen"], 1) for r in per_grid.values()) / n
+    return {"traffic_bytes_per_launch": int(tot("hbm_bytes_per_launch")), "fetch_kib_raw": round(tot("fetch_kib_raw"), 1),
+            "write_kib": round(tot("write_kib"), 1), "mfma_busy_frac": round(tot("mfma_busy_frac"), 3),
+            "by_grid_size": per_grid}
+
+
+def copy(rel, dst):
+    files = glob.glob(os.path.join(src, rel))
+    if files:
+        shutil.copy(files[0], os.path.join(P, dst))
+        return True
+    return False
+
+
+copy("bench.json", tag + "_bench_fwd.json")
+copy("kernel_stats.csv", tag + "_kernel_stats.csv")
+for f in glob.glob(os.path.join(src, "train_profile_*.txt")):
+    shutil.copy(f, os.path.join(P, tag + "_" + os.path.basename(f)))
+copy("sparse_workloads.txt", tag + "_sparse_workloads.txt")
+copy("sparse_profile_thr0.15.txt", tag + "_sparse_profile_thr0.15.txt")
+copy("gpu_tests.txt", tag + "_gpu_tests.txt")
+method = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc <SQ counters> GRBM_GUI_ACTIVE in separate passes (tools/profile_session.sh); "
+          "per-launch averages; HBM-side bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE reports half of the fetched bytes on gfx950)")
+for kind, what in (("fwd", "WMD_BENCH_GRAPH=0 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train"),
+                   ("bwd", "python tools/train_profile.py (decoder forward + backward, config 2 shapes)"),
+                   ("sparse", "python tools/sparse_profile.py 0.15 (sparse KITTI decoder, batch 1)")):
+    summ = summarise(kind)
+    if not summ:
         continue
-    row = {"launches": len(f[k]), "FETCH_SIZE_KiB_avg": sum(f[k]) / len(f[k]),
-           "WRITE_SIZE_KiB_avg": sum(w.get(k, [0])) / max(1, len(w.get(k, [1])))}
-    if k in mb and sum(ga.get(k, [0])):
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
-        row["mfma_busy_frac"] = (sum(mb[k]) / len(mb[k])) / ((sum(ga[k]) / len(ga[k])) / 8 * 1024)
-    out[k] = row
-    m = re.search(r"(conv_fwd_kernel|conv_wino_kernel)<([0-9a-z, ]+)>", k)
-    if m:
-        name = m.group(1) + "<" + m.group(2).replace(" ", "").replace(",false,2", "") + ">"
-        name = name.replace(",false>", ">")      # dense instantiation of the Winograd kernel (MASKED = false)
-        if "true" in name:
-            continue
-        traffic[name] = {"traffic_bytes_per_launch": int((2 * row["FETCH_SIZE_KiB_avg"] + row["WRITE_SIZE_KiB_avg"]) * 1024),
-                         "fetch_kib_raw": round(row["FETCH_SIZE_KiB_avg"], 1), "write_kib": round(row["WRITE_SIZE_KiB_avg"], 1),
-                         "mfma_busy_frac": round(row.get("mfma_busy_frac", 0.0), 3)}
-json.dump(out, open(os.path.join(P, tag + "_pmc_fwd.json"), "w"), indent=1)
-json.dump({"_method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters in separate passes over `WMD_BENCH_GRAPH=0 python "
-                      "bench.py --steps 3 --warmup 2 --no-cpu-baseline` with the committed autotune cache; per-launch averages; bytes = "
-                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md: FETCH_SIZE reports half of the fetched bytes on gfx950; "
-                      "WRITE_SIZE calibrated exact on the IDWT kernel: 11520 KiB reported = 11520 KiB written)",
-           "session": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, session " + tag, "kernels": traffic}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-for k, v in sorted(traffic.items()):
-    print(k, v)
+    json.dump({"_method": method, "command": what, "session": tag, "kernels": summ}, open(os.path.join(P, "%s_pmc_%s.json" % (tag, kind)), "w"), indent=1)
+    if kind == "fwd":
+        json.dump({"_method": method, "session": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, session " + tag,
+                   "kernels": {k: merged(v) for k, v in summ.items()}}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    print("==", kind)
+    for name, grids in sorted(summ.items()):
+        for g, r in grids.items():
+            print("  %-44s grid %-9s %7.1f MB  mfma %.3f  wait %.2f  stall %.2f" % (name, g, r["hbm_bytes_per_launch"] / 1e6, r.get("mfma_busy_frac", 0),
+                                                                                r.get("wait_frac", 0), r.get("issue_stall_frac", 0)))

@@ -1,26 +1,50 @@
 #!/bin/bash
 # One profiling session on the GPU box (run from the repo root through gpurun); raw outputs go to gpurun_out/<tag>/,
 # tools/make_profile_summary.py turns them into the committed profiles/ artefacts.
-#   usage: bash tools/profile_session.sh <tag>
+#   usage: bash tools/profile_session.sh <tag> [fwd] [bwd] [sparse] [tests]        (default: all four)
 set -u
-TAG=${1:-session}
+TAG=${1:-session}; shift
+WHAT=${*:-fwd bwd sparse tests}
 OUT=$PWD/gpurun_out/$TAG
+REPO=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
-# 1. re-tune tile/split-K choices for config 2 and run the full bench line (with the CPU baseline)
-WMD_BENCH_RETUNE=1 WMD_TUNE_CACHE=$OUT/tune_cache.json python bench.py > $OUT/bench_retune.json 2> $OUT/bench_retune.err
-export WMD_TUNE_CACHE=$OUT/tune_cache.json
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -c 600 $OUT/bench.json
-# 2. kernel trace of the same command (no CPU leg)
-#    (two-stream replay off: co-running kernels stretch each other's durations, the summary is compared with bench.py's
-#     serial per-launch hipEvents; the overlapped trace is kept next to it)
-(cd /tmp && WMD_TWO_STREAM_GRAPHS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $OLDPWD/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_two_stream -- python $OLDPWD/bench.py --no-cpu-baseline > $OUT/stats_two_stream.log 2>&1)
-# 3. PMC passes, separate runs, eager launches so every kernel is a dispatch of its own
-for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-    set -- $pass
-    name=$1; shift
-    (cd /tmp && WMD_BENCH_GRAPH=0 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python $OLDPWD/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1)
+pmc_passes() {   # $1 = name prefix, rest = command: FETCH_SIZE / WRITE_SIZE / SQ counters in separate passes (never with a trace domain)
+    local name=$1; shift
+    local SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA"
+    (cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${name}_fetch -- "$@" > $OUT/pmc_${name}_fetch.log 2>&1)
+    python $REPO/tools/pmc_reduce.py $OUT/pmc_${name}_fetch
+    (cd /tmp && timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${name}_write -- "$@" > $OUT/pmc_${name}_write.log 2>&1)
+    python $REPO/tools/pmc_reduce.py $OUT/pmc_${name}_write
+    (cd /tmp && timeout 400 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmc_${name}_mfma -- "$@" > $OUT/pmc_${name}_mfma.log 2>&1)
+    python $REPO/tools/pmc_reduce.py $OUT/pmc_${name}_mfma
+}
+for w in $WHAT; do
+case $w in
+fwd)
+    python bench.py > $OUT/bench.json 2> $OUT/bench.err
+    tail -c 400 $OUT/bench.json; echo
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $REPO/bench.py --no-cpu-baseline --no-train > $OUT/stats.log 2>&1)
+    cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv; rm -rf $OUT/stats
+    WMD_BENCH_GRAPH=0 pmc_passes fwd python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train ;;
+bwd)   # WMD_TUNE_CACHE: the first run tunes and stores its choices, the counter passes replay them (no tuning launches in the counters)
+    export WMD_TUNE_CACHE=$OUT/train_tune_cache.json
+    python tools/train_profile.py > $OUT/train_profile_r18_640x192_bs12.txt 2>&1
+    python tools/train_profile.py --chans 64,256,512,1024,2048 --height 320 --width 1024 --batch 8 > $OUT/train_profile_r50_1024x320_bs8.txt 2>&1
+    python tools/train_profile.py --nyu > $OUT/train_profile_nyu_densenet161_640x480_bs4.txt 2>&1
+    head -4 $OUT/train_profile_*.txt
+    pmc_passes bwd python $REPO/tools/train_profile.py
+    unset WMD_TUNE_CACHE ;;
+sparse)
+    python tools/config_bench.py sparse > $OUT/sparse_workloads.txt 2>&1
+    tail -n 30 $OUT/sparse_workloads.txt
+    export WMD_TUNE_CACHE=$OUT/sparse_tune_cache.json
+    python tools/sparse_profile.py 0.15 > $OUT/sparse_profile_thr0.15.txt 2>&1
+    pmc_passes sparse python $REPO/tools/sparse_profile.py 0.15
+    unset WMD_TUNE_CACHE ;;
+tests)
+    timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=10 > $OUT/gpu_tests.txt 2>&1
+    tail -n 3 $OUT/gpu_tests.txt ;;
+esac
 done
-ls $OUT
+du -sh $OUT; ls $OUT

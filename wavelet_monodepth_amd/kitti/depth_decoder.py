@@ -70,7 +70,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
         # 200-register blocks per CU) the side-stream heads no longer find idle CUs: 0.648 vs 0.625 ms (round 3, same box)
         self.two_stream_graphs = os.environ.get("WMD_TWO_STREAM_GRAPHS", "0") == "1"
         self.static_inputs = None      # bind_inputs(): decoder-owned input buffers of the replayed graphs
-        self.capture_count = 0         # graph captures so far (a caller that thrashes the replay cache sees it grow)
+        self._segment_captures = 0
         self._segments = {}
 
     # -- pieces ------------------------------------------------------------------------------
@@ -135,6 +135,11 @@ class DepthWaveProgressiveDecoder(nn.Module):
                                 pad="reflect", mode=2, scale=2.0 ** (scale - 1))
         return yl, yh.unsqueeze(1)
 
+    @property
+    def capture_count(self):
+        """Graph captures so far, in either graph mode (a caller that thrashes the replay cache sees it grow)."""
+        return self._segment_captures + self._graphs.captures
+
     def bind_inputs(self, example_features):
         """Static-input entry for graph replay.  The replay key of `enable_graph` is the identity of the input tensors, so a
         caller whose encoder returns fresh tensors every step (every real caller: trainer.py:240-241) would re-capture on
@@ -190,7 +195,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
             if len(self._segments) >= 4:
                 self._segments.clear()
             ent = self._capture_two_streams(list(input_features))
-            self.capture_count += 1
+            self._segment_captures += 1
             self._segments[key] = ent
         trunk, heads, events, side, done, outputs, _keep = ent
         main = torch.cuda.current_stream()

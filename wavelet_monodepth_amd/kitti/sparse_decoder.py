@@ -185,6 +185,7 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         SPECS = [(1, 1), (1, 2), (2, 2), (2, 1), (2, 0)]   # lowres, upconv0, upsample, upconv1, wavelet (:311-319)
         for i in range(4, -1, -1):
             scale_ops = 0
+            fused_idwt = None       # (next low-pass, disparity) when the level's head kernels already ran the synthesis
             h, w = x.shape[-2:] if xbuf is None else xbuf.shape[-2:]
             forced = _force_masks is not None and i in _force_masks
             if i == 4 and not forced:
@@ -264,18 +265,31 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                     i, h, w, False, ((src.shape[1], c0.weight.shape[0]), (cin1, c1.weight.shape[0])),
                     [(hd[0].conv.weight.shape[1], hd[0].conv.weight.shape[0], hd[2].conv.weight.shape[1],
                       hd[2].conv.weight.shape[0]) for hd in hds])
-                ll_new, yh = self._dense_coefficients(ux, i, with_ll=(i == 4))
-                if i == 4:
-                    yl = ll_new
+                if i == 4 and not forced and int(ux.shape[1]) in ops.FUSED_HEAD_WIDTHS:
+                    # the dense level of every decode: the inference form of the heads (chained 1x1 -> tap-partial GEMMs, then
+                    # one pass of 9-tap gather + sigmoid + combine + Haar synthesis + clamp: 3 launches instead of 5; the
+                    # all-ones wavelet mask of this level needs no multiply)
+                    unpack = lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias)
+                    yh, yl_next, disp4, yl = ops.head_fused_level_nograd(
+                        ux, unpack(self.convs[("waveconv", 4, 1)]), unpack(self.convs[("waveconv", 4, -1)]), scale=2.0 ** 3,
+                        disp_scale=1.0 / 2 ** 3, clamp01=True, head_ll=unpack(self.convs[("waveconv", 4, 0)]), scale_ll=2.0 ** 4)
+                    fused_idwt = (yl_next, disp4)
                 else:
-                    yh = yh * wavelet.reshape(B, 1, 1, H2, W2)   # reference :272 (all ones at i == 4)
+                    ll_new, yh = self._dense_coefficients(ux, i, with_ll=(i == 4))
+                    if i == 4:
+                        yl = ll_new
+                    else:
+                        yh = yh * wavelet.reshape(B, 1, 1, H2, W2)   # reference :272 (all ones at i == 4)
                 xbuf = ux
 
             out[("wavelets", i - 1, "LL")] = yl
             out[("wavelets", i - 1, "LH")] = yh[:, :, 0]
             out[("wavelets", i - 1, "HL")] = yh[:, :, 1]
             out[("wavelets", i - 1, "HH")] = yh[:, :, 2]
-            yl, disp = ops.idwt_haar(yl, yh, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
+            if fused_idwt is not None:
+                yl, disp = fused_idwt
+            else:
+                yl, disp = ops.idwt_haar(yl, yh, disp_scale=1.0 / 2 ** (i - 1), clamp01=True)
             out[("disp", i - 1)] = disp
             static_ops[i] = scale_ops
             if i == 1:
