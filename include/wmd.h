@@ -137,10 +137,15 @@ typedef struct {
      * block tests its own tile's mask bytes and returns when there is none), outputs outside the mask are written as 0 and
      * tiles without active pixels are NOT touched (y must be zero-initialised); with in_mask [B,H,W] a padded input
      * position outside the mask reads 0 for x1 and x2 alike -- the mask test after the coordinate padding of
-     * sparse_conv3x3 (KITTI/layers.py:439-453).  No split-K in this mode; implemented by the Winograd kernels (needs
-     * wp_wino), the dense instantiations carry no mask code.                                                           */
+     * sparse_conv3x3 (KITTI/layers.py:439-453).  Split-K stays available (the reduce pass writes 0 outside out_mask and
+     * never reads the slots of a skipped tile); implemented by the Winograd kernels (needs wp_wino).
+     * in_mask_2x2 != 0 is the caller's promise that in_mask is constant on aligned 2x2 pixel blocks (it is the nearest
+     * upsampling of a half-resolution mask, as the decoders' upsample mask is: MaxPool5(upsample(m)) = upsample(MaxPool3(m)));
+     * with up1 = 2 it lets the upsampled operand keep the structured low-resolution path of conv_wino32_kernel (the mask
+     * of source pixel (y, x) is read at (2y, 2x)).  Without the promise a masked upsampled layer runs the generic gather.  */
     const uint8_t* in_mask;
     const uint8_t* out_mask;
+    int in_mask_2x2;
 } wmd_conv_args;
 
 /* Fused  upsample(x1) ++ x2  ->  pad  ->  conv kxk  ->  + bias  ->  activation.
@@ -316,6 +321,9 @@ typedef struct {
     const float* bias_ll; /* [1] or NULL */
     float scale_ll;
     float* yl_out;
+    /* optional [B,H,W] bytes: yh is zeroed where the mask is 0 before it is stored and synthesised (the wavelet mask of the
+     * sparse decoders' dense branch, depth_decoder.py:272)                                                              */
+    const uint8_t* yh_mask;
 } wmd_head_shiftsum_args;
 int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* args, void* stream);
 
@@ -341,6 +349,7 @@ typedef struct {
     float* disp;         /* optional [B,2H,2W] = clamp(out * disp_scale)                                      */
     float disp_scale;
     int clamp01;
+    const uint8_t* yh_mask; /* optional [B,H,W] bytes, see wmd_head_shiftsum_args.yh_mask                    */
 } wmd_head_level_args;
 int wmd_head_level_supported(int C);
 int wmd_head_level_fwd(const wmd_head_level_args* args, void* stream);
@@ -368,6 +377,9 @@ typedef struct {
     int up;          /* 1 or 2: nearest-upsample the input mask first (depth_decoder.py:311)       */
     int radius;      /* 0,1,2 ...: MaxPool2d(2r+1, stride 1, padding r) (:313-319)                 */
     uint8_t* out;    /* [h*up, w*up]                                                               */
+    int32_t* nnz;    /* optional: the number of set pixels of frame f is ADDED to nnz[f * nnz_stride] (the caller
+                        zero-initialises it) -- the pixel count of a mask without a compaction pass               */
+    int nnz_stride;
 } wmd_dilate_spec;
 /* All dilated variants of one mask in a single launch (n <= 8). */
 int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wmd_dilate_spec* specs, int n, void* stream);

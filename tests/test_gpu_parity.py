@@ -222,6 +222,60 @@ def test_conv_winograd_configurations(dev, case):
     assert tested >= 2
 
 
+@pytest.mark.skipif(os.environ.get("WMD_WINOGRAD", "1") == "0", reason="Winograd family switched off (WMD_WINOGRAD=0)")
+@pytest.mark.parametrize("up,C1,C2,pad", [(2, 32, 48, "reflect"), (1, 64, 0, "reflect"), (2, 16, 24, "zero"), (2, 20, 12, "replicate")])
+def test_conv_block_sparse_every_winograd_configuration(dev, up, C1, C2, pad):
+    """Block-sparse execution (wmd_conv_args.in_mask / out_mask, KITTI/layers.py:439-453 semantics) on every Winograd
+    configuration and split-K: input positions outside in_mask read 0 after the coordinate padding, outputs outside out_mask
+    are 0, tiles without an active pixel are not computed (out is zero-initialised).  The upsampled operand is masked through
+    a 2x2-constant mask (the decoders' upsample mask) with and without the in_mask_2x2 promise: conv_wino32_kernel's flattened
+    staging (channel counts that are multiples of its chunk) and the generic gather must agree with the oracle."""
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib, ops, tuner
+    B, Cout, H, W = 2, 40, 40, 72
+    gen = torch.Generator().manual_seed(11)
+    x1 = t(synth.normal((B, C1, H // up, W // up), "mx1", 5))
+    x2 = t(synth.normal((B, C2, H, W), "mx2", 5)) if C2 else None
+    w, b = [t(a) for a in synth.conv_params("mw", Cout, C1 + C2, 3, 5)]
+    coarse = (torch.rand((B, H // 2, W // 2), generator=gen) < 0.6)
+    coarse[:, :, : W // 4] &= torch.rand((B, H // 2, W // 4), generator=gen) < 0.2
+    in_mask = coarse.repeat_interleave(2, 1).repeat_interleave(2, 2)                  # constant on 2x2 blocks
+    out_mask = torch.rand((B, H, W), generator=gen) < 0.5
+    out_mask[:, :16, :32] = False                                                      # whole tiles without active pixels
+    out_mask[1, 24:, 40:] = False
+    xin = R.up2(x1) if up == 2 else x1
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    ref = torch.nn.functional.elu(R.conv3x3(xin * in_mask[:, None].float(), w, b, pad)) * out_mask[:, None].float()
+    wd, bd = w.to(dev), b.to(dev)
+    wp, ww = ops.pack_weights(wd), ops.pack_weights_wino(wd)
+    x1d, x2d = x1.to(dev), None if x2 is None else x2.to(dev)
+    im, om = in_mask.to(torch.uint8).to(dev).contiguous(), out_mask.to(torch.uint8).to(dev).contiguous()
+    l = _lib.lib()
+    tested = 0
+    for i, name in enumerate(tuner.config_names()):
+        if not name.startswith("conv_wino"):
+            continue
+        for promise in (1, 0):
+            for ks in (1, 2):
+                y = torch.zeros((B, Cout, H, W), device=dev)
+                a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=C2, Cout=Cout, ksize=3, pad_mode=ops.PAD[pad], act=ops.ACT["elu"],
+                                  slope=0.0, x1=x1d.data_ptr(), x2=None if x2d is None else x2d.data_ptr(), wp=wp.data_ptr(),
+                                  bias=bd.data_ptr(), y=y.data_ptr(), workspace=None, workspace_floats=0, tune_cfg=i + 1,
+                                  tune_ksplit=ks, wp_wino=ww.data_ptr(), in_mask=im.data_ptr(), out_mask=om.data_ptr(),
+                                  in_mask_2x2=promise)
+                n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
+                ws = torch.full((max(n, 1),), float("nan"), device=dev)     # a skipped tile's slots must never be read
+                a.workspace, a.workspace_floats = ws.data_ptr(), n
+                st = l.wmd_conv_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream)
+                if st == -3 and ks > 1:
+                    continue
+                _lib.check(st, name)
+                assert_close(y, ref, 5e-5, "%s ksplit %d promise %d" % (name, ks, promise))
+                tested += 1
+    assert tested >= 8
+
+
 def test_conv_rejects_bad_input(dev):
     from wavelet_monodepth_amd import ops, _lib
     w = torch.zeros(4, 3, 3, 3, device=dev)

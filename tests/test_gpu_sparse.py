@@ -156,12 +156,15 @@ def test_sparse_decoder_full_density_vs_reference_golden(dev, thr):
     _check(out, gold)
 
 
+@pytest.mark.parametrize("tiles", ["0", "1"], ids=["gather", "tiles"])
 @pytest.mark.parametrize("name,hw,seed,thr", [("64x64", (64, 64), 1, 0.05), ("64x64", (64, 64), 1, 0.1),
                                               ("96x160", (96, 160), 2, 0.15), ("96x160", (96, 160), 2, 0.2)])
-def test_sparse_decoder_vs_reference_golden_with_reference_masks(dev, name, hw, seed, thr):
+def test_sparse_decoder_vs_reference_golden_with_reference_masks(dev, name, hw, seed, thr, tiles, monkeypatch):
     """Feed the reference's own threshold masks (a pixel sitting exactly at the threshold may legitimately
     flip with fp32 rounding); everything downstream — dilations, compaction, gather-GEMMs, heads, IDWT, the five
-    mask families and the integer op model — must then match the reference exactly / to 1e-4."""
+    mask families and the integer op model — must then match the reference exactly / to 1e-4.  Both forms of the sparse
+    levels: gather-GEMMs over the pixel lists, and the block-sparse dense kernels + masked fused heads."""
+    monkeypatch.setenv("WMD_SPARSE_TILES", tiles)
     gold = load_golden("kitti_sparse_r18_%s_thr%g.npz" % (name, thr))
     feats = kitti_feats(2 if name == "64x64" else 1, hw[0], hw[1], seed=seed)
     force = {i: t(gold["wavelet_mask|%d" % (i - 1)])[0, 0, ::2, ::2] for i in (3, 2, 1)}
@@ -287,7 +290,7 @@ def test_nyu_sparse_decoder_vs_reference_golden_with_reference_masks(dev):
 
 
 @pytest.mark.parametrize("thr,forced", [(0.15, False), (0.05, True), (2.0, False)])
-def test_sparse_decoder_batched_equals_per_frame(dev, thr, forced):
+def test_sparse_decoder_batched_equals_per_frame(dev, thr, forced, monkeypatch):
     """Extension over the reference's batch-1 assert (depth_decoder.py:297): B frames decoded through the same launches,
     each with its own coefficient range, masks, pixel lists and counts.  Every per-frame output -- maps, the five mask
     families, the integer op model -- must equal the batch-1 decode of that frame; eager and from the replayed graph."""
@@ -301,7 +304,9 @@ def test_sparse_decoder_batched_equals_per_frame(dev, thr, forced):
         shapes = {3: (6, 10), 2: (12, 20), 1: (24, 40)}
         force_b = {i: (torch.rand((B,) + hw, generator=gen) < 0.25).to(torch.uint8).to(dev) for i, hw in shapes.items()}
         force_k = [{i: m[k].clone() for i, m in force_b.items()} for k in range(B)]
+    monkeypatch.setenv("WMD_SPARSE_TILES", "0")       # the per-frame references run the gather-GEMM form ...
     singles = [dict(sp(frames[k], thr, _force_masks=None if not forced else force_k[k]).items()) for k in range(B)]
+    monkeypatch.delenv("WMD_SPARSE_TILES")            # ... the batch the block-sparse dense kernels
     for graph in (False, True):
         sp.enable_graph(graph)
         for _ in range(2 if graph else 1):

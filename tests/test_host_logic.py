@@ -36,6 +36,17 @@ def test_kitti_sparse_op_model_from_reference_masks(name):
     assert total == int(gold["total_ops"])
 
 
+@pytest.mark.parametrize("name", ["64x64_thr0.05", "64x64_thr0.1", "96x160_thr0.15", "96x160_thr0.2"])
+def test_reference_upsample_mask_is_the_upsampled_lowres_mask(name):
+    """The block-sparse form of the second trunk convolution promises the kernel that its input mask is constant on 2x2
+    blocks (wmd_conv_args.in_mask_2x2): MaxPool2d(5)(upsample(m)) == upsample(MaxPool2d(3)(m)) (depth_decoder.py:311-316).
+    Checked on the masks the reference itself produced."""
+    gold = load_golden("kitti_sparse_r18_%s.npz" % name)
+    for s in range(4):
+        lo, up = gold["lowres_mask|%d" % s], gold["upsample_mask|%d" % s]
+        assert np.array_equal(lo.repeat(2, -2).repeat(2, -1), up), "scale %d" % s
+
+
 def test_kitti_sparse_op_model_full_size_known_answer():
     """R18 640x192 with every pixel active: the notebook's printed 3.560 G."""
     gold = {}

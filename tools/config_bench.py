@@ -61,6 +61,15 @@ if "sparse" in which:
         t = timeit(lambda: sp(feats, 0.05, _force_masks=force), n=10)
         print("sparse: injected density %.2f -> masks %.2f %.2f %.2f  total_ops %.3f G  %.3f ms  %.0f frames/s" % (
             p, dens[0], dens[1], dens[2], out["total_ops"] / 1e9, t * 1e3, 1 / t))
+    # contour masks: thin outlines of a smooth field (what depth discontinuities look like), per-level densities
+    for ps in ((0.10, 0.10, 0.10), (0.30, 0.10, 0.03), (0.10, 0.03, 0.01)):
+        force = {i: torch.from_numpy(synth.contour_mask(h, w, p, "contour", 3)).to(dev)
+                 for (i, (h, w)), p in zip(((3, (12, 40)), (2, (24, 80)), (1, (48, 160))), ps)}
+        out = sp(feats, 0.05, _force_masks=force)
+        dens = [float(out[("wavelet_mask", s)].float().mean()) for s in (2, 1, 0)]
+        t = timeit(lambda: sp(feats, 0.05, _force_masks=force), n=10)
+        print("sparse: contour masks, densities %.2f %.2f %.2f  total_ops %.3f G  %.3f ms  %.0f frames/s" % (
+            dens[0], dens[1], dens[2], out["total_ops"] / 1e9, t * 1e3, 1 / t))
 
 if "sparse-throughput" in which:
     # BASELINE config 4 as a THROUGHPUT question: a single 640x192 frame cannot fill 256 CUs (dense: ~25 dependent launches,
@@ -107,6 +116,13 @@ if "sparse-throughput" in which:
             t_s = timeit(lambda: sp(batch, 0.05, _force_masks=fb), n=20)
             print("throughput: sparse decoder, ONE batch of %d, injected density %.2f (mean total_ops %.3f G): %.3f ms  %.0f frames/s"
                   % (K, p, float(np.mean(out["total_ops"])) / 1e9, t_s * 1e3, K / t_s))
+        for ps in ((0.10, 0.10, 0.10), (0.30, 0.10, 0.03), (0.10, 0.03, 0.01)):
+            fb = {i: torch.from_numpy(np.stack([synth.contour_mask(h, w, p, "contour", 10 + k) for k in range(K)])).to(dev)
+                  for (i, (h, w)), p in zip(((3, (12, 40)), (2, (24, 80)), (1, (48, 160))), ps)}
+            out = sp(batch, 0.05, _force_masks=fb)
+            t_s = timeit(lambda: sp(batch, 0.05, _force_masks=fb), n=20)
+            print("throughput: sparse decoder, ONE batch of %d, contour masks of density %.2f %.2f %.2f (mean total_ops %.3f G): %.3f ms  %.0f frames/s"
+                  % (K, ps[0], ps[1], ps[2], float(np.mean(out["total_ops"])) / 1e9, t_s * 1e3, K / t_s))
         for thr in (0.05, 0.10, 0.15, 0.20):
             out = sp(batch, thr)
             t_s = timeit(lambda: sp(batch, thr), n=20)

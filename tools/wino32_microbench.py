@@ -29,6 +29,8 @@ ap.add_argument("--size", default="r18")
 ap.add_argument("--ksplits", default="1,2,4")
 ap.add_argument("--cfgs", default="", help="semicolon-separated template argument lists of the wino32 configurations to run (default: all)")
 ap.add_argument("--no-old", action="store_true", help="skip the sweep over the existing configurations")
+ap.add_argument("--mask-which", default="both", help="both | in | out")
+ap.add_argument("--mask", type=float, default=0.0, help="block-sparse mode: density of the i.i.d. coarse seed mask whose dilations are the in / out masks")
 args = ap.parse_args()
 LAYERS = R18 if args.size == "r18" else R50
 dev = torch.device("cuda:0")
@@ -71,7 +73,21 @@ for name in args.layers:
     wp, ww = ops.pack_weights(w), ops.pack_weights_wino(w)
     y = torch.empty(B, Cout, H, W, device=dev)
 
+    im = om = None
+    if args.mask > 0:
+        import torch.nn.functional as F
+        seed = (torch.rand(B, 1, H // 2, W // 2, device=dev) < args.mask).float()
+        im = F.interpolate(F.max_pool2d(seed, 3, 1, 1), scale_factor=2).to(torch.uint8).reshape(B, H, W).contiguous()   # 2x2-constant
+        om = F.max_pool2d(F.interpolate(seed, scale_factor=2), 3, 1, 1).to(torch.uint8).reshape(B, H, W).contiguous()
+        print("   masks: in %.2f out %.2f" % (float(im.float().mean()), float(om.float().mean())))
+
     def mk(cfg, ks):
+        if im is not None:
+            return _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=C2, Cout=Cout, ksize=3, pad_mode=ops.PAD["reflect"], act=ops.ACT["elu"],
+                                 slope=0.0, x1=x1.data_ptr(), x2=None if x2 is None else x2.data_ptr(), wp=wp.data_ptr(),
+                                 bias=b.data_ptr(), y=y.data_ptr(), workspace=None, workspace_floats=0, tune_cfg=cfg,
+                                 tune_ksplit=ks, wp_wino=ww.data_ptr(), in_mask=im.data_ptr() if args.mask_which != "out" else None,
+                                 out_mask=om.data_ptr() if args.mask_which != "in" else None, in_mask_2x2=1)
         return _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=C2, Cout=Cout, ksize=3, pad_mode=ops.PAD["reflect"], act=ops.ACT["elu"],
                              slope=0.0, x1=x1.data_ptr(), x2=None if x2 is None else x2.data_ptr(), wp=wp.data_ptr(),
                              bias=b.data_ptr(), y=y.data_ptr(), workspace=None, workspace_floats=0, tune_cfg=cfg,
@@ -79,9 +95,10 @@ for name in args.layers:
 
     fl = 2.0 * (C1 + C2) * 9 * Cout * B * H * W
     # reference output: a direct (non-Winograd) configuration chosen by the library's model
-    direct = [i + 1 for i, n in enumerate(names) if n.endswith(",9>")]
+    direct = [i + 1 for i, n in enumerate(names) if (n.startswith("conv_wino_kernel") if im is not None else n.endswith(",9>"))]
     ref = None
     for cfg in direct:
+        y.zero_()
         a = mk(cfg, 1)
         if run(a) == 0:
             torch.cuda.synchronize()
@@ -111,7 +128,7 @@ for name in args.layers:
         if args.cfgs and n.split("<")[1].rstrip(">") not in args.cfgs.split(";"):
             continue
         for ks in [int(k) for k in args.ksplits.split(",")]:
-            y.fill_(float("nan"))
+            y.fill_(0.0 if im is not None else float("nan"))
             a = mk(i + 1, ks)
             st = run(a)
             if st != 0:

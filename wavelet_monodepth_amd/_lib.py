@@ -23,7 +23,7 @@ class ConvArgs(C.Structure):
                 ("x1", C.c_void_p), ("x2", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
                 ("wp_wino", C.c_void_p), ("gate", C.c_void_p), ("gate_act", C.c_int), ("gate_slope", C.c_float),
-                ("in_mask", C.c_void_p), ("out_mask", C.c_void_p)]
+                ("in_mask", C.c_void_p), ("out_mask", C.c_void_p), ("in_mask_2x2", C.c_int)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -63,7 +63,7 @@ class HeadLevelArgs(C.Structure):
                 ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p),
                 ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
                 ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
-                ("clamp01", C.c_int)]
+                ("clamp01", C.c_int), ("yh_mask", C.c_void_p)]
 
 
 class EvalKittiArgs(C.Structure):
@@ -88,11 +88,12 @@ class HeadShiftsumArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pad_mode", C.c_int), ("scale", C.c_float),
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
                 ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
-                ("clamp01", C.c_int), ("bias_ll", C.c_void_p), ("scale_ll", C.c_float), ("yl_out", C.c_void_p)]
+                ("clamp01", C.c_int), ("bias_ll", C.c_void_p), ("scale_ll", C.c_float), ("yl_out", C.c_void_p),
+                ("yh_mask", C.c_void_p)]
 
 
 class DilateSpec(C.Structure):
-    _fields_ = [("up", C.c_int), ("radius", C.c_int), ("out", C.c_void_p)]
+    _fields_ = [("up", C.c_int), ("radius", C.c_int), ("out", C.c_void_p), ("nnz", C.c_void_p), ("nnz_stride", C.c_int)]
 
 
 class PackItem(C.Structure):

@@ -39,6 +39,7 @@ struct ConvKArgs {
     // layers.py:439-453) and outputs outside out_mask are written as 0
     const uint8_t* in_mask;
     const uint8_t* out_mask;
+    int in_mask_2x2;   // in_mask is constant on aligned 2x2 blocks (wmd_conv_args.in_mask_2x2)
     // out-channel slabs per pixel tile when the grid is 1-D (0: the slab is blockIdx.y -- the fused-head launches)
     int cob;
 };
@@ -89,9 +90,11 @@ struct W32Tile {
 };
 
 // conv_wino32_kernel's flattened-staging instantiation needs every chunk inside one source tensor, one full-resolution
-// geometry and no masks; everything else runs the GENERIC instantiation
+// geometry; an input mask must live on that geometry too (same-size x1, or an upsampled x1 under a 2x2-constant mask, whose
+// low-resolution patch reads the mask at (2y, 2x)); everything else runs the GENERIC instantiation
 inline bool wino32_pure(const ConvKArgs& a, int CK) {
-    return !a.in_mask && !a.out_mask && (a.Cin % CK) == 0 && (a.C2 == 0 || (a.C1 % CK) == 0) && (a.C2 == 0 || a.shift1 == 0);
+    const bool mask_ok = !a.in_mask || (a.up1 == 2 ? a.in_mask_2x2 != 0 : (a.shift1 == 0 && a.H1 == a.H && a.W1 == a.W));
+    return mask_ok && (a.Cin % CK) == 0 && (a.C2 == 0 || (a.C1 % CK) == 0) && (a.C2 == 0 || a.shift1 == 0);
 }
 
 template <int TH, int TW, int WN, int CK>

@@ -381,12 +381,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 // split-K second stage: y = act(bias + sum_s partial[s])
 __global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                           float* __restrict__ y, size_t n, size_t plane, int Cout, int ksplit,
-                                          int act, float slope, const float* __restrict__ gate, int gate_act, float gate_slope) {
+                                          int act, float slope, const float* __restrict__ gate, int gate_act, float gate_slope,
+                                          const uint8_t* __restrict__ out_mask) {
+    // out_mask [B,plane] (block-sparse execution): an inactive pixel is 0 -- its partial sums are never read (a skipped tile left
+    // its workspace slots unwritten).
     // the ksplit partial loads of an element are independent: issue them four at a time (a plain `v += partial[...]` loop
     // with a run-time trip count waits for every round trip in turn), summing in the fixed order s = 0 .. ksplit-1
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float v = 0.f;
         int s = 0;
+        if (out_mask && out_mask[i / (plane * Cout) * plane + i % plane] == 0) {
+            y[i] = 0.f;
+            continue;
+        }
         for (; s + 4 <= ksplit; s += 4) {
             const float p0 = partial[(size_t)s * n + i], p1 = partial[(size_t)(s + 1) * n + i];
             const float p2 = partial[(size_t)(s + 2) * n + i], p3 = partial[(size_t)(s + 3) * n + i];
@@ -480,7 +487,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_wino_kernel(const ConvKAr
             const int yy = y0 + i / TW, xx = x0 + i % TW;
             if (yy < H && xx < W) any |= a.out_mask[(size_t)b * H * W + (size_t)yy * W + xx];
         }
-        if (!__syncthreads_or(any)) return;
+        // a ballot per wave + flags in LDS (not __syncthreads_or: the device library's work-group reduction it pulls in
+        // slowed conv_wino32_kernel by 45 % -- even its launches without masks)
+        __shared__ int tile_flags[16];
+        const bool wave_any = __builtin_amdgcn_ballot_w64(any != 0) != 0;
+        if ((tid & 63) == 0) tile_flags[tid >> 6] = wave_any ? 1 : 0;
+        __syncthreads();
+        int all = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) all |= tile_flags[w];
+        if (__builtin_amdgcn_readfirstlane(all) == 0) return;
     }
 
     // ---- staging geometry (identical to conv_fwd_kernel: see the comments there) -------------------------------
@@ -930,7 +945,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * c.TAPS;   // MFMA work (Winograd: 16 positions x 16 tiles)
         for (int ks = 1; ks <= 32; ++ks) {
             if (force_ks > 0 ? ks != force_ks : (ks & (ks - 1)) != 0 || ks > 16) continue;  // model: powers of two
-            if (ks > 1 && (!have_ws || nchunks < ks || g->out_mask)) continue;   // block-sparse mode: one pass
+            if (ks > 1 && (!have_ws || nchunks < ks)) continue;
             const int cps = (nchunks + ks - 1) / ks;
             const int ks_eff = (nchunks + cps - 1) / cps;
             if (ks > 1 && (size_t)ks_eff * g->B * g->Cout * g->H * g->W > ws_floats) continue;
@@ -1277,6 +1292,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.gate_slope = g->gate_slope;
     a.in_mask = g->in_mask;
     a.out_mask = g->out_mask;
+    a.in_mask_2x2 = g->in_mask_2x2;
     if ((g->out_mask || g->in_mask) && !wino)
         return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: masks (block-sparse execution) need a 3x3 layer and the Winograd weight image (wp_wino)");
     const int cob = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
@@ -1312,7 +1328,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
         ProfScope prof("conv_splitk_reduce_kernel", (double)n * plan.ksplit, 4.0 * n * (plan.ksplit + 1), (hipStream_t)stream);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g->workspace,
                            g->bias, g->y, n, (size_t)g->H * g->W, g->Cout, plan.ksplit, g->act, g->slope, g->gate, g->gate_act,
-                           g->gate_slope);
+                           g->gate_slope, g->out_mask);
         st = check_launch("conv_splitk_reduce_kernel");
     }
     return st;

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     using T = W32Tile<TH, TW, WN, CK>;
     constexpr int NT = T::NT, PWS = T::PWS, PSF = T::PSF, PWL = T::PWL, PSL = T::PSL;
     constexpr int KW = T::KW, TXB = T::TXB;
-    constexpr bool MASKED = GENERIC;
-    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS + T::TAB_FLOATS];
+    constexpr bool MASKED = true;   // masks are tested in the prologue (input: folded into the gather offsets) and the epilogue only
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS + T::TAB_FLOATS + 16];   // + one tile-activity flag per wave
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -124,13 +124,26 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     const int y0 = ty * TH, x0 = tx * TW;
     const int ks = blockIdx.z;
     const int H = a.H, W = a.W;
-    if (MASKED && a.out_mask) {   // block-sparse: a tile without active output pixels keeps its zeros
+    // Block-sparse: a tile without active output pixels keeps its zeros.  It does not `return` here: an early exit ahead of
+    // the pipelined body costs the DENSE launches of this same instantiation 45 % (L14: 110 -> 160 us, A/B builds on one box;
+    // the epilogue's mask code costs nothing) -- the skipped block walks an empty chunk range and stores nothing instead
+    // (prologue + an epilogue over zeros: a few thousand cycles against ~50 k for a computed tile).
+    bool skip = false;
+    if (MASKED && a.out_mask) {
         int any = 0;
         for (int i = tid; i < TH * TW; i += NT) {
             const int yy = y0 + i / TW, xx = x0 + i % TW;
             if (yy < H && xx < W) any |= a.out_mask[(size_t)b * H * W + (size_t)yy * W + xx];
         }
-        if (!__syncthreads_or(any)) return;
+        // (a ballot per wave + flags in LDS; __syncthreads_or pulls in the device library's work-group reduction)
+        int* flags = reinterpret_cast<int*>(lds + T::LDS_FLOATS + T::TAB_FLOATS);
+        const bool wave_any = __builtin_amdgcn_ballot_w64(any != 0) != 0;
+        if (lane == 0) flags[wave] = wave_any ? 1 : 0;
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int w = 0; w < T::NW; ++w) all |= flags[w];
+        skip = __builtin_amdgcn_readfirstlane(all) == 0;
     }
     const bool upl = !GENERIC && a.up1 == 2;   // structured low-resolution path of the upsampled operand
 
@@ -203,14 +216,23 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             const unsigned e = tid + i * NT, ch = e / PSF, pos = e - __umul24(ch, PSF);
             const unsigned py = pos / PWS, px = pos - __umul24(py, PWS);
             const int r = tab[py], c = tab[PH + px];
-            obF[i] = (ch < CK && (r | c) >= 0) ? ch * pbs + (unsigned)(r + c) : kOOB;
+            bool ok = ch < CK && (r | c) >= 0;
+            // block-sparse input support: the full-resolution geometry is the mask's own (wino32_pure), so the folded pixel
+            // offset indexes it directly; a masked position gathers from the out-of-range offset like a zero-padded one
+            if (a.in_mask && ok) ok = a.in_mask[(size_t)b * plane2 + ((unsigned)(r + c) >> 2)] != 0;
+            obF[i] = ok ? ch * pbs + (unsigned)(r + c) : kOOB;
         }
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const unsigned e = tid + i * NT, ch = e / PSL, pos = e - __umul24(ch, PSL);
             const unsigned py = pos / PWL, px = pos - __umul24(py, PWL);
             const int r = tab[PH + PWS + py], c = tab[PH + PWS + PHL + px];
-            obL[i] = (ch < CK && (r | c) >= 0) ? ch * pb1 + (unsigned)(r + c) : kOOB;
+            bool ok = ch < CK && (r | c) >= 0;
+            if (a.in_mask && upl && ok) {   // 2x2-constant mask (wino32_pure): source pixel (sy, sx) is masked like (2sy, 2sx)
+                const unsigned sidx = (unsigned)(r + c) >> 2, sy = sidx / (unsigned)a.W1, sx = sidx - sy * (unsigned)a.W1;
+                ok = a.in_mask[(size_t)b * plane2 + (size_t)(2 * sy) * W + 2 * sx] != 0;
+            }
+            obL[i] = ok ? ch * pb1 + (unsigned)(r + c) : kOOB;
         }
     } else {
 #pragma unroll
@@ -287,7 +309,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     };
 
     const int c_begin = ks * a.chunks_per_split;
-    const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
+    const int c_end = skip ? c_begin : min(c_begin + a.chunks_per_split, a.nchunks);
     if (c_begin < c_end) {
         if (is_up(c_begin)) {
             static_for<NPB_L + T::NAV>([&](auto qc) { stage_up_piece(c_begin, lds, decltype(qc)::value); });
@@ -482,7 +504,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             for (int q = 0; q < 4; ++q) {
                 const int tfirst = wn * 32 + 8 * q + 4 * (lane >> 5);
                 const int oy = y0 + (tfirst / TXB) * 2 + HF, ox = x0 + (tfirst % TXB) * 2;
-                if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W) continue;
+                if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W || skip) continue;
                 float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
                 float o[8];
 #pragma unroll
@@ -490,11 +512,13 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
                     const float yv = keep[4 * q + (e >> 1)][e & 1];
                     o[e] = ACT < 0 ? yv : act_const<(ACT < 0 ? 0 : ACT)>(yv + bias_v, a.slope);
                 }
-                if (MASKED && a.out_mask) {
-                    const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W + ox;
+                if (MASKED && a.out_mask) {   // branch-free: clamped byte loads + selects (elements past W are never stored)
+                    const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W;
+                    uint8_t mv[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (ox + e < W && mp[e] == 0) o[e] = 0.f;
+                    for (int e = 0; e < 8; ++e) mv[e] = mp[min(ox + e, W - 1)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = mv[e] ? o[e] : 0.f;
                 }
                 if (vec_ok && ox + 7 < W) {
                     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);

@@ -327,6 +327,7 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
             }
             const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
             yh[co] = a.scale * a1 - a.scale * a2;
+            if (a.yh_mask && a.yh_mask[b * plane + (size_t)y * W + x] == 0) yh[co] = 0.f;
             a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
         }
         float l = 0.f;

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(NW * 64, 2) void head_level_kernel(const wmd_head_l
     for (int co = 0; co < 3; ++co) {
         const float a1 = 1.f / (1.f + expf(-hs[0][co])), a2 = 1.f / (1.f + expf(-hs[1][co]));
         yh[co] = a.scale * a1 - a.scale * a2;
+        if (a.yh_mask && a.yh_mask[(size_t)b * plane + (size_t)y * W + x] == 0) yh[co] = 0.f;
         a.yh[((size_t)b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
     }
     if (a.yl && a.out) {

@@ -15,6 +15,7 @@
 // Activations stay dense and zero-initialised; "not in the input mask => reads 0" is a mask test after the
 // coordinate padding, which is exactly what padding the index map does in the reference (layers.py:444).
 #include <algorithm>
+#include <cstring>
 #include "wmd_internal.h"
 
 namespace wmd {
@@ -61,119 +62,132 @@ __global__ void mask_threshold_kernel(const float* __restrict__ yh, const float*
     }
 }
 
-struct DilateKArgs {
-    wmd_dilate_spec s[8];
-};
-
-__global__ void mask_dilate_multi_kernel(const uint8_t* __restrict__ mask0, int h, int w, const DilateKArgs a) {
-    wmd_dilate_spec sp = a.s[blockIdx.y];
-    const int H = h * sp.up, W = w * sp.up, r = sp.radius;
-    const uint8_t* mask = mask0 + (size_t)blockIdx.z * h * w;   // blockIdx.z = frame of the batch
-    sp.out += (size_t)blockIdx.z * H * W;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
-        const int y = i / W, x = i % W;
-        uint8_t v = 0;
-        for (int dy = -r; dy <= r; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;  // MaxPool2d pads with -inf: out-of-range taps never win
-            for (int dx = -r; dx <= r; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= W) continue;
-                v |= mask[(yy / sp.up) * w + xx / sp.up];
-            }
-        }
-        sp.out[i] = v;
-    }
-}
-
-// minmax + threshold + every dilated variant of one level in ONE launch (the three steps above are a dependent chain of
-// tiny kernels at batch 1).  No grid synchronisation is needed: yl has only h*w values, so every block reduces min/max
-// itself (exact whatever the order), and a dilated pixel is the OR of the thresholded coefficients of the COARSE cells
-// its window covers -- the base mask is never read back.  Spec (1, 0) is the base mask itself.
+// One tiled kernel behind wmd_mask_dilate_multi and wmd_mask_level: a block owns a 16x16 cell tile of the COARSE grid, puts the
+// base mask of the tile + a 3-cell halo into LDS (FROM_MASK: copied from the given mask; else thresholded from the three
+// coefficient bands, one evaluation per cell) and writes every spec's pixels of its tile from there -- a dilated pixel is the
+// OR of the coarse cells its clamped window covers (out-of-range taps never win: MaxPool2d pads with -inf).  The untiled
+// forms re-evaluated up to 25 cells x 3 bands per output pixel and spec (2 M loads per 640x192 frame at the finest level:
+// 54 us per level at 12 frames).  Optional counts: the set pixels of a spec are added to spec.nnz[frame * nnz_stride] (one
+// atomic per wavefront and pass), which is all the block-sparse decoders need of a compaction.
+constexpr int ML_T = 16, ML_HALO = 3, ML_P = ML_T + 2 * ML_HALO;
 struct MaskLevelKArgs {
-    const float* mm;     // optional [B,2] precomputed (min, max) of every frame's yl: skips the in-block reduction
+    const float* mm;       // optional [B,2] precomputed (min, max) of every frame's yl: skips the in-block reduction
     const float* yl;
     const float* yh;
+    const uint8_t* mask0;  // FROM_MASK: the base mask [B,h,w]
     float ratio;
-    int n_yl, h, w;
+    int n_yl, h, w, n, tiles_x;
     wmd_dilate_spec s[8];
 };
 
-// NC = compile-time bound on the coarse cells one window spans per dimension (2r+1 without upsampling, r+1 with): the
-// loads of all NC*NC cells are unconditional (indices clamped into the window, which leaves the OR unchanged) and
-// independent, so they go out back to back instead of one memory round trip per cell.
+// One spec over one tile: a pixel's window covers coarse rows cy0..cy1 (at most NC) and columns cx0..cx1; the OR over the
+// window is the OR of the rows' bit words masked to the column range -- NC LDS words per pixel, no inner loops (a wave64
+// VALU instruction takes four cycles: the per-cell loop of the first tiled version spent 8 k cycles per wavefront).
 template <int NC>
-__device__ __forceinline__ void mask_level_body(const MaskLevelKArgs& a, const wmd_dilate_spec& sp, float thr) {
-    const int h = a.h, w = a.w, npix = h * w;
-    const int H = h * sp.up, W = w * sp.up, r = sp.radius;
-    const int sh = sp.up == 2 ? 1 : 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
-        const int y = i / W, x = i % W;
-        // out-of-range taps never win (MaxPool2d pads with -inf): clamp the window, then map it to coarse cells
-        const int cy0 = max(y - r, 0) >> sh, cy1 = min(y + r, H - 1) >> sh;
-        const int cx0 = max(x - r, 0) >> sh, cx1 = min(x + r, W - 1) >> sh;
-        float m[NC * NC];
+__device__ __forceinline__ int mask_tile_spec(const wmd_dilate_spec& sp, const unsigned* rows, int f, int h, int w, int ty0, int tx0) {
+    const int up = sp.up, r = sp.radius, sh = up == 2 ? 1 : 0;
+    const int H = h * up, W = w * up, lts = 4 + sh;     // log2 of the tile side in output pixels
+    uint8_t* out = sp.out + (size_t)f * H * W;
+    int cnt = 0;
+    for (int p = threadIdx.x; p < (1 << (2 * lts)); p += 256) {
+        const int y = ty0 * up + (p >> lts), x = tx0 * up + (p & ((1 << lts) - 1));
+        if (y < H && x < W) {
+            const int cy0 = (max(y - r, 0) >> sh) - ty0 + ML_HALO, cy1 = (min(y + r, H - 1) >> sh) - ty0 + ML_HALO;
+            const int cx0 = (max(x - r, 0) >> sh) - tx0 + ML_HALO, cx1 = (min(x + r, W - 1) >> sh) - tx0 + ML_HALO;
+            unsigned acc = 0;
 #pragma unroll
-        for (int p = 0; p < NC; ++p)
-#pragma unroll
-            for (int q = 0; q < NC; ++q) {
-                const int c = min(cy0 + p, cy1) * w + min(cx0 + q, cx1);
-                m[p * NC + q] = fmaxf(fmaxf(fabsf(a.yh[c]), fabsf(a.yh[npix + c])), fabsf(a.yh[2 * npix + c]));
-            }
-        uint8_t v = 0;
-#pragma unroll
-        for (int p = 0; p < NC * NC; ++p) v |= m[p] > thr ? 1 : 0;
-        sp.out[i] = v;
+            for (int k = 0; k < NC; ++k) acc |= rows[min(cy0 + k, cy1)];
+            const uint8_t v = ((acc >> cx0) & ((2u << (cx1 - cx0)) - 1u)) != 0;
+            out[(size_t)y * W + x] = v;
+            cnt += v;
+        }
     }
+    return cnt;
 }
 
-__global__ __launch_bounds__(256) void mask_level_kernel(MaskLevelKArgs a) {
-    // blockIdx.z = frame of the batch: its own LL plane, coefficients, range and masks
-    a.yl += (size_t)blockIdx.z * a.n_yl;
-    a.yh += (size_t)blockIdx.z * 3 * a.h * a.w;
-    float lo, hi;
-    if (a.mm) {          // batched decode: every block re-reducing its frame's whole LL plane was 40 us per level at 12 frames
-        lo = a.mm[2 * blockIdx.z];
-        hi = a.mm[2 * blockIdx.z + 1];
-    } else {
-        lo = INFINITY, hi = -INFINITY;
-        // eight independent loads per round (clamped index, the duplicate of the last element changes neither min nor max):
-        // a rolled one-load-per-iteration loop would be one memory round trip per 256 values
-        for (int i = threadIdx.x; i < a.n_yl; i += 256 * 8) {
-            float v[8];
+template <bool FROM_MASK>
+__global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a) {
+    // (`a` is never written: a modified by-value argument struct becomes a private copy, and the run-time index a.s[blockIdx.z]
+    // into a private copy is scratch memory -- every wavefront then waits for a scratch allocation at dispatch)
+    // blockIdx.y = frame of the batch: its own LL plane, coefficients, range and masks
+    const int f = blockIdx.y, h = a.h, w = a.w, npix = h * w;
+    const int ty0 = (blockIdx.x / a.tiles_x) * ML_T, tx0 = (blockIdx.x % a.tiles_x) * ML_T;
+    __shared__ unsigned rows[ML_P];
+    float thr = 0.f;
+    const float* yl = FROM_MASK ? nullptr : a.yl + (size_t)f * a.n_yl;
+    const float* yh = FROM_MASK ? nullptr : a.yh + (size_t)f * 3 * npix;
+    const uint8_t* mask0 = FROM_MASK ? a.mask0 + (size_t)f * npix : nullptr;
+    if constexpr (!FROM_MASK) {
+        float lo, hi;
+        if (a.mm) {          // batched decode: every block re-reducing its frame's whole LL plane was 40 us per level at 12 frames
+            lo = a.mm[2 * f];
+            hi = a.mm[2 * f + 1];
+        } else {
+            lo = INFINITY, hi = -INFINITY;
+            // eight independent loads per round (clamped index, the duplicate of the last element changes neither min nor max):
+            // a rolled one-load-per-iteration loop would be one memory round trip per 256 values
+            for (int i = threadIdx.x; i < a.n_yl; i += 256 * 8) {
+                float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = a.yl[min(i + k * 256, a.n_yl - 1)];
+                for (int k = 0; k < 8; ++k) v[k] = yl[min(i + k * 256, a.n_yl - 1)];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                lo = fminf(lo, v[k]);
-                hi = fmaxf(hi, v[k]);
+                for (int k = 0; k < 8; ++k) {
+                    lo = fminf(lo, v[k]);
+                    hi = fmaxf(hi, v[k]);
+                }
             }
-        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o));
-            hi = fmaxf(hi, __shfl_xor(hi, o));
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = fminf(lo, __shfl_xor(lo, o));
+                hi = fmaxf(hi, __shfl_xor(hi, o));
+            }
+            __shared__ float slo[4], shi[4];
+            if ((threadIdx.x & 63) == 0) {
+                slo[threadIdx.x >> 6] = lo;
+                shi[threadIdx.x >> 6] = hi;
+            }
+            __syncthreads();
+            lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+            hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
         }
-        __shared__ float slo[4], shi[4];
-        if ((threadIdx.x & 63) == 0) {
-            slo[threadIdx.x >> 6] = lo;
-            shi[threadIdx.x >> 6] = hi;
-        }
-        __syncthreads();
-        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
-        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+        thr = (hi - lo) * a.ratio;   // same fp32 expression as mask_threshold_kernel
     }
-    const float thr = (hi - lo) * a.ratio;   // same fp32 expression as mask_threshold_kernel
-
-    wmd_dilate_spec sp = a.s[blockIdx.y];
-    sp.out += (size_t)blockIdx.z * (a.h * sp.up) * (a.w * sp.up);
-    switch (sp.up == 2 ? sp.radius + 1 : 2 * sp.radius + 1) {
-        case 1: mask_level_body<1>(a, sp, thr); break;
-        case 2: mask_level_body<2>(a, sp, thr); break;
-        case 3: mask_level_body<3>(a, sp, thr); break;
-        case 4: mask_level_body<4>(a, sp, thr); break;
-        case 5: mask_level_body<5>(a, sp, thr); break;
-        default: mask_level_body<7>(a, sp, thr); break;
+    // the base tile as one bit row per coarse row (bit cx = cell (cy, cx) of the haloed tile)
+    if (threadIdx.x < ML_P) rows[threadIdx.x] = 0;
+    __syncthreads();
+    for (int c = threadIdx.x; c < ML_P * ML_P; c += 256) {
+        const int ry = c / ML_P, rx = c % ML_P;
+        const int cy = ty0 - ML_HALO + ry, cx = tx0 - ML_HALO + rx;
+        bool v = false;
+        if (cy >= 0 && cy < h && cx >= 0 && cx < w) {
+            const int p = cy * w + cx;
+            if constexpr (FROM_MASK) v = mask0[p] != 0;
+            else v = fmaxf(fmaxf(fabsf(yh[p]), fabsf(yh[npix + p])), fabsf(yh[2 * npix + p])) > thr;
+        }
+        if (v) atomicOr(&rows[ry], 1u << rx);
+    }
+    __syncthreads();
+    // blockIdx.z = spec: the specs of a tile run side by side (each block rebuilds the small base tile; at batch 1 a level
+    // has 3 to 30 tiles and the launch is a latency chain, not a throughput problem)
+    const wmd_dilate_spec sp = a.s[blockIdx.z];
+    int cnt = 0;
+    switch (sp.up == 2 ? sp.radius + 1 : 2 * sp.radius + 1) {   // coarse rows a window can span (clamped re-reads are harmless)
+        case 1: cnt = mask_tile_spec<1>(sp, rows, f, h, w, ty0, tx0); break;
+        case 2: cnt = mask_tile_spec<2>(sp, rows, f, h, w, ty0, tx0); break;
+        case 3: cnt = mask_tile_spec<3>(sp, rows, f, h, w, ty0, tx0); break;
+        case 4:
+        case 5: cnt = mask_tile_spec<5>(sp, rows, f, h, w, ty0, tx0); break;
+        default: cnt = mask_tile_spec<7>(sp, rows, f, h, w, ty0, tx0); break;
+    }
+    if (sp.nnz) {   // one atomic per block: a frame's blocks all add to the same word
+        __shared__ int blk_cnt;
+        if (threadIdx.x == 0) blk_cnt = 0;
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&blk_cnt, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_cnt) atomicAdd(sp.nnz + (size_t)f * sp.nnz_stride, blk_cnt);
     }
 }
 
@@ -524,21 +538,33 @@ extern "C" int wmd_mask_dilate_multi(const uint8_t* mask, int h, int w, const wm
     return wmd_mask_dilate_multi_b(mask, 1, h, w, specs, n, stream);
 }
 
+static int mask_specs_ok(const char* who, const wmd_dilate_spec* specs, int n, int* max_up) {
+    *max_up = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!specs[i].out || (specs[i].up != 1 && specs[i].up != 2) || specs[i].radius < 0 || specs[i].radius > 3)
+            return fail(WMD_ERR_BAD_ARG, "%s: spec %d (up=%d radius=%d)", who, i, specs[i].up, specs[i].radius);
+        *max_up = std::max(*max_up, specs[i].up);
+    }
+    return WMD_OK;
+}
+
 extern "C" int wmd_mask_dilate_multi_b(const uint8_t* mask, int B, int h, int w, const wmd_dilate_spec* specs, int n, void* stream) {
     if (!mask || !specs) return fail(WMD_ERR_BAD_ARG, "wmd_mask_dilate_multi: null pointer");
     if (B <= 0 || B > 65535 || h <= 0 || w <= 0 || n <= 0 || n > 8)
         return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_dilate_multi: B=%d h=%d w=%d n=%d", B, h, w, n);
-    DilateKArgs a;
-    int maxpix = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!specs[i].out || (specs[i].up != 1 && specs[i].up != 2) || specs[i].radius < 0 || specs[i].radius > 3)
-            return fail(WMD_ERR_BAD_ARG, "wmd_mask_dilate_multi: spec %d (up=%d radius=%d)", i, specs[i].up, specs[i].radius);
-        a.s[i] = specs[i];
-        maxpix = std::max(maxpix, h * specs[i].up * w * specs[i].up);
-    }
+    int up;
+    if (int st = mask_specs_ok("wmd_mask_dilate_multi", specs, n, &up)) return st;
+    MaskLevelKArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mask0 = mask;
+    a.h = h;
+    a.w = w;
+    a.n = n;
+    a.tiles_x = (w + ML_T - 1) / ML_T;
+    for (int i = 0; i < n; ++i) a.s[i] = specs[i];
+    const double maxpix = (double)h * up * w * up;
     ProfScope prof("mask_dilate_multi_kernel", 25.0 * maxpix * n * B, 2.0 * maxpix * n * B, (hipStream_t)stream);
-    hipLaunchKernelGGL(mask_dilate_multi_kernel, dim3(std::min((maxpix + 255) / 256, 1024), n, B), dim3(256), 0,
-                       (hipStream_t)stream, mask, h, w, a);
+    hipLaunchKernelGGL(mask_level_kernel<true>, dim3(a.tiles_x * ((h + ML_T - 1) / ML_T), B, n), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("mask_dilate_multi_kernel");
 }
 
@@ -553,8 +579,10 @@ extern "C" int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, f
     if (B <= 0 || B > 65535) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: B=%d", B);
     if (n_yl == 0 || n_yl > (size_t)1 << 24) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: n_yl=%zu", n_yl);
     if (h <= 0 || w <= 0 || n <= 0 || n > 8) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level: h=%d w=%d n=%d", h, w, n);
+    int up;
+    if (int st = mask_specs_ok("wmd_mask_level", specs, n, &up)) return st;
     MaskLevelKArgs a;
-    a.mm = nullptr;
+    memset(&a, 0, sizeof(a));
     if (B > 1 && minmax_scratch) {   // one min/max launch per batch instead of a whole-plane reduction in every block of every frame
         hipLaunchKernelGGL(minmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, yl, n_yl, minmax_scratch);
         a.mm = minmax_scratch;
@@ -565,15 +593,12 @@ extern "C" int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, f
     a.n_yl = (int)n_yl;
     a.h = h;
     a.w = w;
-    int maxpix = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!specs[i].out || (specs[i].up != 1 && specs[i].up != 2) || specs[i].radius < 0 || specs[i].radius > 3)
-            return fail(WMD_ERR_BAD_ARG, "wmd_mask_level: spec %d (up=%d radius=%d)", i, specs[i].up, specs[i].radius);
-        a.s[i] = specs[i];
-        maxpix = std::max(maxpix, h * specs[i].up * w * specs[i].up);
-    }
+    a.n = n;
+    a.tiles_x = (w + ML_T - 1) / ML_T;
+    for (int i = 0; i < n; ++i) a.s[i] = specs[i];
+    const double maxpix = (double)h * up * w * up;
     ProfScope prof("mask_level_kernel", 25.0 * maxpix * n * B, (2.0 * maxpix * n + 16.0 * h * w) * B, (hipStream_t)stream);
-    hipLaunchKernelGGL(mask_level_kernel, dim3(std::min((maxpix + 255) / 256, 1024), n, B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mask_level_kernel<false>, dim3(a.tiles_x * ((h + ML_T - 1) / ML_T), B, n), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("mask_level_kernel");
 }
 

@@ -98,6 +98,8 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self._graph_mode = False
         self._graphs = GraphCache()
+        self._side = None          # stream of the activation-pool fill
+        self._ones = {}            # all-ones mask constants of the coarsest level, per (device, B, h, w)
 
     # ------------------------------------------------------------------------------------------
     def _dense_coefficients(self, x, i, with_ll):
@@ -120,10 +122,11 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         return yl, yh.unsqueeze(1)
 
     def _block_sparse(self, B):
-        """Trunk convolutions of the sparse levels: gather-GEMM over compacted pixel lists (one frame: shortest dependent
-        chain) or block-sparse execution of the dense kernels (several frames: throughput).  WMD_SPARSE_TILES=0/1 forces."""
-        e = os.environ.get("WMD_SPARSE_TILES")
-        return (B >= 2) if e is None else e == "1"
+        """Form of the sparse levels.  Default: block-sparse execution of the dense Winograd kernels over the pixel TILES that
+        hold active pixels + the dense fused head kernels with the wavelet mask in their epilogue (batch 1: 0.30 ms against
+        0.33 ms, batch 12 at 10 % density: 0.75 ms against 1.18 ms).  WMD_SPARSE_TILES=0: gather-GEMMs over compacted pixel
+        lists, the literal form of KITTI/layers.py:337-507."""
+        return os.environ.get("WMD_SPARSE_TILES", "1") != "0"
 
     def enable_graph(self, on=True):
         """Capture the whole device-side chain (≈35 launches, all pixel counts stay on the device) into one hipGraph
@@ -155,6 +158,7 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
 
     def _device_chain(self, input_features, thresh_ratio, sparse_scales, _force_masks):
         out = {}
+        S._on_gpu(*input_features)      # fails loudly on CPU tensors: there is no fallback path
         x = input_features[-1].contiguous()
         dev = x.device
         B = x.shape[0]           # frames decoded together: every frame has its own range, masks, pixel lists and counts
@@ -166,15 +170,41 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         # every zero-initialised activation plane of the sparse levels comes out of ONE pooled buffer (one fill per
         # forward instead of four per level; at batch 1 the chain is launch-latency bound)
         pool_floats = 0
+        tiles = self._block_sparse(B)
+        fused_heads = {}       # level -> the level's heads run on the dense fused head kernels (tile mode, supported width)
         for i in sparse_scales:
             if 1 <= i <= 3:
                 hh, ww = input_features[i].shape[-2:]
                 c0w, c1w = self.convs[("upconv", i, 0)].conv.conv.weight, self.convs[("upconv", i, 1)].conv.conv.weight
                 cm = self.convs[("waveconv", i, 1)][0].conv.weight.shape[0]
-                pool_floats += sum(_round64(B * c * n) for c, n in ((c0w.shape[0], hh * ww), (c1w.shape[0], 4 * hh * ww),
-                                                                    (2 * cm, 4 * hh * ww), (3, 4 * hh * ww)))
-        pool = torch.zeros(pool_floats, device=dev) if pool_floats else None
-        pool_used = [0]
+                fused_heads[i] = tiles and int(c1w.shape[0]) in ops.FUSED_HEAD_WIDTHS
+                pool_floats += sum(_round64(B * c * n) for c, n in ((c0w.shape[0], hh * ww), (c1w.shape[0], 4 * hh * ww)) +
+                                   (() if fused_heads[i] else ((2 * cm, 4 * hh * ww), (3, 4 * hh * ww))))
+        n_sparse = len(fused_heads)
+        nnz_off = pool_floats
+        pool_floats += _round64(n_sparse * B * 3)       # the pixel counts of every sparse level share the fill (int32 zeros)
+        # ... filled on a side stream while the dense coarsest level runs when it is large (41 us at batch 12; at batch 1 the
+        # fill takes 9 us and so does the stream join); joined before the first sparse level takes its first plane
+        pool, pool_used, fill_stream = None, [0], [None]
+        if n_sparse:
+            pool = torch.empty(pool_floats, device=dev)
+            cur = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            if pool_floats * 4 >= (16 << 20):
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    pool.zero_()
+                if not torch.cuda.is_current_stream_capturing():
+                    pool.record_stream(self._side)
+                fill_stream[0] = self._side
+            else:                      # one frame: the join of a second stream costs as much as the fill itself
+                pool.zero_()
+
+        def join_fill():
+            if fill_stream[0] is not None:
+                torch.cuda.current_stream(dev).wait_stream(fill_stream[0])
+                fill_stream[0] = None
 
         def zeros(*shape):
             n = int(np.prod(shape))
@@ -182,15 +212,24 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             pool_used[0] += _round64(n)          # every plane set starts 256-byte aligned
             return v
 
+        all_nnz = pool[nnz_off:nnz_off + n_sparse * B * 3].view(torch.int32).view(n_sparse, B, 3) if n_sparse else None
+
         SPECS = [(1, 1), (1, 2), (2, 2), (2, 1), (2, 0)]   # lowres, upconv0, upsample, upconv1, wavelet (:311-319)
         for i in range(4, -1, -1):
             scale_ops = 0
             fused_idwt = None       # (next low-pass, disparity) when the level's head kernels already ran the synthesis
             h, w = x.shape[-2:] if xbuf is None else xbuf.shape[-2:]
             forced = _force_masks is not None and i in _force_masks
+            # a level whose heads run on the fused kernels needs no pixel lists: its three counts (upconv0, upconv1, wavelet:
+            # specs 1, 3, 4) are accumulated by the mask launch itself
+            counted = (all_nnz[len(counters)], [1, 3, 4]) if (i in sparse_scales and fused_heads.get(i)) else None
+            if i in sparse_scales:
+                join_fill()         # the counts and every activation plane of the sparse levels live in the pool
             if i == 4 and not forced:
-                # all-ones mask: every dilation of it is all ones too (MaxPool2d pads with -inf) -- one fill, five views
-                ones = torch.ones(B * (2 * h * w + 3 * 4 * h * w), device=dev, dtype=torch.uint8)
+                # all-ones mask: every dilation of it is all ones too (MaxPool2d pads with -inf) -- one constant, five views
+                ones = self._ones.get((dev, B, h, w))
+                if ones is None:
+                    ones = self._ones[(dev, B, h, w)] = torch.ones(B * (2 * h * w + 3 * 4 * h * w), device=dev, dtype=torch.uint8)
                 lowres, upconv0 = ones[:B * h * w].view(B, h, w), ones[B * h * w:2 * B * h * w].view(B, h, w)
                 o4 = 2 * B * h * w
                 upsample_m, upconv1, wavelet = (ones[o4 + k * 4 * B * h * w:o4 + (k + 1) * 4 * B * h * w].view(B, 2 * h, 2 * w)
@@ -199,13 +238,14 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 mask = _force_masks[i].to(dev).reshape(-1, h, w).to(torch.uint8)
                 if mask.shape[0] != B:           # one injected mask shared by every frame
                     mask = mask.expand(B, h, w)
-                lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask.contiguous(), SPECS)
+                lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(mask.contiguous(), SPECS, counts=counted)
             elif os.environ.get("WMD_SPARSE_UNFUSED_MASKS", "0") == "1" and B == 1:   # the three-launch form (parity tests)
                 mask = S.mask_threshold(yh, S.minmax(yl), thresh_ratio)
                 lowres, upconv0, upsample_m, upconv1, wavelet = [m.unsqueeze(0) for m in S.dilate_multi(mask, SPECS)]
+                counted = None
             else:
                 lowres, upconv0, upsample_m, upconv1, wavelet = [m.reshape(B, *m.shape[-2:]) for m in
-                                                                 S.mask_level(yl, yh, thresh_ratio, SPECS)]
+                                                                 S.mask_level(yl, yh, thresh_ratio, SPECS, counts=counted)]
             H2, W2 = 2 * h, 2 * w
             b = lambda m: m.view(torch.bool).reshape(B, 1, *m.shape[-2:])
             out[("lowres_mask", i - 1)] = b(lowres)
@@ -219,38 +259,53 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             if i in sparse_scales:
                 assert self.use_skips and i > 0 and yl is not None
                 scale_ops = level_static_ops(i, h, w, True)
-                (co0, co1, cow), nnz = S.compact_multi([upconv0, upconv1, wavelet])      # coords [B,npix], counts [B,3]
+                nnz = all_nnz[len(counters)]
+                if counted is None:     # pixel lists (gather-GEMM form) and / or counts by stream compaction
+                    (co0, co1, cow), nnz = S.compact_multi([upconv0, upconv1, wavelet], nnz_out=nnz)   # coords [B,npix], counts [B,3]
                 src = xbuf if xbuf is not None else x
                 C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
                 x0 = zeros(B, C0, h, w)
                 skip = input_features[i - 1].contiguous()
                 x1 = zeros(B, C1_, H2, W2)
-                if self._block_sparse(B):
+                if tiles:
                     # several frames: the trunk convolutions run on the dense Winograd / MFMA kernels over the pixel TILES
                     # that contain active pixels (tile list built on the device), input support and output mask folded
                     # into the patch gather / the epilogue -- same values as the gather-GEMM, dense-kernel throughput
                     ops._conv_fwd_raw(src, None, ops.pack_weights(c0.weight), c0.bias, C0, 3, "reflect", "elu", 0.0, 1,
                                       ops.pack_weights_wino(c0.weight), in_mask=lowres, out_mask=upconv0, out=x0)
                     ops._conv_fwd_raw(x0, skip, ops.pack_weights(c1.weight), c1.bias, C1_, 3, "reflect", "elu", 0.0, 2,
-                                      ops.pack_weights_wino(c1.weight), in_mask=upsample_m, out_mask=upconv1, out=x1)
+                                      ops.pack_weights_wino(c1.weight), in_mask=upsample_m, out_mask=upconv1, out=x1,
+                                      in_mask_2x2=True)   # MaxPool5(upsample(m)) = upsample(MaxPool3(m)): constant on 2x2 blocks
                 else:
                     S.sparse_conv(x0, src, ops.pack_weights(c0.weight), c0.bias, C0, 3, co0, nnz.data_ptr(), h * w,
                                   in_mask=lowres, pad="reflect", act="elu", nnz_stride=3)
                     S.sparse_conv(x1, x0, ops.pack_weights(c1.weight), c1.bias, C1_, 3, co1, nnz.data_ptr() + 4, H2 * W2,
                                   x2=skip, up1=2, in_mask=upsample_m, pad="reflect", act="elu", nnz_stride=3)
-                # heads: stacked 1x1 + LeakyReLU on the upconv1 support, dual 3x3 + sigmoid on the wavelet mask
                 hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
-                wstack, bstack = ops.stacked_pack([hp[0].conv.weight, hn[0].conv.weight], [hp[0].conv.bias, hn[0].conv.bias])
                 Cm = hp[0].conv.weight.shape[0]
-                mid = zeros(B, 2 * Cm, H2, W2)
-                S.sparse_conv(mid, x1, wstack, bstack, 2 * Cm, 1, co1, nnz.data_ptr() + 4, H2 * W2, act="leaky", slope=0.1,
-                              nnz_stride=3)
-                yh_d = zeros(B, 3, H2, W2)
-                S.sparse_conv(yh_d, mid, ops.pack_weights(hp[2].conv.weight), hp[2].conv.bias, 3, 3, cow,
-                              nnz.data_ptr() + 8, H2 * W2, in_mask=upconv1, pad="reflect", act="sigmoid",
-                              out_scale=2.0 ** (i - 1), c1=Cm, c1_off=0, wp2=ops.pack_weights(hn[2].conv.weight),
-                              bias2=hn[2].conv.bias, c1_off2=Cm, nnz_stride=3)
-                yh = yh_d.unsqueeze(1)
+                if tiles and C1_ in ops.FUSED_HEAD_WIDTHS:
+                    # heads of the tile mode: the dense fused head kernels (chained 1x1 -> tap-partial 3x3 -> sigmoid -> Haar
+                    # synthesis) with the wavelet mask applied to yh in their epilogue.  Same values as the gather form: every
+                    # 3x3 neighbour of a wavelet-mask pixel (reflection included) lies inside upconv1 = its radius-1 dilation,
+                    # where x1 holds the sparse activations, so the mid channels those taps read are the ones layers.py:405
+                    # computes; mid values outside the support are never read by a surviving output.
+                    unpack = lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias)
+                    yh, yl_next, disp_i = ops.head_fused_level_nograd(x1, unpack(hp), unpack(hn), scale=2.0 ** (i - 1), yl=yl,
+                                                                      disp_scale=1.0 / 2 ** (i - 1), clamp01=True,
+                                                                      yh_mask=wavelet.contiguous())
+                    fused_idwt = (yl_next, disp_i)
+                else:
+                    # heads: stacked 1x1 + LeakyReLU on the upconv1 support, dual 3x3 + sigmoid on the wavelet mask
+                    wstack, bstack = ops.stacked_pack([hp[0].conv.weight, hn[0].conv.weight], [hp[0].conv.bias, hn[0].conv.bias])
+                    mid = zeros(B, 2 * Cm, H2, W2)
+                    S.sparse_conv(mid, x1, wstack, bstack, 2 * Cm, 1, co1, nnz.data_ptr() + 4, H2 * W2, act="leaky", slope=0.1,
+                                  nnz_stride=3)
+                    yh_d = zeros(B, 3, H2, W2)
+                    S.sparse_conv(yh_d, mid, ops.pack_weights(hp[2].conv.weight), hp[2].conv.bias, 3, 3, cow,
+                                  nnz.data_ptr() + 8, H2 * W2, in_mask=upconv1, pad="reflect", act="sigmoid",
+                                  out_scale=2.0 ** (i - 1), c1=Cm, c1_off=0, wp2=ops.pack_weights(hn[2].conv.weight),
+                                  bias2=hn[2].conv.bias, c1_off2=Cm, nnz_stride=3)
+                    yh = yh_d.unsqueeze(1)
                 counters.append((i, nnz, (c0.weight.shape[1], C0), (c1.weight.shape[1], C1_),
                                  (hp[0].conv.weight.shape[1], Cm), (hp[2].conv.weight.shape[1], 3)))
                 xbuf = x1

@@ -193,9 +193,10 @@ def pack_weights_wino(weight, dgrad=False):
 # dense convolution
 # ---------------------------------------------------------------------------------------------
 
-def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None, in_mask=None, out_mask=None, out=None):
+def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None, in_mask=None, out_mask=None, out=None,
+                  in_mask_2x2=False):
     """in_mask / out_mask (uint8 [B,H,W]) + out (zero-initialised [B,cout,H,W]): block-sparse execution, see
-    wmd_conv_args.in_mask in include/wmd.h."""
+    wmd_conv_args.in_mask in include/wmd.h; in_mask_2x2: the caller's promise that in_mask is constant on 2x2 blocks."""
     l = _lib.lib()
     B, C1 = x1.shape[0], x1.shape[1]
     H, W = x1.shape[2] * up1, x1.shape[3] * up1
@@ -208,7 +209,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
     a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up1, C2=C2, Cout=cout, ksize=ksize, pad_mode=PAD[pad], act=ACT[act],
                       slope=float(slope), x1=ptr(x1), x2=ptr(x2), wp=ptr(wp), bias=ptr(bias), y=ptr(y),
                       workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_wino=ptr(wp_wino),
-                      in_mask=ptr(in_mask), out_mask=ptr(out_mask))
+                      in_mask=ptr(in_mask), out_mask=ptr(out_mask), in_mask_2x2=int(bool(in_mask_2x2)))
     stream = current_stream()
     keep = []
 
@@ -230,7 +231,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
         if wp_wino is None and ksize == 3:
             key += "|direct"   # a choice made with the Winograd configurations on offer must not be reused without them
         if out_mask is not None:
-            key += "|tiles"    # block-sparse: no split-K, small tiles skip more
+            key += "|tiles"    # block-sparse: small tiles skip more (timed on the masks of the first call)
         choice = tuner.lookup(key)
         if choice is None:
             if torch.cuda.is_current_stream_capturing():
@@ -736,17 +737,21 @@ _TWO_LAUNCH_HEAD = os.environ.get("WMD_TWO_LAUNCH_HEAD", "0") == "1"   # develop
 _LL_FOLD = os.environ.get("WMD_LL_FOLD", "1") != "0"                   # 0: the low-pass head on its own three launches
 
 
-def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False, head_ll=None, scale_ll=1.0):
+def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False, head_ll=None, scale_ll=1.0,
+                            yh_mask=None):
     """Inference form of one level's high-frequency heads + (optionally) the Haar IDWT in one launch (C = 32:
     wmd_head_level_fwd, every intermediate in LDS) or two: wmd_head_fused_fwd (1x1 -> LeakyReLU -> 27 tap-partials per
     side, intermediate stays on chip) and wmd_head_shiftsum_fwd (9-tap gather, bias, sigmoid, combine, IDWT).
     head_* = (w1, b1, w3, b3).  head_ll: the coarsest level's low-pass head (C -> C/4 -> 1, sigmoid * scale_ll); at C = 256
     it is a small third launch of the same fused kernel (tap-partials into planes 54..62 of the shared buffer) that the
     shift-sum completes and feeds to the synthesis as its low-pass input (yl must be None); other widths: own operators.
+    yh_mask (uint8 [B,H,W]): yh is zeroed outside it before the store and the synthesis (depth_decoder.py:272).
     Returns (yh [B,1,3,H,W], out or None, disp or None[, yl_ll [B,1,H,W] when head_ll is given])."""
     l = _lib.lib()
     x = _c(x)
     B, Cc, H, W = x.shape
+    if yh_mask is not None and (yh_mask.dtype != torch.uint8 or yh_mask.numel() != B * H * W or not yh_mask.is_contiguous()):
+        raise _lib.WmdError("head_fused_level_nograd: yh_mask must be a contiguous uint8 [B,H,W] tensor")
     (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
     one_launch = bool(l.wmd_head_level_supported(Cc)) and not _TWO_LAUNCH_HEAD
     yl_ll = None
@@ -772,7 +777,7 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
         a = _lib.HeadLevelArgs(B=B, H=H, W=W, C=Cc, pad_mode=PAD["reflect"], slope=0.1, scale=float(scale), x=ptr(x),
                                wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), bias_p=ptr(b3p), bias_n=ptr(b3n), yh=ptr(yh),
                                yl=ptr(yl), out=ptr(out), disp=ptr(disp), disp_scale=float(disp_scale or 1.0),
-                               clamp01=int(clamp01))
+                               clamp01=int(clamp01), yh_mask=ptr(yh_mask))
         check(l.wmd_head_level_fwd(C.byref(a), s), "wmd_head_level_fwd")
     else:
         planes = 81 if head_ll is not None else 54
@@ -790,7 +795,7 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
                                   bias_n=ptr(b3n), yh=ptr(yh), yl=ptr(yl), out=ptr(out), disp=ptr(disp),
                                   disp_scale=float(disp_scale or 1.0), clamp01=int(clamp01),
                                   bias_ll=ptr(b3l) if head_ll is not None else None, scale_ll=float(scale_ll),
-                                  yl_out=ptr(yl_ll) if head_ll is not None else None)
+                                  yl_out=ptr(yl_ll) if head_ll is not None else None, yh_mask=ptr(yh_mask))
         check(l.wmd_head_shiftsum_fwd(C.byref(g), s), "wmd_head_shiftsum_fwd")
     if yl_ll is not None:
         return yh.unsqueeze(1), out, disp, yl_ll

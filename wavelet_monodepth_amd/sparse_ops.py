@@ -37,45 +37,63 @@ def mask_threshold(yh, mm, thresh_ratio):
     return mask
 
 
-def dilate_multi(mask, specs):
+def _spec_array(specs, outs, counts):
+    """counts = (int32 tensor [B,k] (or [k]), zero-initialised by the caller; [spec index of column 0, of column 1, ...]): the
+    number of set pixels of those specs' masks is ADDED to the tensor by the same launch (wmd_dilate_spec.nnz)."""
+    col = {}
+    if counts is not None:
+        t, which = counts
+        if t.dtype != torch.int32 or not t.is_contiguous() or t.shape[-1] != len(which):
+            raise _lib.WmdError("mask counts: a contiguous int32 tensor with one column per counted spec")
+        col = {si: j for j, si in enumerate(which)}
+    return (_lib.DilateSpec * len(specs))(*[
+        _lib.DilateSpec(up, r, ptr(o), (counts[0].data_ptr() + 4 * col[i]) if i in col else None, len(col))
+        for i, ((up, r), o) in enumerate(zip(specs, outs))])
+
+
+def dilate_multi(mask, specs, counts=None):
     """mask uint8 [h,w] (or [B,h,w]: one mask per frame); specs = [(up, radius), ...] -> list of uint8 masks
-    [h*up, w*up] (or [B,h*up,w*up]), one launch."""
+    [h*up, w*up] (or [B,h*up,w*up]), one launch.  counts: see _spec_array."""
     _on_gpu(mask)
     batched = mask.dim() == 3
     B = mask.shape[0] if batched else 1
     h, w = mask.shape[-2:]
     mask = mask.contiguous()
     outs = [torch.empty(((B,) if batched else ()) + (h * up, w * up), device=mask.device, dtype=torch.uint8) for up, _ in specs]
-    arr = (_lib.DilateSpec * len(specs))(*[_lib.DilateSpec(up, r, ptr(o)) for (up, r), o in zip(specs, outs)])
+    arr = _spec_array(specs, outs, counts)
     check(_lib.lib().wmd_mask_dilate_multi_b(ptr(mask), B, h, w, arr, len(specs), current_stream()), "wmd_mask_dilate_multi")
     return outs
 
 
-def mask_level(yl, yh, thresh_ratio, specs):
+def mask_level(yl, yh, thresh_ratio, specs, counts=None):
     """minmax(yl) -> threshold(yh) -> every dilated variant, one launch (depth_decoder.py:308-319).
     specs = [(up, radius), ...]; (1, 0) is the thresholded mask itself.  Bit-identical to the three separate calls.
-    yh [B,1,3,h,w], yl [B,1,*,*]: B > 1 = one range / threshold / mask set per frame, outputs [B,h*up,w*up]."""
+    yh [B,1,3,h,w], yl [B,1,*,*]: B > 1 = one range / threshold / mask set per frame, outputs [B,h*up,w*up].
+    counts: see _spec_array."""
     _on_gpu(yl, yh)
     h, w = yh.shape[-2:]
     B = yh.shape[0] if yh.dim() == 5 else 1
     yl, yh = yl.contiguous(), yh.contiguous()
     outs = [torch.empty(((B,) if B > 1 else ()) + (h * up, w * up), device=yh.device, dtype=torch.uint8) for up, _ in specs]
-    arr = (_lib.DilateSpec * len(specs))(*[_lib.DilateSpec(up, r, ptr(o)) for (up, r), o in zip(specs, outs)])
+    arr = _spec_array(specs, outs, counts)
     mm = torch.empty((B, 2), device=yh.device, dtype=torch.float32) if B > 1 else None
     check(_lib.lib().wmd_mask_level_b(ptr(yl), yl.numel() // B, ptr(yh), float(thresh_ratio), B, h, w, arr, len(specs), ptr(mm),
                                       current_stream()), "wmd_mask_level")
     return outs
 
 
-def compact_multi(masks):
+def compact_multi(masks, nnz_out=None):
     """uint8 masks [h,w] (or [B,h,w]) -> (list of int32 coordinate lists [npix capacity] (or [B,npix]), int32 tensor of
-    counts [n] (or [B,n])) in one launch; raster order, counts stay on the device."""
+    counts [n] (or [B,n])) in one launch; raster order, counts stay on the device.  nnz_out: a contiguous int32 tensor of that
+    shape to receive the counts (callers that collect the counts of several calls in one buffer)."""
     _on_gpu(*masks)
     n = len(masks)
     batched = masks[0].dim() == 3
     B = masks[0].shape[0] if batched else 1
     masks = [m.contiguous() for m in masks]
-    nnz = torch.empty((B, n) if batched else (n,), device=masks[0].device, dtype=torch.int32)
+    nnz = nnz_out if nnz_out is not None else torch.empty((B, n) if batched else (n,), device=masks[0].device, dtype=torch.int32)
+    if nnz.dtype != torch.int32 or not nnz.is_contiguous() or nnz.numel() != B * n:
+        raise _lib.WmdError("compact_multi: nnz_out must be a contiguous int32 tensor of %d elements" % (B * n))
     coords = [torch.empty((B, m.numel() // B) if batched else (m.numel(),), device=m.device, dtype=torch.int32) for m in masks]
     arr = (_lib.CompactSpec * n)(*[_lib.CompactSpec(ptr(m), m.numel() // B, ptr(c), nnz.data_ptr() + 4 * i)
                                    for i, (m, c) in enumerate(zip(masks, coords))])
@@ -186,7 +204,15 @@ def counts_to_host(count_tensors):
     import torch
     if not count_tensors:
         return lambda: []
-    flat = torch.cat([c.reshape(-1) for c in count_tensors])
+    first = count_tensors[0]
+    expect, adjacent = first.data_ptr(), True
+    for c in count_tensors:          # views that tile one buffer in order: copy the buffer, no gather launch
+        adjacent = adjacent and c.is_contiguous() and c.data_ptr() == expect and c.dtype == first.dtype
+        expect += c.numel() * c.element_size()
+    if adjacent and len(count_tensors) > 1:
+        flat = torch.as_strided(first, (sum(c.numel() for c in count_tensors),), (1,), first.storage_offset())
+    else:
+        flat = torch.cat([c.reshape(-1) for c in count_tensors])
     host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
     host.copy_(flat, non_blocking=True)
     ev = torch.cuda.Event()

@@ -81,3 +81,19 @@ def encoder_features(batch, height, width, num_ch_enc, seed=0, dist="normal"):
         else:
             feats.append(uniform(shape, "feat%d" % k, seed))
     return feats
+
+
+def contour_mask(h, w, density, name="contour", seed=0):
+    """uint8 [h,w] mask of thin level-set contours of a smooth random field covering ~`density` of the grid: the shape the
+    decoders' wavelet masks have on photographs (depth discontinuities along object outlines), as opposed to i.i.d. pixels
+    (`uniform(...) < density`), whose dilations cover almost everything.  The same (name, seed) at another resolution samples
+    the same field, so the masks of successive decoder levels trace the same outlines."""
+    ph = uniform((6, 4), name, seed, 0.0, 1.0).astype(np.float64)
+    ys = (np.arange(h, dtype=np.float64) + 0.5) / h
+    xs = (np.arange(w, dtype=np.float64) + 0.5) / h          # same units as ys: the field is isotropic
+    f = np.zeros((h, w), dtype=np.float64)
+    for a, fy, fx, p in ph:
+        f += (0.5 + a) * np.sin(2 * np.pi * ((fy - 0.5) * 1.6 * ys[:, None] + (fx - 0.5) * 1.6 * xs[None, :] + p))
+    d = np.abs(f - np.median(f))
+    eps = np.quantile(d, min(max(float(density), 0.0), 1.0))
+    return (d <= eps).astype(np.uint8)
