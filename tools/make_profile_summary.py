@@ -90,6 +90,7 @@ for f in glob.glob(os.path.join(src, "train_profile_*.txt")):
     shutil.copy(f, os.path.join(P, tag + "_" + os.path.basename(f)))
 copy("sparse_workloads.txt", tag + "_sparse_workloads.txt")
 copy("sparse_profile_thr0.15.txt", tag + "_sparse_profile_thr0.15.txt")
+copy("sparse_timelines.txt", tag + "_sparse_timelines.txt")
 copy("gpu_tests.txt", tag + "_gpu_tests.txt")
 method = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc <SQ counters> GRBM_GUI_ACTIVE in separate passes (tools/profile_session.sh); "
           "per-launch averages; HBM-side bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE reports half of the fetched bytes on gfx950)")

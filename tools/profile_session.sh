@@ -36,8 +36,11 @@ bwd)   # WMD_TUNE_CACHE: the first run tunes and stores its choices, the counter
     pmc_passes bwd python $REPO/tools/train_profile.py
     unset WMD_TUNE_CACHE ;;
 sparse)
-    python tools/config_bench.py sparse > $OUT/sparse_workloads.txt 2>&1
-    tail -n 30 $OUT/sparse_workloads.txt
+    python tools/config_bench.py sparse sparse-throughput > $OUT/sparse_workloads.txt 2>&1
+    grep "sparse\|throughput" $OUT/sparse_workloads.txt | tail -n 50
+    bash tools/sparse_timeline_session.sh > $OUT/sparse_timelines.txt 2>&1      # one graph replay each, kernel by kernel
+    for f in dense_b1 sparse_b1_tiles sparse_b1_gather dense_b12 sparse_b12_d0.1 sparse_b12_contour; do
+        echo "==== $f" >> $OUT/sparse_timelines.txt; cat gpurun_out/tl/$f.txt >> $OUT/sparse_timelines.txt; done
     export WMD_TUNE_CACHE=$OUT/sparse_tune_cache.json
     python tools/sparse_profile.py 0.15 > $OUT/sparse_profile_thr0.15.txt 2>&1
     pmc_passes sparse python $REPO/tools/sparse_profile.py 0.15
