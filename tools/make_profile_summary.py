@@ -27,8 +27,8 @@ def short(name):
     if not m:
         return name[:80]
     args = (m.group(2) or "").replace(" ", "")
-    args = re.sub(r",false(,2)?>$", ">", args)      # dense / pure instantiations; NBUF = 2 default of conv_fwd_kernel
-    args = args.replace(",false,2>", ">")
+    args = args.replace(",false,2>", ">")                  # dense instantiation, NBUF = 2 default of conv_fwd_kernel
+    args = re.sub(r"(,false)+>$", ">", args)               # dense / pure-and-dense instantiations
     return m.group(1) + args
 
 

@@ -92,12 +92,15 @@ __device__ __forceinline__ float act_const(float v, float slope) {
 //   the structured low-resolution path.
 // GENERIC = true: ragged channel counts, chunks that straddle the concat boundary, block-sparse masks (in_mask / out_mask of
 //   the sparse decoders): per-channel pieces with a per-piece source choice, upsampling through the >>1 gather.
-template <int TH, int TW, int WN, int CK, bool GENERIC>
+// MASKED: the instantiation carries the block-sparse mask code (always with GENERIC; the flattened staging has a dense and a
+// masked instantiation -- the mask code in the epilogue cost the dense launches 2-3 % when they shared one).
+template <int TH, int TW, int WN, int CK, bool GENERIC, bool MASKED>
 __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArgs a) {
     using T = W32Tile<TH, TW, WN, CK>;
     constexpr int NT = T::NT, PWS = T::PWS, PSF = T::PSF, PWL = T::PWL, PSL = T::PSL;
     constexpr int KW = T::KW, TXB = T::TXB;
-    constexpr bool MASKED = true;   // masks are tested in the prologue (input: folded into the gather offsets) and the epilogue only
+    static_assert(MASKED || !GENERIC, "the generic instantiation carries the mask code");
+    // masks are tested in the prologue (input: folded into the gather offsets) and the epilogue only
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS + T::TAB_FLOATS + 16];   // + one tile-activity flag per wave
 
     const int tid = threadIdx.x;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             bool ok = ch < CK && (r | c) >= 0;
             // block-sparse input support: the full-resolution geometry is the mask's own (wino32_pure), so the folded pixel
             // offset indexes it directly; a masked position gathers from the out-of-range offset like a zero-padded one
-            if (a.in_mask && ok) ok = a.in_mask[(size_t)b * plane2 + ((unsigned)(r + c) >> 2)] != 0;
+            if (MASKED && a.in_mask && ok) ok = a.in_mask[(size_t)b * plane2 + ((unsigned)(r + c) >> 2)] != 0;
             obF[i] = ok ? ch * pbs + (unsigned)(r + c) : kOOB;
         }
 #pragma unroll
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             const unsigned py = pos / PWL, px = pos - __umul24(py, PWL);
             const int r = tab[PH + PWS + py], c = tab[PH + PWS + PHL + px];
             bool ok = ch < CK && (r | c) >= 0;
-            if (a.in_mask && upl && ok) {   // 2x2-constant mask (wino32_pure): source pixel (sy, sx) is masked like (2sy, 2sx)
+            if (MASKED && a.in_mask && upl && ok) {   // 2x2-constant mask (wino32_pure): source pixel (sy, sx) is masked like (2sy, 2sx)
                 const unsigned sidx = (unsigned)(r + c) >> 2, sy = sidx / (unsigned)a.W1, sx = sidx - sy * (unsigned)a.W1;
                 ok = a.in_mask[(size_t)b * plane2 + (size_t)(2 * sy) * W + 2 * sx] != 0;
             }
@@ -543,8 +546,10 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 // ---- launchers (the configuration table lives in wmd_conv_fwd.hip) -----------------------------------------------
 template <int TH, int TW, int WN, int CK>
 void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s) {
-    if (wino32_pure(a, CK)) hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, false>), grid, dim3(WN * 128), 0, s, a);
-    else hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, true>), grid, dim3(WN * 128), 0, s, a);
+    const bool masked = a.in_mask || a.out_mask;
+    if (!wino32_pure(a, CK)) hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, true, true>), grid, dim3(WN * 128), 0, s, a);
+    else if (masked) hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, false, true>), grid, dim3(WN * 128), 0, s, a);
+    else hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, false, false>), grid, dim3(WN * 128), 0, s, a);
 }
 
 #define WMD_W32_INST(TH, TW, WN, CK) template void launch_wino32<TH, TW, WN, CK>(const ConvKArgs&, dim3, hipStream_t);
