@@ -354,6 +354,39 @@ typedef struct {
 int wmd_head_level_supported(int C);
 int wmd_head_level_fwd(const wmd_head_level_args* args, void* stream);
 
+/* Backward of the 3x3 stage of a level's wavelet heads (training): the 2-3 heads Conv3x3(C, 3 | 1) + sigmoid of a level
+ * (depth_decoder.py:104-136; backward from torch.autograd, KITTI/trainer.py:211) given the pre-sigmoid gradients dy3
+ * [B,n_out,H,W] (rows [LL], +, -) and the LeakyReLU outputs mid [B,Ct,H,W] of the stacked 1x1 stage:
+ *   dzmid = act'(mid) * conv3x3^T(dy3)  (the 1x1 stage's pre-activation gradient),  dw3 / db3 per head.
+ * One pass each over mid for the data and the weight gradient, no padded-domain buffer (wmd_head_bwd.hip).  At most 24
+ * 64-channel slices over all heads (WMD_ERR_UNSUPPORTED beyond: use wmd_conv_dgrad / wmd_conv_wgrad on the stacked filter). */
+typedef struct {
+    int row0;          /* first plane of dy3 that belongs to this head                   */
+    int nrows;         /* its output channels: 3 (high-frequency heads) or 1 (low-pass)  */
+    int ch0;           /* first channel of mid that belongs to this head                 */
+    int nch;           /* its channel count                                              */
+    const float* w3;   /* [nrows, nch, 3, 3]                                             */
+    float* dw3;        /* [nrows, nch, 3, 3]                                             */
+    float* db3;        /* [nrows]                                                        */
+} wmd_head_bwd_head;
+typedef struct {
+    int B, H, W;
+    int Ct;            /* channels of mid                                                */
+    int n_out;         /* planes of dy3                                                  */
+    int pad_mode;      /* padding of the 3x3 (reflect for the KITTI heads)               */
+    int act;           /* activation that produced mid: WMD_ACT_LEAKY (or NONE / ELU)    */
+    float slope;
+    const float* dy3;  /* [B,n_out,H,W]                                                  */
+    const float* mid;  /* [B,Ct,H,W]                                                     */
+    float* dzmid;      /* [B,Ct,H,W]; channels of no head are not written                */
+    int n_heads;       /* 1..3                                                           */
+    wmd_head_bwd_head head[3];
+    float* workspace;  /* wmd_head3x3_bwd_workspace_floats(args) floats                  */
+    size_t workspace_floats;
+} wmd_head3x3_bwd_args;
+size_t wmd_head3x3_bwd_workspace_floats(const wmd_head3x3_bwd_args* args);
+int wmd_head3x3_bwd(const wmd_head3x3_bwd_args* args, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Sparse (threshold-gated) decoder path, batch 1
  *

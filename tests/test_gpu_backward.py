@@ -373,6 +373,44 @@ def test_stacked_heads_equal_per_head_operators_and_the_oracle(dev):
     assert none is None and float((yh2 - yh).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("C,H,W,B,with_ll", [(32, 9, 21, 2, False), (64, 2, 5, 1, True), (16, 3, 2, 3, False), (80, 7, 66, 1, False), (128, 5, 9, 1, True),
+                                             (256, 6, 20, 2, True)])
+def test_head3x3_backward_kernels_vs_oracle_and_generic_path(dev, C, H, W, B, with_ll, monkeypatch):
+    """wmd_head3x3_bwd (tap-partial rows gathered from dy, one pass over mid for the data and one for the weight gradient,
+    reflection ring folded analytically) against autograd through the oracle and against the generic dgrad / wgrad kernels on
+    the block-diagonal filter: odd sizes, maps of 2 rows / 2 columns (both ring rows fold onto the same source row), channel
+    counts that are not multiples of 16 or 64, more pixels than one wave tile, with and without the low-pass head."""
+    from wavelet_monodepth_amd import ops
+    x = t(synth.normal((B, C, H, W), "hbx", 5))
+    mk = lambda tag, mid, out: [t(a) for a in synth.conv_params(tag + "1", mid, C, 1, 5)] + [t(a) for a in synth.conv_params(tag + "3", out, mid, 3, 5)]
+    hp, hn = mk("hbp", C, 3), mk("hbn", C, 3)
+    hl = mk("hbl", max(C // 4, 1), 1) if with_ll else []
+    gyh, gyl = t(synth.normal((B, 3, H, W), "hbgy", 5)), t(synth.normal((B, 1, H, W), "hbgl", 5))
+    lk = lambda v: torch.nn.functional.leaky_relu(v, 0.1)
+    sig = lambda xx, h: torch.sigmoid(R.conv3x3(lk(R.conv1x1(xx, h[0], h[1])), h[2], h[3], "reflect"))
+    leaves = [x] + hp + hn + hl
+    ref = [v.clone().requires_grad_(True) for v in leaves]
+    loss = (2.0 * (sig(ref[0], ref[1:5]) - sig(ref[0], ref[5:9])) * gyh).sum()
+    if with_ll:
+        loss = loss + (8.0 * sig(ref[0], ref[9:13]) * gyl).sum()
+    loss.backward()
+    got = {}
+    monkeypatch.setattr(ops, "_HEAD_BWD_MIN_PIXELS", 0)      # the size rule would send these small maps to the generic kernels
+    for new_path in (True, False):
+        monkeypatch.setattr(ops, "_HEAD_BWD", new_path)
+        d = [v.to(dev).requires_grad_(True) for v in leaves]
+        yh, yl = ops.stacked_heads(d[0], d[1:5], d[5:9], 2.0, head_ll=d[9:13] if with_ll else None, scale_ll=8.0)
+        out = (yh * gyh.to(dev)).sum()
+        if with_ll:
+            out = out + (yl * gyl.to(dev)).sum()
+        out.backward()
+        got[new_path] = [v.grad for v in d]
+        for a_, b_, k in zip(d, ref, range(len(ref))):
+            assert_close(a_.grad, b_.grad, GRAD_TOL, "head backward (own kernels: %s): leaf %d" % (new_path, k))
+    for a_, b_, k in zip(got[True], got[False], range(len(ref))):
+        assert_close(a_, b_.cpu(), GRAD_TOL, "own kernels vs generic path: leaf %d" % k)
+
+
 def test_kitti_decoder_per_head_training_path_still_matches_reference_gradients(dev):
     """dec.stack_heads = False keeps the round-1 per-head operators (with the new gating); same reference gradients."""
     from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder

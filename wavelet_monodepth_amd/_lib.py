@@ -66,6 +66,17 @@ class HeadLevelArgs(C.Structure):
                 ("clamp01", C.c_int), ("yh_mask", C.c_void_p)]
 
 
+class HeadBwdHead(C.Structure):
+    _fields_ = [("row0", C.c_int), ("nrows", C.c_int), ("ch0", C.c_int), ("nch", C.c_int), ("w3", C.c_void_p),
+                ("dw3", C.c_void_p), ("db3", C.c_void_p)]
+
+
+class Head3x3BwdArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Ct", C.c_int), ("n_out", C.c_int), ("pad_mode", C.c_int),
+                ("act", C.c_int), ("slope", C.c_float), ("dy3", C.c_void_p), ("mid", C.c_void_p), ("dzmid", C.c_void_p),
+                ("n_heads", C.c_int), ("head", HeadBwdHead * 3), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+
+
 class EvalKittiArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("h", C.c_int), ("w", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("min_depth", C.c_float), ("max_depth", C.c_float), ("mask_mode", C.c_int), ("pred_scale", C.c_float),
@@ -151,6 +162,8 @@ SIGNATURES = {
     "wmd_head_shiftsum_fwd": (C.c_int, [C.POINTER(HeadShiftsumArgs), C.c_void_p]),
     "wmd_head_level_supported": (C.c_int, [C.c_int]),
     "wmd_head_level_fwd": (C.c_int, [C.POINTER(HeadLevelArgs), C.c_void_p]),
+    "wmd_head3x3_bwd_workspace_floats": (C.c_size_t, [C.POINTER(Head3x3BwdArgs)]),
+    "wmd_head3x3_bwd": (C.c_int, [C.POINTER(Head3x3BwdArgs), C.c_void_p]),
     "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),

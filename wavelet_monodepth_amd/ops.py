@@ -583,29 +583,57 @@ class _StackedHeadsFn(torch.autograd.Function):
         for k in order:
             rows[k] = r
             r += heads[k][2].shape[0]
-        # block-diagonal 3x3 filter [n_out, Ct, 3, 3] and stacked 1x1 filter [Ct, C, 1, 1]
-        w3bd = torch.zeros((n_out, Ct, 3, 3), device=dev, dtype=torch.float32)
-        for k in order:
-            w3 = heads[k][2].detach()
-            w3bd[rows[k]:rows[k] + w3.shape[0], offs[k]:offs[k] + w3.shape[1]] = w3
         w1s = torch.cat([heads[k][0].detach() for k in order], 0)
-        # 3x3: weight gradient of the stacked filter (diagonal blocks are the heads' gradients) ...
-        dw3f = torch.empty_like(w3bd)
-        db3f = torch.empty(n_out, device=dev, dtype=torch.float32)
-        a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=Ct, up1=1, C2=0, Cout=n_out, ksize=3, pad_mode=PAD["reflect"], x1=ptr(mid), x2=None,
-                               dz=ptr(dy3), dw=ptr(dw3f), dbias=ptr(db3f), workspace=None, workspace_floats=0, tune_cfg=0,
-                               tune_nsplit=0)
-        _wgrad_launch(a, dev)
-        # ... and data gradient, gated by LeakyReLU'(mid): dzmid
-        dzmid = torch.empty_like(mid)
-        # the three weight images of this backward (3x3 data gradient direct + Winograd, 1x1 data gradient) in one launch
         want_dx = ctx.needs_input_grad[0]
-        imgs = pack_many([(w3bd, ("dgrad", "wino_dgrad") if _WINOGRAD else ("dgrad",))] + ([(w1s, ("dgrad",))] if want_dx else []))
-        wpd, wpdw = imgs[0]["dgrad"], imgs[0].get("wino_dgrad")
-        a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=Ct, up1=1, C2=0, Cout=n_out, ksize=3, pad_mode=PAD["reflect"], dz=ptr(dy3),
-                               wp_dgrad=ptr(wpd), dx1=ptr(dzmid), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
-                               tune_ksplit=0, wp_dgrad_wino=ptr(wpdw), x1_fwd=ptr(mid), x1_act=ACT["leaky"], x1_slope=0.1)
-        _dgrad_launch(a, dev, 9)
+        dzmid = torch.empty_like(mid)
+        nsl = sum((heads[k][2].shape[1] + 63) // 64 for k in order)
+        # (worth it where a level has pixels to spread: >= 256 wave tiles; the coarsest level stays on the generic kernels, which
+        # split its few pixels over channels instead -- tools/head_bwd_microbench.py)
+        if _HEAD_BWD and nsl <= 24 and B * H * W >= _HEAD_BWD_MIN_PIXELS and all(heads[k][2].shape[0] in (1, 3) for k in order):
+            # the 3x3 stage on its own kernels (wmd_head_bwd.hip): tap-partial rows gathered from dy3, one pass over mid each for
+            # the data gradient (returned gated by LeakyReLU'(mid)) and for the weight + bias gradients of every head
+            dw3s = {k: torch.empty_like(heads[k][2]) for k in order}
+            db3s = {k: torch.empty(heads[k][2].shape[0], device=dev, dtype=torch.float32) for k in order}
+            a = _lib.Head3x3BwdArgs(B=B, H=H, W=W, Ct=Ct, n_out=n_out, pad_mode=PAD["reflect"], act=ACT["leaky"], slope=0.1,
+                                    dy3=ptr(dy3), mid=ptr(mid), dzmid=ptr(dzmid), n_heads=len(order), workspace=None,
+                                    workspace_floats=0)
+            keep = []
+            for i, k in enumerate(order):
+                w3c = _c(heads[k][2].detach())
+                keep.append(w3c)
+                a.head[i] = _lib.HeadBwdHead(row0=rows[k], nrows=w3c.shape[0], ch0=offs[k], nch=w3c.shape[1], w3=ptr(w3c),
+                                             dw3=ptr(dw3s[k]), db3=ptr(db3s[k]))
+            n = l.wmd_head3x3_bwd_workspace_floats(C.byref(a))
+            ws = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+            a.workspace, a.workspace_floats = ptr(ws), n
+            check(l.wmd_head3x3_bwd(C.byref(a), current_stream()), "wmd_head3x3_bwd")
+            imgs = pack_many([(w1s, ("dgrad",))]) if want_dx else []
+            wpd1 = imgs[0]["dgrad"] if want_dx else None
+            head_grads3 = lambda k: (dw3s[k], db3s[k])
+        else:
+            # block-diagonal 3x3 filter [n_out, Ct, 3, 3]
+            w3bd = torch.zeros((n_out, Ct, 3, 3), device=dev, dtype=torch.float32)
+            for k in order:
+                w3 = heads[k][2].detach()
+                w3bd[rows[k]:rows[k] + w3.shape[0], offs[k]:offs[k] + w3.shape[1]] = w3
+            # 3x3: weight gradient of the stacked filter (diagonal blocks are the heads' gradients) ...
+            dw3f = torch.empty_like(w3bd)
+            db3f = torch.empty(n_out, device=dev, dtype=torch.float32)
+            a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=Ct, up1=1, C2=0, Cout=n_out, ksize=3, pad_mode=PAD["reflect"], x1=ptr(mid), x2=None,
+                                   dz=ptr(dy3), dw=ptr(dw3f), dbias=ptr(db3f), workspace=None, workspace_floats=0, tune_cfg=0,
+                                   tune_nsplit=0)
+            _wgrad_launch(a, dev)
+            # ... and data gradient, gated by LeakyReLU'(mid): dzmid
+            # the three weight images of this backward (3x3 data gradient direct + Winograd, 1x1 data gradient) in one launch
+            imgs = pack_many([(w3bd, ("dgrad", "wino_dgrad") if _WINOGRAD else ("dgrad",))] + ([(w1s, ("dgrad",))] if want_dx else []))
+            wpd, wpdw = imgs[0]["dgrad"], imgs[0].get("wino_dgrad")
+            a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=Ct, up1=1, C2=0, Cout=n_out, ksize=3, pad_mode=PAD["reflect"], dz=ptr(dy3),
+                                   wp_dgrad=ptr(wpd), dx1=ptr(dzmid), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
+                                   tune_ksplit=0, wp_dgrad_wino=ptr(wpdw), x1_fwd=ptr(mid), x1_act=ACT["leaky"], x1_slope=0.1)
+            _dgrad_launch(a, dev, 9)
+            wpd1 = imgs[1]["dgrad"] if want_dx else None
+            head_grads3 = lambda k: (dw3f[rows[k]:rows[k] + heads[k][2].shape[0], offs[k]:offs[k] + heads[k][2].shape[1]].contiguous(),
+                                     db3f[rows[k]:rows[k] + heads[k][2].shape[0]])
         # 1x1: weight gradient of the stacked filter ...
         dw1f = torch.empty_like(w1s)
         db1f = torch.empty(Ct, device=dev, dtype=torch.float32)
@@ -618,7 +646,6 @@ class _StackedHeadsFn(torch.autograd.Function):
         if want_dx:
             dx = torch.empty_like(x)
             gate_act, gate_slope = (ACT[x_gate[0]], float(x_gate[1])) if x_gate else (0, 0.0)
-            wpd1 = imgs[1]["dgrad"]
             a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], dz=ptr(dzmid),
                                    wp_dgrad=ptr(wpd1), dx1=ptr(dx), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
                                    tune_ksplit=0, wp_dgrad_wino=None, x1_fwd=ptr(x) if gate_act else None, x1_act=gate_act,
@@ -628,8 +655,8 @@ class _StackedHeadsFn(torch.autograd.Function):
         for k in range(len(heads)):
             w1, _b1, w3, _b3 = heads[k]
             c1, c3 = w1.shape[0], w3.shape[0]
-            grads += [dw1f[offs[k]:offs[k] + c1].reshape(w1.shape), db1f[offs[k]:offs[k] + c1],
-                      dw3f[rows[k]:rows[k] + c3, offs[k]:offs[k] + w3.shape[1]].contiguous(), db3f[rows[k]:rows[k] + c3]]
+            dw3k, db3k = head_grads3(k)
+            grads += [dw1f[offs[k]:offs[k] + c1].reshape(w1.shape), db1f[offs[k]:offs[k] + c1], dw3k, db3k]
         return (dx, None, None, None) + tuple(grads)
 
 
@@ -733,6 +760,8 @@ def _ll_chain_pack(w1l, w3l):
 
 
 FUSED_HEAD_WIDTHS = (32, 64, 128, 256)
+_HEAD_BWD = os.environ.get("WMD_HEAD_BWD", "1") != "0"                 # 0: 3x3 head backward on the generic dgrad / wgrad kernels
+_HEAD_BWD_MIN_PIXELS = int(os.environ.get("WMD_HEAD_BWD_MIN_PIXELS", "16384"))
 _TWO_LAUNCH_HEAD = os.environ.get("WMD_TWO_LAUNCH_HEAD", "0") == "1"   # development switch: A/B the two forms
 _LL_FOLD = os.environ.get("WMD_LL_FOLD", "1") != "0"                   # 0: the low-pass head on its own three launches
 
