@@ -387,6 +387,28 @@ typedef struct {
 size_t wmd_head3x3_bwd_workspace_floats(const wmd_head3x3_bwd_args* args);
 int wmd_head3x3_bwd(const wmd_head3x3_bwd_args* args, void* stream);
 
+/* Backward of the 1x1 stage of a level's wavelet heads (training): the first layers Conv1x1(C, C | C/4) of every head of a
+ * level, stacked along the output channels (depth_decoder.py:104-136), given the pre-activation gradient dz [B,Ct,H,W] of the
+ * stack (wmd_head3x3_bwd's dzmid):  dx = act_x'(x) * w1^T dz (optional),  dw1 = sum_p dz (x) x,  db1 = sum_p dz.
+ * One pass over dz and x each for the data and the weight gradient (wmd_head_bwd1.hip).                                   */
+typedef struct {
+    int B, H, W;
+    int C;             /* channels of x                                                  */
+    int Ct;            /* channels of dz = rows of w1 (a multiple of 8)                  */
+    int x_act;         /* activation that produced x (WMD_ACT_ELU for the decoders' trunk; NONE: no gate) */
+    float x_slope;
+    const float* dz;   /* [B,Ct,H,W]                                                     */
+    const float* x;    /* [B,C,H,W]                                                      */
+    const float* w1;   /* [Ct,C] (the [Ct,C,1,1] filters of the heads, concatenated)     */
+    float* dx;         /* [B,C,H,W] or NULL                                              */
+    float* dw1;        /* [Ct,C]                                                         */
+    float* db1;        /* [Ct]                                                           */
+    float* workspace;  /* wmd_head1x1_bwd_workspace_floats(args) floats                  */
+    size_t workspace_floats;
+} wmd_head1x1_bwd_args;
+size_t wmd_head1x1_bwd_workspace_floats(const wmd_head1x1_bwd_args* args);
+int wmd_head1x1_bwd(const wmd_head1x1_bwd_args* args, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Sparse (threshold-gated) decoder path, batch 1
  *

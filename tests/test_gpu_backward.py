@@ -396,6 +396,7 @@ def test_head3x3_backward_kernels_vs_oracle_and_generic_path(dev, C, H, W, B, wi
     loss.backward()
     got = {}
     monkeypatch.setattr(ops, "_HEAD_BWD_MIN_PIXELS", 0)      # the size rule would send these small maps to the generic kernels
+    monkeypatch.setattr(ops, "_HEAD_BWD1_MIN_PIXELS", 0)
     for new_path in (True, False):
         monkeypatch.setattr(ops, "_HEAD_BWD", new_path)
         d = [v.to(dev).requires_grad_(True) for v in leaves]

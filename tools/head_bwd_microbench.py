@@ -18,6 +18,7 @@ for (C, H, W, ll) in ((32, 96, 320, False), (64, 48, 160, False), (128, 24, 80, 
     for new in (True, False):
         ops._HEAD_BWD = new
         ops._HEAD_BWD_MIN_PIXELS = 0
+        ops._HEAD_BWD1_MIN_PIXELS = 0
         for it in range(4):
             if it == 3:
                 _lib.profile_begin()

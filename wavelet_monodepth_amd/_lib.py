@@ -77,6 +77,12 @@ class Head3x3BwdArgs(C.Structure):
                 ("n_heads", C.c_int), ("head", HeadBwdHead * 3), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
 
 
+class Head1x1BwdArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("Ct", C.c_int), ("x_act", C.c_int),
+                ("x_slope", C.c_float), ("dz", C.c_void_p), ("x", C.c_void_p), ("w1", C.c_void_p), ("dx", C.c_void_p),
+                ("dw1", C.c_void_p), ("db1", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+
+
 class EvalKittiArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("h", C.c_int), ("w", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("min_depth", C.c_float), ("max_depth", C.c_float), ("mask_mode", C.c_int), ("pred_scale", C.c_float),
@@ -164,6 +170,8 @@ SIGNATURES = {
     "wmd_head_level_fwd": (C.c_int, [C.POINTER(HeadLevelArgs), C.c_void_p]),
     "wmd_head3x3_bwd_workspace_floats": (C.c_size_t, [C.POINTER(Head3x3BwdArgs)]),
     "wmd_head3x3_bwd": (C.c_int, [C.POINTER(Head3x3BwdArgs), C.c_void_p]),
+    "wmd_head1x1_bwd_workspace_floats": (C.c_size_t, [C.POINTER(Head1x1BwdArgs)]),
+    "wmd_head1x1_bwd": (C.c_int, [C.POINTER(Head1x1BwdArgs), C.c_void_p]),
     "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),

@@ -607,8 +607,7 @@ class _StackedHeadsFn(torch.autograd.Function):
             ws = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
             a.workspace, a.workspace_floats = ptr(ws), n
             check(l.wmd_head3x3_bwd(C.byref(a), current_stream()), "wmd_head3x3_bwd")
-            imgs = pack_many([(w1s, ("dgrad",))]) if want_dx else []
-            wpd1 = imgs[0]["dgrad"] if want_dx else None
+            wpd1 = None        # packed by the generic 1x1 path on demand
             head_grads3 = lambda k: (dw3s[k], db3s[k])
         else:
             # block-diagonal 3x3 filter [n_out, Ct, 3, 3]
@@ -634,23 +633,35 @@ class _StackedHeadsFn(torch.autograd.Function):
             wpd1 = imgs[1]["dgrad"] if want_dx else None
             head_grads3 = lambda k: (dw3f[rows[k]:rows[k] + heads[k][2].shape[0], offs[k]:offs[k] + heads[k][2].shape[1]].contiguous(),
                                      db3f[rows[k]:rows[k] + heads[k][2].shape[0]])
-        # 1x1: weight gradient of the stacked filter ...
         dw1f = torch.empty_like(w1s)
         db1f = torch.empty(Ct, device=dev, dtype=torch.float32)
-        a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], x1=ptr(x), x2=None,
-                               dz=ptr(dzmid), dw=ptr(dw1f), dbias=ptr(db1f), workspace=None, workspace_floats=0, tune_cfg=0,
-                               tune_nsplit=0)
-        _wgrad_launch(a, dev)
-        # ... and data gradient (one GEMM over all heads' mid channels), gated by the caller's activation if x has one
-        dx = None
-        if want_dx:
-            dx = torch.empty_like(x)
-            gate_act, gate_slope = (ACT[x_gate[0]], float(x_gate[1])) if x_gate else (0, 0.0)
-            a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], dz=ptr(dzmid),
-                                   wp_dgrad=ptr(wpd1), dx1=ptr(dx), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
-                                   tune_ksplit=0, wp_dgrad_wino=None, x1_fwd=ptr(x) if gate_act else None, x1_act=gate_act,
-                                   x1_slope=gate_slope)
-            _dgrad_launch(a, dev, 1)
+        dx = torch.empty_like(x) if want_dx else None
+        gate_act, gate_slope = (ACT[x_gate[0]], float(x_gate[1])) if x_gate else (0, 0.0)
+        if _HEAD_BWD and B * H * W >= _HEAD_BWD1_MIN_PIXELS and Ct % 8 == 0 and gate_act in (ACT["none"], ACT["leaky"], ACT["elu"]):
+            # 1x1 stage on its own kernels (wmd_head_bwd1.hip): one pass over dz and x each for dx (gated by the caller's
+            # activation if x has one) and for the stacked weight + bias gradient
+            w1c = _c(w1s.reshape(Ct, C_in))
+            a = _lib.Head1x1BwdArgs(B=B, H=H, W=W, C=C_in, Ct=Ct, x_act=gate_act, x_slope=gate_slope, dz=ptr(dzmid), x=ptr(x),
+                                    w1=ptr(w1c), dx=ptr(dx), dw1=ptr(dw1f), db1=ptr(db1f), workspace=None, workspace_floats=0)
+            n = l.wmd_head1x1_bwd_workspace_floats(C.byref(a))
+            ws1 = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+            a.workspace, a.workspace_floats = ptr(ws1), n
+            check(l.wmd_head1x1_bwd(C.byref(a), current_stream()), "wmd_head1x1_bwd")
+        else:
+            # 1x1: weight gradient of the stacked filter ...
+            a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], x1=ptr(x), x2=None,
+                                   dz=ptr(dzmid), dw=ptr(dw1f), dbias=ptr(db1f), workspace=None, workspace_floats=0, tune_cfg=0,
+                                   tune_nsplit=0)
+            _wgrad_launch(a, dev)
+            # ... and data gradient (one GEMM over all heads' mid channels), gated by the caller's activation if x has one
+            if want_dx:
+                if wpd1 is None:
+                    wpd1 = pack_many([(w1s, ("dgrad",))])[0]["dgrad"]
+                a = _lib.ConvDgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], dz=ptr(dzmid),
+                                       wp_dgrad=ptr(wpd1), dx1=ptr(dx), dx2=None, workspace=None, workspace_floats=0, tune_cfg=0,
+                                       tune_ksplit=0, wp_dgrad_wino=None, x1_fwd=ptr(x) if gate_act else None, x1_act=gate_act,
+                                       x1_slope=gate_slope)
+                _dgrad_launch(a, dev, 1)
         grads = []
         for k in range(len(heads)):
             w1, _b1, w3, _b3 = heads[k]
@@ -762,6 +773,8 @@ def _ll_chain_pack(w1l, w3l):
 FUSED_HEAD_WIDTHS = (32, 64, 128, 256)
 _HEAD_BWD = os.environ.get("WMD_HEAD_BWD", "1") != "0"                 # 0: 3x3 head backward on the generic dgrad / wgrad kernels
 _HEAD_BWD_MIN_PIXELS = int(os.environ.get("WMD_HEAD_BWD_MIN_PIXELS", "16384"))
+_HEAD_BWD1_MIN_PIXELS = int(os.environ.get("WMD_HEAD_BWD1_MIN_PIXELS", "196608"))     # same for the 1x1 stage (wmd_head1x1_bwd):
+# its kernels walk the whole channel sum per 64-pixel wave tile and only win where a level has thousands of tiles (the finest one)
 _TWO_LAUNCH_HEAD = os.environ.get("WMD_TWO_LAUNCH_HEAD", "0") == "1"   # development switch: A/B the two forms
 _LL_FOLD = os.environ.get("WMD_LL_FOLD", "1") != "0"                   # 0: the low-pass head on its own three launches
 
