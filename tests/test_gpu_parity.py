@@ -276,6 +276,93 @@ def test_conv_block_sparse_every_winograd_configuration(dev, up, C1, C2, pad):
     assert tested >= 8
 
 
+@pytest.mark.parametrize("case", [(2, 512, 6, 20, 256, 3, "reflect", 1), (1, 40, 10, 32, 70, 3, "replicate", 1), (2, 24, 8, 10, 20, 3, "reflect", 2), (1, 24, 7, 9, 20, 3, "reflect", 1),
+                                  (1, 2208, 15, 20, 96, 1, "zero", 1), (2, 64, 12, 40, 32, 3, "reflect", 1)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_pre_activation_edge_vs_oracle(dev, case):
+    """Encoder edge (wmd_conv_args.x1_pre_act / x1_scale / x1_shift): the convolution reads x1 through
+    act(x1 * scale[c] + shift[c]) on load.  Against the oracle's convolution of the explicitly activated tensor: the KITTI
+    coarsest maps (R18 6x20 with 512 channels), ragged channels / sizes, upsampling, DenseNet161's 2208-channel 1x1, with and
+    without the affine, ReLU and LeakyReLU, every split-K the planner accepts."""
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib, ops
+    B, C1, H, W, Cout, k, pad, up = case
+    x = t(synth.normal((B, C1, H // up, W // up), "ex", 7))
+    w, b = [t(a) for a in synth.conv_params("ew", Cout, C1, k, 7)]
+    sc = t(synth.uniform((C1,), "esc", 7, 0.5, 1.5))
+    sh = t(synth.uniform((C1,), "esh", 7, -0.5, 0.5))
+    for scale, shift, slope in ((None, None, 0.0), (sc, sh, 0.0), (sc, None, 0.2)):
+        v = x
+        if scale is not None:
+            v = v * scale.view(1, -1, 1, 1)
+        if shift is not None:
+            v = v + shift.view(1, -1, 1, 1)
+        v = torch.nn.functional.leaky_relu(v, slope)
+        v = R.up2(v) if up == 2 else v
+        ref = torch.nn.functional.elu(R.conv3x3(v, w, b, pad) if k == 3 else R.conv1x1(v, w, b))
+        pre = (None if scale is None else scale.to(dev), None if shift is None else shift.to(dev), "leaky", slope)
+        with torch.no_grad():
+            y = ops.conv2d_pre_activated(x.to(dev), pre, w.to(dev), b.to(dev), up1=up, pad=pad, act="elu")
+        assert_close(y, ref, OP_TOL, "pre-activation edge %s" % (pre[2:],))
+    # forced split-K through the C ABI
+    l = _lib.lib()
+    wp = ops.pack_weights(w.to(dev))
+    xd, bd, scd, shd = x.to(dev), b.to(dev), sc.to(dev), sh.to(dev)
+    v = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    v = R.up2(v) if up == 2 else v
+    ref = torch.nn.functional.elu(R.conv3x3(v, w, b, pad) if k == 3 else R.conv1x1(v, w, b))
+    for ks in (2, 4):
+        y = torch.full((B, Cout, H, W), float("nan"), device=dev)
+        a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=0, Cout=Cout, ksize=k, pad_mode=ops.PAD[pad], act=ops.ACT["elu"], slope=0.0,
+                          x1=xd.data_ptr(), x2=None, wp=wp.data_ptr(), bias=bd.data_ptr(), y=y.data_ptr(), workspace=None,
+                          workspace_floats=0, tune_cfg=0, tune_ksplit=ks, x1_scale=scd.data_ptr(), x1_shift=shd.data_ptr(),
+                          x1_pre_act=ops.ACT["leaky"], x1_pre_slope=0.0)
+        n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
+        ws = torch.empty(max(n, 1), device=dev)
+        a.workspace, a.workspace_floats = ws.data_ptr(), n
+        st = l.wmd_conv_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream)
+        if st == -3:
+            continue
+        _lib.check(st, "wmd_conv_fwd")
+        assert_close(y, ref, OP_TOL, "pre-activation edge, split-K %d" % ks)
+    # what the edge refuses: zero padding of a 3x3 (a padded 0 would become act(shift)), a second source tensor
+    if k == 3:
+        with pytest.raises(_lib.WmdError):
+            ops.conv2d_pre_activated(xd, (scd, shd, "leaky", 0.0), w.to(dev), bd, up1=up, pad="zero")
+
+
+def test_kitti_decoders_take_a_deferred_last_feature(dev):
+    """The dense and the sparse wavelet decoder fed with the encoder's last PRE-activation (layers.DeferredActivation: ReLU on
+    load in upconv(4,0)) give the outputs of the ordinary call on the activated tensor -- eagerly and from the replayed graph --
+    and under autograd the wrapper is activated explicitly (same gradients)."""
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder, SparseDepthWaveProgressiveDecoder
+    from wavelet_monodepth_amd.layers import DeferredActivation
+    chans = [64, 64, 128, 256, 512]
+    feats = [f.to(dev) for f in kitti_feats(2, 64, 96, seed=4)]
+    pre = feats[-1] * 2.0 - 0.3                                  # a tensor with negative values
+    act = torch.relu(pre)
+    for cls, kw in ((DepthWaveProgressiveDecoder, {}), (SparseDepthWaveProgressiveDecoder, {"thresh_ratio": 0.05})):
+        dec = synth.fill_state_dict(cls(np.array(chans)), seed=2).to(dev)
+        fa = [f[:1] for f in feats[:-1]] + [act[:1]] if kw else feats[:-1] + [act]
+        fp = [f[:1] for f in feats[:-1]] + [DeferredActivation(pre[:1])] if kw else feats[:-1] + [DeferredActivation(pre)]
+        with torch.no_grad():
+            want = dict(dec(fa, **kw))
+            for graph in (False, True):
+                dec.enable_graph(graph)
+                for _ in range(2 if graph else 1):
+                    got = dec(fp, **kw)
+                for s in range(4):
+                    assert_close(got[("disp", s)], want[("disp", s)].cpu(), 1e-5, "%s graph=%s disp %d" % (cls.__name__, graph, s))
+            dec.enable_graph(False)
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=2).to(dev)
+    p1, p2 = pre.clone().requires_grad_(True), pre.clone().requires_grad_(True)
+    o1 = dec(feats[:-1] + [DeferredActivation(p1)])
+    o2 = dec(feats[:-1] + [torch.relu(p2)])
+    sum((o1[("disp", s)] ** 2).mean() for s in range(4)).backward()
+    sum((o2[("disp", s)] ** 2).mean() for s in range(4)).backward()
+    assert_close(p1.grad, p2.grad.cpu(), 1e-5, "gradient through the activated edge")
+
+
 def test_conv_rejects_bad_input(dev):
     from wavelet_monodepth_amd import ops, _lib
     w = torch.zeros(4, 3, 3, 3, device=dev)

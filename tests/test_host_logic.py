@@ -587,3 +587,28 @@ def test_mobilenetv2_encoder_starts_from_the_reference_initialisation_and_honour
     with torch.no_grad():
         for a, b in zip(enc(x), custom(x)):
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_resnet_encoder_can_defer_its_last_relu():
+    """Encoder edge: with defer_last_relu the last feature comes back as a DeferredActivation whose
+    activation is the block's final ReLU -- applied by the decoders' first convolution on load; under autograd the encoder
+    returns the ordinary activated tensor.  Plain PyTorch on the CPU."""
+    import torch
+    from wavelet_monodepth_amd.encoders import ResnetEncoder
+    from wavelet_monodepth_amd.layers import DeferredActivation, split_edge
+    torch.manual_seed(0)
+    for layers in (18, 50):
+        enc = ResnetEncoder(layers, defer_last_relu=True).eval()
+        ref = ResnetEncoder(layers).eval()
+        ref.load_state_dict(enc.state_dict())
+        x = torch.rand(1, 3, 64, 96)
+        with torch.no_grad():
+            got, want = enc(x), ref(x)
+        assert isinstance(got[-1], DeferredActivation) and got[-1].act == "leaky" and got[-1].slope == 0.0
+        assert float(got[-1].tensor.min()) < 0.0                      # really a pre-activation
+        assert torch.equal(got[-1].activate(), want[-1])
+        for a, b in zip(got[:-1], want[:-1]):
+            assert torch.equal(a, b)
+        feats, edge = split_edge(got)
+        assert edge is got[-1] and feats[-1] is edge.tensor and split_edge(want)[1] is None
+        assert torch.is_tensor(enc(x)[-1])                             # autograd on: ordinary path

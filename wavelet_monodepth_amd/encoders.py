@@ -20,11 +20,11 @@ class _Basic(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = down
 
-    def forward(self, x):
+    def forward(self, x, defer_relu=False):
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        return out + idt if defer_relu else self.relu(out + idt)
 
 
 class _Bottleneck(nn.Module):
@@ -41,12 +41,12 @@ class _Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = down
 
-    def forward(self, x):
+    def forward(self, x, defer_relu=False):
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        return out + idt if defer_relu else self.relu(out + idt)
 
 
 class _ResNet(nn.Module):
@@ -80,8 +80,14 @@ _SPECS = {18: (_Basic, [2, 2, 2, 2]), 34: (_Basic, [3, 4, 6, 3]), 50: (_Bottlene
 
 
 class ResnetEncoder(nn.Module):
-    def __init__(self, num_layers=18, pretrained=False, num_input_images=1):
+    """defer_last_relu (extension): in inference the last residual block returns `out + identity` WITHOUT
+    its final ReLU, wrapped as layers.DeferredActivation -- the decoders' first convolution applies the ReLU while it loads the
+    tensor, so the activated stride-32 map is neither written by the encoder nor re-read.  Under autograd the ordinary
+    activated tensor is returned."""
+
+    def __init__(self, num_layers=18, pretrained=False, num_input_images=1, defer_last_relu=False):
         super().__init__()
+        self.defer_last_relu = bool(defer_last_relu)
         if pretrained:
             raise RuntimeError("no network access in this environment: load encoder.pth explicitly")
         block, layers = _SPECS[num_layers]
@@ -97,6 +103,12 @@ class ResnetEncoder(nn.Module):
         f1 = e.layer1(e.maxpool(f0))
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)
+        if self.defer_last_relu and not torch.is_grad_enabled():
+            from .layers import DeferredActivation
+            h = f3
+            for blk in list(e.layer4)[:-1]:
+                h = blk(h)
+            return [f0, f1, f2, f3, DeferredActivation(e.layer4[-1](h, defer_relu=True), act="leaky", slope=0.0)]
         f4 = e.layer4(f3)
         return [f0, f1, f2, f3, f4]
 

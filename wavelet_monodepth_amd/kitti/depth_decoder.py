@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..layers import Conv1x1, Conv3x3, ConvBlock, gated_backward_allowed
+from ..layers import Conv1x1, Conv3x3, ConvBlock, gated_backward_allowed, split_edge
 from ..wavelets import IDWT
 from ..graphs import GraphCache
 
@@ -59,6 +59,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.tanh = nn.Tanh()
         self._graph_mode = False
+        self._edge = None         # layers.DeferredActivation of the current call's last feature (encoder edge), if any
         self._graphs = GraphCache()
         self.stack_heads = os.environ.get("WMD_STACKED_HEADS", "1") == "1"   # training: one launch per stage over all heads of a level
         self.branch_trace = None   # set to a dict to record the LeakyReLU pieces of a training-mode forward
@@ -170,12 +171,18 @@ class DepthWaveProgressiveDecoder(nn.Module):
         return st
 
     def forward(self, input_features):
+        # encoder edge: the last feature may arrive as a layers.DeferredActivation (pre-activation + what to apply on load)
+        input_features, edge = split_edge(input_features)
+        if edge is not None and torch.is_grad_enabled():
+            input_features[-1], edge = edge.activate(), None        # training: the ordinary path on the activated tensor
+        self._edge = edge
         if self._graph_mode and not torch.is_grad_enabled():
             input_features = self._bound(input_features) or input_features
-            if self.two_stream_graphs:
+            if self.two_stream_graphs and edge is None:
                 self.outputs = self._forward_two_streams(input_features)
             else:
-                self.outputs = self._graphs.run(self._forward_impl, input_features, self.parameters())
+                self.outputs = self._graphs.run(self._forward_impl, input_features, self.parameters(),
+                                                extra_key=("edge",) + edge.key() if edge is not None else ())
             return self.outputs
         return self._forward_impl(input_features)
 
@@ -270,8 +277,12 @@ class DepthWaveProgressiveDecoder(nn.Module):
         # pass (ops.conv2d_fused: x1_gate / grad_is_dz)
         elu = ("elu", 0.0) if (torch.is_grad_enabled() and gated_backward_allowed(self)) else None
         self._gated = elu is not None
+        edge = getattr(self, "_edge", None)
         for i in range(4, 0, -1):
-            x = self.convs[("upconv", i, 0)](x, x1_gate=elu if i < 4 else None, grad_is_dz=elu is not None)
+            if i == 4 and edge is not None:
+                x = self.convs[("upconv", 4, 0)](x, x1_pre=edge.pre())      # ReLU (+ affine) of the encoder's last block on load
+            else:
+                x = self.convs[("upconv", i, 0)](x, x1_gate=elu if i < 4 else None, grad_is_dz=elu is not None)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip=skip, up=2, x1_gate=elu, grad_is_dz=elu is not None)  # fused upsample + concat
             if overlap:
@@ -347,6 +358,9 @@ class DepthDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, input_features):
+        input_features, edge = split_edge(input_features)
+        if edge is not None:
+            input_features[-1] = edge.activate()      # the baseline decoder takes the activated tensor (no fused edge)
         self.outputs = {}
         ops.prepack_module(self)
         x = input_features[-1]

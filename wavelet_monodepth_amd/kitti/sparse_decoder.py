@@ -22,6 +22,7 @@ from .. import ops, sparse_ops as S
 from ..wavelets import IDWT
 from ..graphs import GraphCache
 from .depth_decoder import _build_wave_convs
+from ..layers import split_edge
 
 
 def _conv_ops(cin, cout, npix, k):
@@ -98,6 +99,7 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self._graph_mode = False
         self._graphs = GraphCache()
+        self._edge = None
         self._side = None          # stream of the activation-pool fill
         self._ones = {}            # all-ones mask constants of the coarsest level, per (device, B, h, w)
 
@@ -141,6 +143,8 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         # B frames -- each with its own coefficient range, masks, pixel lists and counts -- through the SAME launches (one
         # 640x192 frame is a few dozen to a few hundred 16-pixel tiles per launch and cannot fill 256 CUs); every per-frame
         # output equals the batch-1 result, and the `total_ops` entries become lists with one integer per frame.
+        input_features, edge = split_edge(input_features)       # encoder edge: the last feature may be a pre-activation
+        self._edge = edge
         forced_on_device = _force_masks is None or all(m.is_cuda for m in _force_masks.values())
         if self._graph_mode and forced_on_device:
             thr, scales = float(thresh_ratio), tuple(sparse_scales)
@@ -148,7 +152,7 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             nf = len(input_features)
             res = self._graphs.run(lambda f: self._device_chain(f[:nf], thr, scales, dict(zip(lv, f[nf:])) if lv else None),
                                    list(input_features) + [_force_masks[i] for i in lv], self.parameters(),
-                                   extra_key=(thr, scales, tuple(lv)))
+                                   extra_key=(thr, scales, tuple(lv)) + (("edge",) + edge.key() if edge is not None else ()))
             out, counters, static_ops = dict(res[0]), res[1], res[2]
         else:
             out, counters, static_ops = self._device_chain(input_features, thresh_ratio, sparse_scales, _force_masks)
@@ -311,7 +315,10 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 xbuf = x1
             else:
                 src = xbuf if xbuf is not None else x
-                xd = ops.conv2d_fused(src, c0.weight, c0.bias, pad="reflect", act="elu")
+                if xbuf is None and getattr(self, "_edge", None) is not None:     # level 4 on the encoder's pre-activation
+                    xd = ops.conv2d_pre_activated(src, self._edge.pre(), c0.weight, c0.bias, pad="reflect", act="elu")
+                else:
+                    xd = ops.conv2d_fused(src, c0.weight, c0.bias, pad="reflect", act="elu")
                 skip = input_features[i - 1] if (self.use_skips and i > 0) else None
                 cin1 = xd.shape[1] + (0 if skip is None else skip.shape[1])
                 ux = ops.conv2d_fused(xd, c1.weight, c1.bias, x2=skip, up1=2, pad="reflect", act="elu")

@@ -12,6 +12,48 @@ import torch.nn as nn
 from . import ops
 
 
+class DeferredActivation:
+    """An encoder's last feature map handed over BEFORE its final activation (the encoder edge):
+    `tensor` is the pre-activation, the consumer reads it as  act(tensor * scale[c] + shift[c])  (scale / shift optional
+    per-channel float32 tensors: an eval-mode BatchNorm folded into the edge; act in {"none", "leaky"}, ReLU = leaky with
+    slope 0).  The decoders pass it to their first convolution, which applies it on load (ops.conv2d_pre_activated ->
+    wmd_conv_args.x1_pre_act), so the activated map is never written or re-read; under autograd they call `activate()` and
+    run the ordinary path.  encoders.ResnetEncoder(defer_last_relu=True) produces one."""
+
+    def __init__(self, tensor, act="leaky", slope=0.0, scale=None, shift=None):
+        if act not in ("none", "leaky"):
+            raise ValueError("DeferredActivation: act must be 'none' or 'leaky' (ReLU = leaky with slope 0)")
+        self.tensor, self.act, self.slope, self.scale, self.shift = tensor, act, float(slope), scale, shift
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    def pre(self):
+        return (self.scale, self.shift, self.act, self.slope)
+
+    def key(self):
+        return (self.act, self.slope, None if self.scale is None else self.scale.data_ptr(),
+                None if self.shift is None else self.shift.data_ptr())
+
+    def activate(self):
+        v = self.tensor
+        if self.scale is not None:
+            v = v * self.scale.view(1, -1, 1, 1)
+        if self.shift is not None:
+            v = v + self.shift.view(1, -1, 1, 1)
+        return nn.functional.leaky_relu(v, self.slope) if self.act == "leaky" else v
+
+
+def split_edge(input_features):
+    """-> (list of plain tensors, DeferredActivation or None) for a feature list whose last entry may be deferred."""
+    feats = list(input_features)
+    edge = feats[-1] if isinstance(feats[-1], DeferredActivation) else None
+    if edge is not None:
+        feats[-1] = edge.tensor
+    return feats, edge
+
+
 def gated_backward_allowed(decoder):
     """The decoders fold every trunk activation's derivative into the CONSUMERS' data gradients (`x1_gate`) and tell the
     producer that what arrives is already the pre-activation gradient (`grad_is_dz`).  That is only sound while the decoder's
@@ -42,7 +84,10 @@ class Conv3x3(nn.Module):
         self.pad_mode = "reflect" if use_refl else "zero"
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3, stride=stride, bias=use_bias)
 
-    def forward(self, x, skip=None, up=1, act="none", slope=0.0, x1_gate=None, grad_is_dz=False):
+    def forward(self, x, skip=None, up=1, act="none", slope=0.0, x1_gate=None, grad_is_dz=False, x1_pre=None):
+        if x1_pre is not None:      # encoder edge (inference): x is a pre-activation, activated on load
+            assert skip is None
+            return ops.conv2d_pre_activated(x, x1_pre, self.conv.weight, self.conv.bias, up1=up, pad=self.pad_mode, act=act, slope=slope)
         return ops.conv2d_fused(x, self.conv.weight, self.conv.bias, x2=skip, up1=up, pad=self.pad_mode, act=act,
                                 slope=slope, x1_gate=x1_gate, grad_is_dz=grad_is_dz)
 
@@ -74,9 +119,11 @@ class ConvBlock(nn.Module):
             raise NotImplementedError
         self.kernel_size = kernel_size
 
-    def forward(self, x, skip=None, up=1, x1_gate=None, grad_is_dz=False):
+    def forward(self, x, skip=None, up=1, x1_gate=None, grad_is_dz=False, x1_pre=None):
         if self.kernel_size == 3:
-            return self.conv(x, skip=skip, up=up, act="elu", x1_gate=x1_gate, grad_is_dz=grad_is_dz)
+            return self.conv(x, skip=skip, up=up, act="elu", x1_gate=x1_gate, grad_is_dz=grad_is_dz, x1_pre=x1_pre)
+        if x1_pre is not None:
+            raise NotImplementedError("the encoder edge feeds a 3x3 ConvBlock")
         return self.conv(x, act="elu", x1_gate=x1_gate, grad_is_dz=grad_is_dz)
 
 

@@ -194,9 +194,11 @@ def pack_weights_wino(weight, dgrad=False):
 # ---------------------------------------------------------------------------------------------
 
 def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None, in_mask=None, out_mask=None, out=None,
-                  in_mask_2x2=False):
+                  in_mask_2x2=False, x1_pre=None):
     """in_mask / out_mask (uint8 [B,H,W]) + out (zero-initialised [B,cout,H,W]): block-sparse execution, see
-    wmd_conv_args.in_mask in include/wmd.h; in_mask_2x2: the caller's promise that in_mask is constant on 2x2 blocks."""
+    wmd_conv_args.in_mask in include/wmd.h; in_mask_2x2: the caller's promise that in_mask is constant on 2x2 blocks.
+    x1_pre = (scale [C1] or None, shift [C1] or None, act, slope): x1 is read through act(x1 * scale + shift)
+    (wmd_conv_args.x1_pre_act: the encoder edge)."""
     l = _lib.lib()
     B, C1 = x1.shape[0], x1.shape[1]
     H, W = x1.shape[2] * up1, x1.shape[3] * up1
@@ -210,6 +212,13 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
                       slope=float(slope), x1=ptr(x1), x2=ptr(x2), wp=ptr(wp), bias=ptr(bias), y=ptr(y),
                       workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_wino=ptr(wp_wino),
                       in_mask=ptr(in_mask), out_mask=ptr(out_mask), in_mask_2x2=int(bool(in_mask_2x2)))
+    if x1_pre is not None:
+        psc, psh, pact, pslope = x1_pre
+        _require_gpu(psc, psh)
+        for v in (psc, psh):
+            if v is not None and (v.dtype != torch.float32 or v.numel() != C1 or not v.is_contiguous()):
+                raise _lib.WmdError("x1_pre: scale / shift must be contiguous float32 tensors with one value per x1 channel")
+        a.x1_scale, a.x1_shift, a.x1_pre_act, a.x1_pre_slope = ptr(psc), ptr(psh), ACT[pact], float(pslope)
     stream = current_stream()
     keep = []
 
@@ -228,6 +237,8 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
     choice = (0, 0)
     if tuner.enabled:
         key = "conv|%d|%d|%d|%d|%d|%d|%d|%d" % (B, H, W, C1, up1, C2, cout, ksize)  # str: JSON-cacheable
+        if x1_pre is not None:
+            key += "|pre"      # encoder edge: its own instantiations of the direct kernel
         if wp_wino is None and ksize == 3:
             key += "|direct"   # a choice made with the Winograd configurations on offer must not be reused without them
         if out_mask is not None:
@@ -237,7 +248,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
             if torch.cuda.is_current_stream_capturing():
                 choice = (0, 0)  # cannot time inside a capture: the library's cost model decides
             else:
-                choice = tuner.tune(key, 9 if ksize == 3 else 1, launch)
+                choice = tuner.tune(key, 9 if ksize == 3 else 1, launch, suffix=",pre>" if x1_pre is not None else None)
     check(launch(*choice), "wmd_conv_fwd")
     return y
 
@@ -320,6 +331,19 @@ def _wgrad_launch(a, device):
         cands = [("library", 0), ("direct", -1)] + [(n, i + 1) for i, n in enumerate(_WGRAD_NAMES)]
         cfg = tuner.choose(key, cands, launch)
     check(launch(cfg), "wmd_conv_wgrad")
+
+
+def conv2d_pre_activated(x1, x1_pre, weight, bias=None, up1=1, pad="reflect", act="none", slope=0.0):
+    """Inference form of conv2d_fused for an x1 that is still a PRE-activation: act( conv( pad( nearest_up( pre(x1) ) ) ) + bias )
+    with pre(v)[c] = pre_act(v * scale[c] + shift[c]) applied on load (wmd_conv_args.x1_pre_act; x1_pre = (scale, shift, act,
+    slope), see layers.DeferredActivation).  No autograd: the training path activates the tensor and calls conv2d_fused."""
+    _require_gpu(x1, weight, bias)
+    if torch.is_grad_enabled() and (x1.requires_grad or weight.requires_grad):
+        raise _lib.WmdError("conv2d_pre_activated is an inference operator (activate the tensor and use conv2d_fused to train)")
+    ksize = weight.shape[-1]
+    if weight.shape[1] != x1.shape[1]:
+        raise _lib.WmdError("weight expects %d input channels, got %d" % (weight.shape[1], x1.shape[1]))
+    return _conv_fwd_raw(_c(x1), None, pack_weights(weight), _c(bias), weight.shape[0], ksize, pad, act, slope, up1, None, x1_pre=x1_pre)
 
 
 def conv2d_fused(x1, weight, bias=None, x2=None, up1=1, pad="reflect", act="none", slope=0.0, x1_gate=None, grad_is_dz=False):
