@@ -69,13 +69,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     float* ldsA = lds + NBUF * T::B_FLOATS;
     constexpr int PRE_MAXC = 2304;      // channels of x1 a PRE launch accepts (DenseNet161: 2208)
     __shared__ float pre_sc[PRE ? PRE_MAXC : 1], pre_sh[PRE ? PRE_MAXC : 1];
-    if constexpr (PRE) {
-        for (int ch = threadIdx.x; ch < PRE_MAXC; ch += WM * WN * 64) {
-            pre_sc[ch] = (a.x1_scale && ch < a.C1) ? a.x1_scale[ch] : 1.f;
-            pre_sh[ch] = (a.x1_shift && ch < a.C1) ? a.x1_shift[ch] : 0.f;
-        }
-    }
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,6 +198,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     if (c_begin < c_end) {
 #pragma unroll
         for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
+    }
+    if constexpr (PRE) {     // per-channel constants of this block's K range (the barrier below publishes them)
+        for (int ch = c_begin * CK + tid; ch < min(c_end * CK, PRE_MAXC); ch += WM * WN * 64) {
+            pre_sc[ch] = (a.x1_scale && ch < a.C1) ? a.x1_scale[ch] : 1.f;
+            pre_sh[ch] = (a.x1_shift && ch < a.C1) ? a.x1_shift[ch] : 0.f;
+        }
     }
     // epilogue operands requested now: a global load at the start of the epilogue is an exposed round trip per block
     float bias_v[MR];
