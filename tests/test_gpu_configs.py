@@ -85,6 +85,12 @@ class _BranchCapture:
                 assert float(z[dis].abs().max()) <= 1e-5 * float(z.abs().max()), "%s: the device took another LeakyReLU " \
                     "piece at a pre-activation of %.3e (scale %.3e)" % (key, float(z[dis].abs().max()), float(z.abs().max()))
                 assert n <= max(2, 1e-4 * z.numel()), "%s: %d branch disagreements" % (key, n)
+        total = sum(z.numel() for z in trace.values())
+        # the guard counts go into the test log (warnings summary): a regression that flips thousands of pieces must not hide
+        # under the per-tensor allowance -- over ALL LeakyReLU inputs of the network at most 1e-5 of the elements may differ
+        import warnings
+        warnings.warn("LeakyReLU pieces: device and oracle differ on %d of %d pre-activations (%d tensors)" % (flips, total, len(trace)))
+        assert flips <= max(4, 1e-5 * total), "%d LeakyReLU branch disagreements over %d pre-activations" % (flips, total)
         return flips
 
 

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 #pragma unroll
         for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
     }
+    const bool pre_relu_only = PRE && !a.x1_scale && !a.x1_shift && a.x1_pre_act == WMD_ACT_LEAKY && a.x1_pre_slope == 0.f;
     if constexpr (PRE) {     // per-channel constants of this block's K range (the barrier below publishes them)
         for (int ch = c_begin * CK + tid; ch < min(c_end * CK, PRE_MAXC); ch += WM * WN * 64) {
             pre_sc[ch] = (a.x1_scale && ch < a.C1) ? a.x1_scale[ch] : 1.f;
@@ -258,10 +259,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
             if (s + D < S) fetch(s + D);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PRE) {
+                if (pre_relu_only) {     // ResNet's edge: one v_max per operand
 #pragma unroll
-                for (int n = 0; n < NR; ++n) {
-                    const float v = fmaf(pf[s % RS][n], psc[s / TAPS], psh[s / TAPS]);
-                    pf[s % RS][n] = a.x1_pre_act == WMD_ACT_LEAKY ? (v > 0.f ? v : v * a.x1_pre_slope) : v;
+                    for (int n = 0; n < NR; ++n) pf[s % RS][n] = fmaxf(pf[s % RS][n], 0.f);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) {
+                        const float v = fmaf(pf[s % RS][n], psc[s / TAPS], psh[s / TAPS]);
+                        pf[s % RS][n] = a.x1_pre_act == WMD_ACT_LEAKY ? (v > 0.f ? v : v * a.x1_pre_slope) : v;
+                    }
                 }
             }
 #pragma unroll
