@@ -421,6 +421,12 @@ typedef struct {
 } wmd_head1x1_bwd_args;
 size_t wmd_head1x1_bwd_workspace_floats(const wmd_head1x1_bwd_args* args);
 int wmd_head1x1_bwd(const wmd_head1x1_bwd_args* args, void* stream);
+/* Both stages of a level's high-frequency heads in three launches instead of six: the 3x3 data gradient (-> dzmid); then the
+ * 3x3 weight gradient, the 1x1 data gradient and the 1x1 weight gradient -- independent of each other once dzmid exists, each a
+ * latency chain on its own -- as ONE launch; then both reduces as one.  Same arguments and results as wmd_head3x3_bwd(a3)
+ * followed by wmd_head1x1_bwd(a1) with a1->dz == a3->dzmid; 3-channel heads only (a level with the low-pass head: the two
+ * separate calls).                                                                                                        */
+int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bwd_args* a1, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Sparse (threshold-gated) decoder path, batch 1

@@ -173,6 +173,7 @@ SIGNATURES = {
     "wmd_head3x3_bwd": (C.c_int, [C.POINTER(Head3x3BwdArgs), C.c_void_p]),
     "wmd_head1x1_bwd_workspace_floats": (C.c_size_t, [C.POINTER(Head1x1BwdArgs)]),
     "wmd_head1x1_bwd": (C.c_int, [C.POINTER(Head1x1BwdArgs), C.c_void_p]),
+    "wmd_head_bwd": (C.c_int, [C.POINTER(Head3x3BwdArgs), C.POINTER(Head1x1BwdArgs), C.c_void_p]),
     "wmd_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wmd_mask_threshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wmd_mask_dilate_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int, C.c_void_p]),

@@ -17,10 +17,9 @@
 #include <algorithm>
 #include <cstring>
 #include "wmd_internal.h"
+#include "wmd_head_bwd1.h"
 
 namespace wmd {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HB_MAX_SLICES = 24;   // (head, 64-channel slice) work items per launch
 constexpr int HB_PART = 8 * 256 + 16;   // floats of one block's partial: 2 row tiles x 4 channel tiles x 16x16 + bias sums
@@ -257,11 +256,11 @@ __global__ __launch_bounds__(256) void head3x3_bwd_data_kernel(const HeadBwdK a)
 // D[row 16][channel 16] += A[row][pixel] * B[pixel][channel] over the pixels (K index kq of MFMA step s = pixel 16 kq + s of the
 // wave's 64): lane (r16 = l & 15, kq) gathers g of ITS row for 16 consecutive pixels, lane (j, kq) loads mid of channel j for
 // the same 16 pixels (four 16-byte loads when the plane allows).  Accumulators stay in registers over all tiles of the block.
-constexpr int HB_WW = 8;   // wavefronts per block of the weight kernel (its partial count, not its parallelism, is capped)
+constexpr int HB_WW = 4;   // wavefronts per block of the weight kernel (256 threads: it also runs as a component of the merged launch)
 template <int NROWS>
-__global__ __launch_bounds__(HB_WW * 64) void head3x3_bwd_weight_kernel(const HeadBwdK a) {
+__device__ __forceinline__ void head3x3_bwd_weight_body(const HeadBwdK& a, int bx, int by, int nbx, float* smem) {
     constexpr int KR = NROWS * 9, RT = (KR + 15) / 16;
-    const HeadBwdSlice sl = a.s[blockIdx.y];
+    const HeadBwdSlice sl = a.s[by];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int HW = a.H * a.W, T = (HW + 63) / 64;
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(HB_WW * 64) void head3x3_bwd_weight_kernel(const He
         goff[rt] = go[rt] * HW - (gty[rt] - 1) * a.W - (gtx[rt] - 1);
     }
 
-    for (int id = blockIdx.x * HB_WW + wave; id < a.B * T; id += gridDim.x * HB_WW) {
+    for (int id = bx * HB_WW + wave; id < a.B * T; id += nbx * HB_WW) {
         const int b = id / T, P0 = (id - b * T) * 64;
         const float* dyb = a.dy3 + ((size_t)b * a.n_out + sl.row0) * HW;
         const int Pl = P0 + 16 * kq;     // this lane's 16 pixels
@@ -360,8 +359,8 @@ __global__ __launch_bounds__(HB_WW * 64) void head3x3_bwd_weight_kernel(const He
         }
     }
     // the four waves' accumulators -> one block partial (fixed order), written as [rt][ct][lane][4] + bias sums
-    __shared__ f32x4 red[HB_WW - 1][RT * 4][64];
-    __shared__ float dbr[HB_WW][NROWS];
+    f32x4 (*red)[RT * 4][64] = reinterpret_cast<f32x4 (*)[RT * 4][64]>(smem);                      // [HB_WW - 1][RT * 4][64]
+    float (*dbr)[NROWS] = reinterpret_cast<float (*)[NROWS]>(smem + (HB_WW - 1) * RT * 4 * 64 * 4);    // [HB_WW][NROWS]
 #pragma unroll
     for (int o = 0; o < NROWS; ++o) {
 #pragma unroll
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(HB_WW * 64) void head3x3_bwd_weight_kernel(const He
     }
     __syncthreads();
     if (wave == 0) {
-        float* out = a.partial + ((size_t)blockIdx.x * a.n_slices + blockIdx.y) * HB_PART;
+        float* out = a.partial + ((size_t)bx * a.n_slices + by) * HB_PART;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -399,11 +398,11 @@ __global__ __launch_bounds__(HB_WW * 64) void head3x3_bwd_weight_kernel(const He
 // sums the block partials (four threads per element, each a contiguous quarter of the blocks in order, combined in a fixed
 // order) and scatters rows (o,tap) x channels into dw3 [nrows, nch, 3, 3] (+ db3).  grid (slices, element chunks of 64)
 template <int NROWS>
-__global__ __launch_bounds__(256) void head3x3_bwd_reduce_kernel(const HeadBwdK a) {
+__device__ __forceinline__ void head3x3_bwd_reduce_body(const HeadBwdK& a, int bx, int by) {
     constexpr int KR = NROWS * 9;
-    const HeadBwdSlice sl = a.s[blockIdx.x];
+    const HeadBwdSlice sl = a.s[bx];
     const int ne = KR * sl.c_count + (sl.c_begin == 0 ? NROWS : 0);
-    const int e = blockIdx.y * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    const int e = by * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
     const bool live = e < ne;
     const bool is_db = e >= KR * sl.c_count;
     int src = 0, r = 0, cl = 0;
@@ -423,13 +422,13 @@ __global__ __launch_bounds__(256) void head3x3_bwd_reduce_kernel(const HeadBwdK 
     if (live) {
         int blk = b0;
         for (; blk + 4 <= b1; blk += 4) {
-            const float p0 = a.partial[((size_t)blk * a.n_slices + blockIdx.x) * HB_PART + src];
-            const float p1 = a.partial[((size_t)(blk + 1) * a.n_slices + blockIdx.x) * HB_PART + src];
-            const float p2 = a.partial[((size_t)(blk + 2) * a.n_slices + blockIdx.x) * HB_PART + src];
-            const float p3 = a.partial[((size_t)(blk + 3) * a.n_slices + blockIdx.x) * HB_PART + src];
+            const float p0 = a.partial[((size_t)blk * a.n_slices + bx) * HB_PART + src];
+            const float p1 = a.partial[((size_t)(blk + 1) * a.n_slices + bx) * HB_PART + src];
+            const float p2 = a.partial[((size_t)(blk + 2) * a.n_slices + bx) * HB_PART + src];
+            const float p3 = a.partial[((size_t)(blk + 3) * a.n_slices + bx) * HB_PART + src];
             s = (((s + p0) + p1) + p2) + p3;
         }
-        for (; blk < b1; ++blk) s += a.partial[((size_t)blk * a.n_slices + blockIdx.x) * HB_PART + src];
+        for (; blk < b1; ++blk) s += a.partial[((size_t)blk * a.n_slices + bx) * HB_PART + src];
     }
     const float s1 = __shfl_xor(s, 1);
     const float t = q & 1 ? s1 + s : s + s1;            // both lanes of a pair hold (even + odd) in that order
@@ -444,6 +443,53 @@ __global__ __launch_bounds__(256) void head3x3_bwd_reduce_kernel(const HeadBwdK 
         }
     }
 }
+
+constexpr int HB_SMEM_FLOATS = (HB_WW - 1) * 8 * 64 * 4 + HB_WW * 4;
+template <int NROWS>
+__global__ __launch_bounds__(HB_WW * 64) void head3x3_bwd_weight_kernel(const HeadBwdK a) {
+    __shared__ __attribute__((aligned(16))) float smem[HB_SMEM_FLOATS];
+    head3x3_bwd_weight_body<NROWS>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
+}
+template <int NROWS>
+__global__ __launch_bounds__(256) void head3x3_bwd_reduce_kernel(const HeadBwdK a) { head3x3_bwd_reduce_body<NROWS>(a, blockIdx.x, blockIdx.y); }
+
+// ---- second stage of wmd_head_bwd as ONE launch ------------------------------------------------------------------------------
+// After head3x3_bwd_data_kernel has produced dz, the 3x3 weight gradient, the 1x1 data gradient and the 1x1 weight gradient are
+// independent of each other, and each of them alone is a latency chain that leaves most of the GPU idle (20-40 us per launch
+// whatever the level's size).  blockIdx.y selects the component (3x3 slices, then the 1x1 data gradient's ci groups, then the 1x1
+// weight gradient's channel-group pairs); blockIdx.x beyond a component's own block count returns.  Same for the two reduces.
+struct HeadBwdStage2K {
+    HeadBwdK h3;
+    Head1x1K h1;
+    int n3, n1d, n1w;        // blockIdx.y extents of the components
+    int nb3, nb1d, nb1w;     // blockIdx.x extents
+};
+__global__ __launch_bounds__(256) void head_bwd_stage2_kernel(const HeadBwdStage2K m) {
+    __shared__ __attribute__((aligned(16))) float smem[H1_SMEM_FLOATS > HB_SMEM_FLOATS ? H1_SMEM_FLOATS : HB_SMEM_FLOATS];
+    int y = blockIdx.y;
+    if (y < m.n3) {
+        if ((int)blockIdx.x < m.nb3) head3x3_bwd_weight_body<3>(m.h3, blockIdx.x, y, m.nb3, smem);
+        return;
+    }
+    y -= m.n3;
+    if (y < m.n1d) {
+        if ((int)blockIdx.x < m.nb1d) head1x1_bwd_data_body(m.h1, blockIdx.x, y, m.nb1d);
+        return;
+    }
+    y -= m.n1d;
+    if ((int)blockIdx.x < m.nb1w) head1x1_bwd_weight_body(m.h1, blockIdx.x, y, m.nb1w, m.n1w, smem);
+}
+__global__ __launch_bounds__(256) void head_bwd_reduce2_kernel(const HeadBwdStage2K m) {
+    if ((int)blockIdx.x < m.n3) {
+        if (blockIdx.y < (9 * 3 * 64 + 3 + 63) / 64) head3x3_bwd_reduce_body<3>(m.h3, blockIdx.x, blockIdx.y);
+        return;
+    }
+    head1x1_bwd_reduce_body(m.h1, blockIdx.x - m.n3, blockIdx.y, m.n1w);
+}
+
+int head1x1_blocks(const wmd_head1x1_bwd_args* g);
+int head1x1_validate(const wmd_head1x1_bwd_args* g);
+void head1x1_fill(const wmd_head1x1_bwd_args* g, Head1x1K* a);
 
 static int head_bwd_blocks(const wmd_head3x3_bwd_args* g) {
     const long tiles = (long)g->B * (((long)g->H * g->W + 63) / 64);
@@ -486,6 +532,41 @@ extern "C" size_t wmd_head3x3_bwd_workspace_floats(const wmd_head3x3_bwd_args* g
     return (size_t)head_bwd_blocks(g) * n * HB_PART;
 }
 
+// fills the kernel arguments of the launch set for heads with `nrows` output channels; returns the floats of partials it uses
+static size_t head_bwd_fill(const wmd_head3x3_bwd_args* g, int nrows, int nblk, float* ws, HeadBwdK* a, double* ch_out) {
+    memset(a, 0, sizeof(*a));
+    a->dy3 = g->dy3;
+    a->mid = g->mid;
+    a->dz = g->dzmid;
+    a->B = g->B, a->H = g->H, a->W = g->W, a->Ct = g->Ct, a->n_out = g->n_out, a->pad_mode = g->pad_mode, a->act = g->act;
+    a->slope = g->slope;
+    a->nblk = nblk;
+    double ch = 0;
+    for (int k = 0; k < g->n_heads; ++k) {
+        const wmd_head_bwd_head& h = g->head[k];
+        if (h.nrows != nrows) continue;
+        for (int c0 = 0; c0 < h.nch; c0 += 64) {
+            HeadBwdSlice& sl = a->s[a->n_slices++];
+            sl.row0 = h.row0, sl.ch0 = h.ch0, sl.nch = h.nch, sl.c_begin = c0, sl.c_count = std::min(64, h.nch - c0);
+            sl.w3 = h.w3, sl.dw3 = h.dw3, sl.db3 = h.db3;
+        }
+        ch += h.nch;
+    }
+    a->partial = ws;
+    *ch_out = ch;
+    return (size_t)nblk * a->n_slices * HB_PART;
+}
+
+static int head_bwd_launch_data(const wmd_head3x3_bwd_args* g, const HeadBwdK& a, int nrows, double ch, hipStream_t s) {
+    const double pix = (double)g->B * g->H * g->W;
+    ProfScope prof("head3x3_bwd_data_kernel", 2.0 * 9 * nrows * ch * pix, 4.0 * pix * (2.0 * ch + nrows), s);
+    const long tiles = (long)g->B * (((long)g->H * g->W + 63) / 64);
+    const dim3 dgrid((unsigned)std::max<long>(1, std::min<long>((tiles + 3) / 4, 4096)), a.n_slices);   // one tile per wave
+    if (nrows == 3) hipLaunchKernelGGL(head3x3_bwd_data_kernel<3>, dgrid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(head3x3_bwd_data_kernel<1>, dgrid, dim3(256), 0, s, a);
+    return check_launch("head3x3_bwd_data_kernel");
+}
+
 extern "C" int wmd_head3x3_bwd(const wmd_head3x3_bwd_args* g, void* stream) {
     int n_all = 0;
     if (int st = head_bwd_validate(g, &n_all)) return st;
@@ -497,36 +578,11 @@ extern "C" int wmd_head3x3_bwd(const wmd_head3x3_bwd_args* g, void* stream) {
     float* ws = g->workspace;
     for (int nrows = 3; nrows >= 1; nrows -= 2) {   // one launch set per head kind: 3-row (+/-) heads, then the 1-row low-pass head
         HeadBwdK a;
-        memset(&a, 0, sizeof(a));
-        a.dy3 = g->dy3;
-        a.mid = g->mid;
-        a.dz = g->dzmid;
-        a.B = g->B, a.H = g->H, a.W = g->W, a.Ct = g->Ct, a.n_out = g->n_out, a.pad_mode = g->pad_mode, a.act = g->act;
-        a.slope = g->slope;
-        a.nblk = nblk;
         double ch = 0;
-        for (int k = 0; k < g->n_heads; ++k) {
-            const wmd_head_bwd_head& h = g->head[k];
-            if (h.nrows != nrows) continue;
-            for (int c0 = 0; c0 < h.nch; c0 += 64) {
-                HeadBwdSlice& sl = a.s[a.n_slices++];
-                sl.row0 = h.row0, sl.ch0 = h.ch0, sl.nch = h.nch, sl.c_begin = c0, sl.c_count = std::min(64, h.nch - c0);
-                sl.w3 = h.w3, sl.dw3 = h.dw3, sl.db3 = h.db3;
-            }
-            ch += h.nch;
-        }
+        ws += head_bwd_fill(g, nrows, nblk, ws, &a, &ch);
         if (a.n_slices == 0) continue;
-        a.partial = ws;
-        ws += (size_t)nblk * a.n_slices * HB_PART;
         const dim3 grid(nblk, a.n_slices);
-        {
-            ProfScope prof("head3x3_bwd_data_kernel", 2.0 * 9 * nrows * ch * pix, 4.0 * pix * (2.0 * ch + nrows), s);
-            const long tiles = (long)g->B * (((long)g->H * g->W + 63) / 64);
-            const dim3 dgrid((unsigned)std::max<long>(1, std::min<long>((tiles + 3) / 4, 4096)), a.n_slices);   // one tile per wave
-            if (nrows == 3) hipLaunchKernelGGL(head3x3_bwd_data_kernel<3>, dgrid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(head3x3_bwd_data_kernel<1>, dgrid, dim3(256), 0, s, a);
-        }
-        if (int st = check_launch("head3x3_bwd_data_kernel")) return st;
+        if (int st = head_bwd_launch_data(g, a, nrows, ch, s)) return st;
         {
             ProfScope prof("head3x3_bwd_weight_kernel", 2.0 * 9 * nrows * ch * pix, 4.0 * pix * (ch + nrows), s);
             if (nrows == 3) hipLaunchKernelGGL(head3x3_bwd_weight_kernel<3>, grid, dim3(HB_WW * 64), 0, s, a);
@@ -542,4 +598,48 @@ extern "C" int wmd_head3x3_bwd(const wmd_head3x3_bwd_args* g, void* stream) {
         if (int st = check_launch("head3x3_bwd_reduce_kernel")) return st;
     }
     return WMD_OK;
+}
+
+// Both stages of a level's heads in three launches: the 3x3 data gradient (-> dzmid), then the 3x3 weight gradient + the 1x1
+// data gradient + the 1x1 weight gradient as ONE launch, then both reduces as one.  a1->dz must be a3->dzmid.
+extern "C" int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bwd_args* a1, void* stream) {
+    int n_all = 0;
+    if (int st = head_bwd_validate(a3, &n_all)) return st;
+    if (int st = head1x1_validate(a1)) return st;
+    for (int k = 0; k < a3->n_heads; ++k)
+        if (a3->head[k].nrows != 3) return fail(WMD_ERR_UNSUPPORTED, "wmd_head_bwd: 3-channel heads only (the low-pass head: wmd_head3x3_bwd + wmd_head1x1_bwd)");
+    if (a1->dz != a3->dzmid || a1->B != a3->B || a1->H != a3->H || a1->W != a3->W || a1->Ct != a3->Ct)
+        return fail(WMD_ERR_BAD_ARG, "wmd_head_bwd: the 1x1 stage must consume the 3x3 stage's dzmid (same B, H, W, Ct)");
+    const int nblk3 = head_bwd_blocks(a3);
+    if (!a3->workspace || a3->workspace_floats < (size_t)nblk3 * n_all * HB_PART)
+        return fail(WMD_ERR_WORKSPACE, "wmd_head_bwd: 3x3 workspace %zu < %zu floats", a3->workspace_floats, (size_t)nblk3 * n_all * HB_PART);
+    HeadBwdStage2K m;
+    memset(&m, 0, sizeof(m));
+    double ch = 0;
+    head_bwd_fill(a3, 3, nblk3, a3->workspace, &m.h3, &ch);
+    head1x1_fill(a1, &m.h1);
+    const size_t need1 = (size_t)m.h1.nblk * m.h1.n_cgrp * m.h1.n_igrp * H1_PART;
+    if (!a1->workspace || a1->workspace_floats < need1)
+        return fail(WMD_ERR_WORKSPACE, "wmd_head_bwd: 1x1 workspace %zu < %zu floats", a1->workspace_floats, need1);
+    hipStream_t s = (hipStream_t)stream;
+    if (int st = head_bwd_launch_data(a3, m.h3, 3, ch, s)) return st;
+    const double pix = (double)a3->B * a3->H * a3->W;
+    const long tiles = (long)a3->B * (((long)a3->H * a3->W + 63) / 64);
+    m.n3 = m.h3.n_slices;
+    m.n1d = a1->dx ? m.h1.n_igrp : 0;
+    m.n1w = m.h1.n_cgrp * m.h1.n_igrp;
+    m.nb3 = nblk3;
+    m.nb1d = (int)std::max<long>(1, std::min<long>((tiles + 3) / 4, 1024));
+    m.nb1w = m.h1.nblk;
+    {
+        ProfScope prof("head_bwd_stage2_kernel", 2.0 * pix * (27.0 * ch + 2.0 * a1->C * a1->Ct),
+                       4.0 * pix * (ch + 3.0 + 2.0 * a1->Ct + 3.0 * a1->C), s);
+        hipLaunchKernelGGL(head_bwd_stage2_kernel, dim3(std::max(m.nb3, std::max(m.nb1d, m.nb1w)), m.n3 + m.n1d + m.n1w), dim3(256), 0, s, m);
+    }
+    if (int st = check_launch("head_bwd_stage2_kernel")) return st;
+    {
+        ProfScope prof("head_bwd_reduce2_kernel", (double)nblk3 * m.n3 * HB_PART + (double)need1, 4.0 * (nblk3 * m.n3 * HB_PART + need1), s);
+        hipLaunchKernelGGL(head_bwd_reduce2_kernel, dim3(m.n3 + m.n1w, (64 * 64 + 64 + 15) / 16), dim3(256), 0, s, m);
+    }
+    return check_launch("head_bwd_reduce2_kernel");
 }

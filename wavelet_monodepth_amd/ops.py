@@ -610,6 +610,7 @@ class _StackedHeadsFn(torch.autograd.Function):
         w1s = torch.cat([heads[k][0].detach() for k in order], 0)
         want_dx = ctx.needs_input_grad[0]
         dzmid = torch.empty_like(mid)
+        a3_pending = None
         nsl = sum((heads[k][2].shape[1] + 63) // 64 for k in order)
         # (worth it where a level has pixels to spread: >= 256 wave tiles; the coarsest level stays on the generic kernels, which
         # split its few pixels over channels instead -- tools/head_bwd_microbench.py)
@@ -630,7 +631,7 @@ class _StackedHeadsFn(torch.autograd.Function):
             n = l.wmd_head3x3_bwd_workspace_floats(C.byref(a))
             ws = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
             a.workspace, a.workspace_floats = ptr(ws), n
-            check(l.wmd_head3x3_bwd(C.byref(a), current_stream()), "wmd_head3x3_bwd")
+            a3_pending = a        # launched below: alone, or merged with the 1x1 stage (wmd_head_bwd)
             wpd1 = None        # packed by the generic 1x1 path on demand
             head_grads3 = lambda k: (dw3s[k], db3s[k])
         else:
@@ -661,7 +662,11 @@ class _StackedHeadsFn(torch.autograd.Function):
         db1f = torch.empty(Ct, device=dev, dtype=torch.float32)
         dx = torch.empty_like(x) if want_dx else None
         gate_act, gate_slope = (ACT[x_gate[0]], float(x_gate[1])) if x_gate else (0, 0.0)
-        if _HEAD_BWD and B * H * W >= _HEAD_BWD1_MIN_PIXELS and Ct % 8 == 0 and gate_act in (ACT["none"], ACT["leaky"], ACT["elu"]):
+        # (alone they only win at the finest level; as components of the merged second-stage launch -- a level without the
+        # low-pass head whose 3x3 stage runs on its own kernels too -- wherever those do)
+        merged = a3_pending is not None and not has_ll and _HEAD_BWD_MERGED
+        if _HEAD_BWD and B * H * W >= (_HEAD_BWD_MIN_PIXELS if merged else _HEAD_BWD1_MIN_PIXELS) and Ct % 8 == 0 and \
+                gate_act in (ACT["none"], ACT["leaky"], ACT["elu"]):
             # 1x1 stage on its own kernels (wmd_head_bwd1.hip): one pass over dz and x each for dx (gated by the caller's
             # activation if x has one) and for the stacked weight + bias gradient
             w1c = _c(w1s.reshape(Ct, C_in))
@@ -670,8 +675,20 @@ class _StackedHeadsFn(torch.autograd.Function):
             n = l.wmd_head1x1_bwd_workspace_floats(C.byref(a))
             ws1 = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
             a.workspace, a.workspace_floats = ptr(ws1), n
-            check(l.wmd_head1x1_bwd(C.byref(a), current_stream()), "wmd_head1x1_bwd")
+            if merged:
+                # three launches for both stages: 3x3 data gradient, then [3x3 weights | 1x1 data | 1x1 weights] as one, then
+                # both reduces as one
+                check(l.wmd_head_bwd(C.byref(a3_pending), C.byref(a), current_stream()), "wmd_head_bwd")
+                a3_pending = None
+            else:
+                if a3_pending is not None:
+                    check(l.wmd_head3x3_bwd(C.byref(a3_pending), current_stream()), "wmd_head3x3_bwd")
+                    a3_pending = None
+                check(l.wmd_head1x1_bwd(C.byref(a), current_stream()), "wmd_head1x1_bwd")
         else:
+            if a3_pending is not None:
+                check(l.wmd_head3x3_bwd(C.byref(a3_pending), current_stream()), "wmd_head3x3_bwd")
+                a3_pending = None
             # 1x1: weight gradient of the stacked filter ...
             a = _lib.ConvWgradArgs(B=B, H=H, W=W, C1=C_in, up1=1, C2=0, Cout=Ct, ksize=1, pad_mode=PAD["zero"], x1=ptr(x), x2=None,
                                    dz=ptr(dzmid), dw=ptr(dw1f), dbias=ptr(db1f), workspace=None, workspace_floats=0, tune_cfg=0,
@@ -796,6 +813,7 @@ def _ll_chain_pack(w1l, w3l):
 
 FUSED_HEAD_WIDTHS = (32, 64, 128, 256)
 _HEAD_BWD = os.environ.get("WMD_HEAD_BWD", "1") != "0"                 # 0: 3x3 head backward on the generic dgrad / wgrad kernels
+_HEAD_BWD_MERGED = os.environ.get("WMD_HEAD_BWD_MERGED", "1") != "0"   # 0: wmd_head3x3_bwd + wmd_head1x1_bwd as separate launch sets
 _HEAD_BWD_MIN_PIXELS = int(os.environ.get("WMD_HEAD_BWD_MIN_PIXELS", "16384"))
 _HEAD_BWD1_MIN_PIXELS = int(os.environ.get("WMD_HEAD_BWD1_MIN_PIXELS", "196608"))     # same for the 1x1 stage (wmd_head1x1_bwd):
 # its kernels walk the whole channel sum per 64-pixel wave tile and only win where a level has thousands of tiles (the finest one)
