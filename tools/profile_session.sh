@@ -47,7 +47,8 @@ sparse)
     unset WMD_TUNE_CACHE ;;
 tests)
     timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=10 > $OUT/gpu_tests.txt 2>&1
-    tail -n 3 $OUT/gpu_tests.txt ;;
+    python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/gpu_tests.txt 2>&1
+    grep -n "passed\|failed\|smoke" $OUT/gpu_tests.txt | tail -n 3 ;;
 esac
 done
 du -sh $OUT; ls $OUT
