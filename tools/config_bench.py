@@ -19,14 +19,22 @@ which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["sparse", "nyu",
 
 
 def timeit(fn, n=20, warm=3):
+    # (the cyclic garbage collector is parked for the timed loop: a generation-2 pass over the captured graphs' tensors is a
+    # 20-30 ms host pause that now and then landed inside one of these 15 ms loops and tripled that line)
+    import gc
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    gc.collect()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    finally:
+        gc.enable()
 
 
 if "sparse" in which:

@@ -198,6 +198,33 @@ class LazyOpsDict(dict):
     __hash__ = None
 
 
+class _PinnedSlot:
+    __slots__ = ("buf", "ev")
+
+
+_pinned_free = []
+
+
+def _pinned_acquire(n, dtype):
+    """A pinned host buffer of >= n elements from a small pool.  A fresh `torch.empty(pin_memory=True)` per forward goes through
+    the caching host allocator, which only recycles a block whose last copy has completed -- a burst of asynchronous decodes
+    outruns it and every now and then pays a hipHostMalloc of tens of milliseconds inside somebody's timed loop."""
+    for i, sl in enumerate(_pinned_free):
+        if sl.buf.dtype == dtype and sl.buf.numel() >= n:
+            del _pinned_free[i]
+            sl.ev.synchronize()       # (long complete: the slot was released by its reader)
+            return sl
+    sl = _PinnedSlot()
+    sl.buf = torch.empty(max(int(n), 256), dtype=dtype, pin_memory=True)
+    sl.ev = torch.cuda.Event()
+    return sl
+
+
+def _pinned_release(slot):
+    if len(_pinned_free) < 64:
+        _pinned_free.append(slot)
+
+
 def counts_to_host(count_tensors):
     """Start an asynchronous copy of small device count tensors into pinned host memory; -> callable returning them as
     lists of python ints (waits for the copy only)."""
@@ -213,17 +240,19 @@ def counts_to_host(count_tensors):
         flat = torch.as_strided(first, (sum(c.numel() for c in count_tensors),), (1,), first.storage_offset())
     else:
         flat = torch.cat([c.reshape(-1) for c in count_tensors])
-    host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+    slot = _pinned_acquire(flat.numel(), flat.dtype)
+    host = slot.buf[:flat.numel()]
     host.copy_(flat, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    slot.ev.record()
     sizes = [c.numel() for c in count_tensors]
 
     def fetch():
-        ev.synchronize()
+        slot.ev.synchronize()
         vals, out, o = host.tolist(), [], 0
         for n in sizes:
             out.append([int(v) for v in vals[o:o + n]])
             o += n
         return out
+    import weakref
+    weakref.finalize(fetch, _pinned_release, slot)      # the slot returns to the pool when the last user of `fetch` is gone
     return fetch
