@@ -99,6 +99,40 @@ __global__ __launch_bounds__(NW * 64, 2) void head_level_kernel(const wmd_head_l
     const bool pix_ok = tid < HL_NPIX && py < H && px < W;
     const float yl_v = (pix_ok && a.yl) ? a.yl[(size_t)b * plane + (size_t)py * W + px] : 0.f;
 
+    // Block-sparse levels (yh_mask = the wavelet mask of the sparse decoders): a tile without a single mask pixel has yh = 0
+    // everywhere, so its synthesis is the low-pass alone -- no patch, no GEMMs.  (Ballot per wave + flags in LDS; the flags are
+    // rewritten only after this tile's barriers.)
+    if (a.yh_mask) {
+        __shared__ int tile_any[NW];
+        const bool mine = pix_ok && a.yh_mask[(size_t)b * plane + (size_t)py * W + px] != 0;
+        const bool wave_any = __builtin_amdgcn_ballot_w64(mine) != 0;
+        if (lane == 0) tile_any[wave] = wave_any ? 1 : 0;
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) all |= tile_any[w];
+        if (__builtin_amdgcn_readfirstlane(all) == 0) {
+            if (pix_ok) {
+#pragma unroll
+                for (int co = 0; co < 3; ++co) a.yh[((size_t)b * 3 + co) * plane + (size_t)py * W + px] = 0.f;
+                if (a.yl && a.out) {
+                    float v = yl_v * 0.5f;
+                    const size_t dst = (size_t)b * 4 * plane + (size_t)(2 * py) * (2 * W) + 2 * px;
+                    *reinterpret_cast<float2*>(a.out + dst) = make_float2(v, v);
+                    *reinterpret_cast<float2*>(a.out + dst + 2 * W) = make_float2(v, v);
+                    if (a.disp) {
+                        v *= a.disp_scale;
+                        if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+                        *reinterpret_cast<float2*>(a.disp + dst) = make_float2(v, v);
+                        *reinterpret_cast<float2*>(a.disp + dst + 2 * W) = make_float2(v, v);
+                    }
+                }
+            }
+            __syncthreads();   // the flags are free for the next tile
+            continue;
+        }
+    }
+
     // ---- 1. gather the patch: wave w moves positions [(w&3)*64, +64) of channels j = (w>>2), (w>>2)+NW/4, ... ----
     {
         const int p = (wave & 3) * 64 + lane;
