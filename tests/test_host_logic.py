@@ -287,6 +287,48 @@ def test_sparse_entry_points_validate_arguments_without_gpu():
     assert lib.wmd_sparse_conv(C.byref(a), None) == 0                                             # nothing to do: no launch
 
 
+def test_round3_entry_points_validate_arguments_without_gpu():
+    """wmd_head3x3_bwd / wmd_head1x1_bwd / wmd_head_bwd and the encoder-edge fields of wmd_conv_args reject bad arguments
+    before any launch (status codes of include/wmd.h: -1 bad argument, -2 bad shape, -3 unsupported, -5 workspace)."""
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib
+    lib = _lib.lib()
+    h = _lib.HeadBwdHead(row0=0, nrows=3, ch0=0, nch=32, w3=1, dw3=1, db3=1)
+    a3 = _lib.Head3x3BwdArgs(B=1, H=8, W=8, Ct=64, n_out=6, pad_mode=1, act=2, slope=0.1, dy3=1, mid=1, dzmid=1, n_heads=1,
+                             workspace=None, workspace_floats=0)
+    a3.head[0] = h
+    assert lib.wmd_head3x3_bwd_workspace_floats(C.byref(a3)) > 0
+    assert lib.wmd_head3x3_bwd(C.byref(a3), None) == -5 and b"workspace" in lib.wmd_last_error()
+    a3.head[0].nrows = 2
+    assert lib.wmd_head3x3_bwd(C.byref(a3), None) == -1                                            # heads have 1 or 3 outputs
+    a3.head[0].nrows, a3.head[0].nch = 3, 65
+    assert lib.wmd_head3x3_bwd(C.byref(a3), None) == -1                                            # channels beyond Ct
+    a3.head[0].nch, a3.act = 32, 3
+    assert lib.wmd_head3x3_bwd(C.byref(a3), None) == -3                                            # sigmoid-gated mid: unsupported
+    a3.act, a3.H = 2, 1
+    assert lib.wmd_head3x3_bwd(C.byref(a3), None) == -2                                            # reflection needs H >= 2
+    a3.H = 8
+    a1 = _lib.Head1x1BwdArgs(B=1, H=8, W=8, C=32, Ct=64, x_act=1, x_slope=0.0, dz=1, x=1, w1=1, dx=1, dw1=1, db1=1,
+                             workspace=None, workspace_floats=0)
+    assert lib.wmd_head1x1_bwd_workspace_floats(C.byref(a1)) > 0
+    assert lib.wmd_head1x1_bwd(C.byref(a1), None) == -5
+    a1.Ct = 60
+    assert lib.wmd_head1x1_bwd(C.byref(a1), None) == -3                                            # Ct must be a multiple of 8
+    a1.Ct, a1.dz = 64, 2
+    assert lib.wmd_head_bwd(C.byref(a3), C.byref(a1), None) == -1 and b"dzmid" in lib.wmd_last_error()
+    a1.dz = 1
+    a3.head[0].nrows, a3.n_out = 1, 6
+    assert lib.wmd_head_bwd(C.byref(a3), C.byref(a1), None) == -3                                  # the merged form: 3-channel heads only
+    # encoder edge of wmd_conv_fwd
+    c = _lib.ConvArgs(B=1, H=8, W=8, C1=16, up1=1, C2=0, Cout=16, ksize=3, pad_mode=0, act=0, slope=0.0, x1=1, x2=None, wp=1,
+                      bias=None, y=1, workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, x1_pre_act=2, x1_pre_slope=0.0)
+    assert lib.wmd_conv_fwd(C.byref(c), None) == -3 and b"zero padding" in lib.wmd_last_error()
+    c.pad_mode, c.x1_pre_act = 1, 1
+    assert lib.wmd_conv_fwd(C.byref(c), None) == -3                                                # ELU on load: not offered
+    c.x1_pre_act, c.C2, c.x2 = 2, 8, 1
+    assert lib.wmd_conv_fwd(C.byref(c), None) == -3 and b"one source tensor" in lib.wmd_last_error()
+
+
 # ---- NYUv2 Model(opts) (NYUv2/model.py:12-71) ------------------------------------------------------------------------------
 def test_nyu_model_picks_encoder_and_decoder_like_the_reference():
     from types import SimpleNamespace as NS
