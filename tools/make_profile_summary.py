@@ -109,3 +109,29 @@ for kind, what in (("fwd", "WMD_BENCH_GRAPH=0 python bench.py --steps 3 --warmup
         for g, r in grids.items():
             print("  %-44s grid %-9s %7.1f MB  mfma %.3f  wait %.2f  stall %.2f" % (name, g, r["hbm_bytes_per_launch"] / 1e6, r.get("mfma_busy_frac", 0),
                                                                                 r.get("wait_frac", 0), r.get("issue_stall_frac", 0)))
+
+
+# ---- the ten largest kernels of the training step with their counters ------------------------------
+tp = os.path.join(P, tag + "_train_profile_r18_640x192_bs12.txt")
+pb = os.path.join(P, tag + "_pmc_bwd.json")
+if os.path.exists(tp) and os.path.exists(pb):
+    pm = json.load(open(pb))["kernels"]
+    rows = []
+    for ln in open(tp):
+        m = re.match(r"\s+(\S+)\s+calls/step\s+(\d+)\s+([0-9.]+) ms/step\s+([0-9.]+) TFLOP/s", ln)
+        if m:
+            rows.append((m.group(1), int(m.group(2)), float(m.group(3)), float(m.group(4))))
+    out = ["# Decoder forward + backward at BASELINE config 2 (R18 640x192, batch 12): the ten largest kernels with their counters",
+           "", "hipEvent time per step from `tools/train_profile.py` (`%s`); counters per launch from the separate `rocprofv3 --pmc` passes of the"
+           % os.path.basename(tp), "same script (`%s`: HBM-side bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB, MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024),"
+           % os.path.basename(pb), "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES), one line per grid size the kernel is launched with.", "",
+           "| kernel | calls / step | ms / step | TFLOP/s (algorithmic) | grid: HBM MB, MFMA-busy, wait |", "|---|---|---|---|---|"]
+    for name, calls, ms, tf in rows[:10]:
+        grids = {}
+        for k, v in pm.items():       # a profile name without template arguments covers every instantiation
+            if k == name or ("<" not in name and k.split("<")[0] == name):
+                grids.update(v)
+        det = "; ".join("%s: %.0f MB, %.2f, %.2f" % (g, r["hbm_bytes_per_launch"] / 1e6, r.get("mfma_busy_frac", 0.0), r.get("wait_frac", 0.0))
+                        for g, r in sorted(grids.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:4]) if grids else "n/a"
+        out.append("| `%s` | %d | %.3f | %.1f | %s |" % (name, calls, ms, tf, det))
+    open(os.path.join(P, tag + "_backward_top10.md"), "w").write("\n".join(out) + "\n")
