@@ -169,11 +169,20 @@ __device__ __forceinline__ void head_side(const float* __restrict__ x, size_t bs
     }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: block id -> tile such that an XCD owns one
+// contiguous run of the tile sequence, so neighbouring tiles' halo columns / rows and shared 128-byte lines meet in ONE L2
+// (counters: this kernel fetched 358 MB per launch at the finest level for 94 MB of input -- every tile's halo lines came from
+// HBM again on another XCD -- and ran bandwidth-bound at 4.5 TB/s).  Same mapping as the convolution kernels (wmd_conv_common.h).
+__device__ __forceinline__ int head_xcd_contiguous(int bid, int n) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int COUT, int NG>
 __global__ __launch_bounds__(H_TT* NG) void head3x3_kernel(const wmd_head_args a, int tiles_x, int tiles_y, int csplit,
                                                             int cper, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) HeadSmem<COUT> sm;
-    int t = blockIdx.x;
+    int t = head_xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx_ = t % tiles_x;
     t /= tiles_x;
     const int ty_ = t % tiles_y;

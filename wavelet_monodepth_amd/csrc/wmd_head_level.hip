@@ -86,8 +86,14 @@ __global__ __launch_bounds__(NW * 64, 2) void head_level_kernel(const wmd_head_l
 #pragma unroll
         for (int co = 0; co < 3; ++co) b3v[sd][co] = b3 ? b3[co] : 0.f;
     }
+    // tile sequence dealt so that an XCD (block id mod 8; gridDim.x is a multiple of 8) owns one contiguous run of it: the halo
+    // rows / columns of neighbouring tiles are fetched into ONE L2 (see head3x3_kernel)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int t = tile;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
