@@ -335,8 +335,13 @@ def sparse_conv_ops(cin, cout, nnz_out, with_mid=None):
     return ops
 
 
-def kitti_sparse_decoder(feats, sd, thresh_ratio=0.05, sparse_scales=(0, 1, 2, 3)):
-    """SparseDepthWaveProgressiveDecoder.forward (depth_decoder.py:292-428), batch 1."""
+def kitti_sparse_decoder(feats, sd, thresh_ratio=0.05, sparse_scales=(0, 1, 2, 3), force_masks=None):
+    """SparseDepthWaveProgressiveDecoder.forward (depth_decoder.py:292-428), batch 1.
+    force_masks = {level i: [h, w] (or [1,1,h,w]) 0/1 mask}: the thresholded mask of depth_decoder.py:308-309 is REPLACED by
+    the given one at those levels (everything downstream -- dilations, index maps, gathers, op model -- is unchanged).  Test
+    hook: lets a parity test run a controlled mask density (SURVEY 8(d) "inject masks"), and lets the reference's own masks be
+    injected so a coefficient sitting exactly at the threshold cannot flip (pinned: tests/test_oracle_golden.py holds this
+    path to the reference fixtures with the reference's masks injected)."""
     keys = kitti_wave_keys()
     sparse_scales = list(sparse_scales)
     out = {}
@@ -354,6 +359,9 @@ def kitti_sparse_decoder(feats, sd, thresh_ratio=0.05, sparse_scales=(0, 1, 2, 3
             thresh = (yl.max() - yl.min()) * thresh_ratio
             mask = (yh.abs().max(2)[0] > thresh).float()
             scale_ops += 3 * mask.shape[2] * mask.shape[3]
+        if force_masks is not None and i in force_masks:
+            forced = torch.as_tensor(force_masks[i]).reshape(1, 1, *mask.shape[2:]).to(mask.dtype)
+            mask = (forced > 0.5).to(mask.dtype)
         umask = up2(mask)
         wavelet_mask = umask > 0.5
         lowres_mask = dilate(mask, 3) > 0.5

@@ -18,7 +18,7 @@ import torch
 
 from oracle import decoder_ref as R
 from wavelet_monodepth_amd import synth
-from util import R18, R50, assert_close, check_packed, key_str, kitti_feats, load_golden, nyu_feats, sample, t, unpack_mask
+from util import R18, R50, assert_close, assert_depth_close, check_packed, key_str, kitti_feats, load_golden, nyu_feats, sample, t, unpack_mask
 
 pytestmark = pytest.mark.gpu
 NET_TOL = 1e-4
@@ -124,6 +124,9 @@ def _kitti_wave_fwd_bwd_vs_oracle(dev, chans, B, H, W, seed):
         out = dec([f.to(dev) for f in feats])
     for k in ref:
         assert_close(out[k], ref[k].detach(), NET_TOL, "no_grad " + key_str(k))
+    for s_ in range(4):      # per pixel on DEPTH (north_star: "<= 1e-4 relative on depth maps")
+        assert_depth_close(out[("disp", s_)], ref[("disp", s_)].detach(), NET_TOL, "no_grad depth %d" % s_)
+        assert_depth_close(og[("disp", s_)], ref[("disp", s_)].detach(), NET_TOL, "grad-mode depth %d" % s_)
     return dec
 
 
@@ -211,6 +214,77 @@ def test_config4_sparse_640x192_vs_reference_with_reference_masks(dev, thr):
     for _ in range(2):
         out = sp(feats, thr, _force_masks=force)
     check_packed(out, gold, NET_TOL)
+
+
+@pytest.mark.parametrize("tiles", ["1", "0"], ids=["tiles", "gather"])
+@pytest.mark.parametrize("thr", [0.05, 0.1])
+def test_config4_sparse_640x192_vs_reference_with_reference_masks_both_forms(dev, thr, tiles, monkeypatch):
+    """Same fixtures through BOTH forms of the sparse levels at the real size: the block-sparse tile form (default) and the
+    gather-GEMM form (WMD_SPARSE_TILES=0: the literal KITTI/layers.py:337-507 with the ballot / prefix-sum compaction)."""
+    monkeypatch.setenv("WMD_SPARSE_TILES", tiles)
+    gold = load_golden("kitti_sparse_r18_640x192_thr%g.npz" % thr)
+    force = {i: t(unpack_mask(gold, "wavelet_mask|%d" % (i - 1)))[0, 0, ::2, ::2].contiguous().to(dev) for i in (3, 2, 1)}
+    sp = _sparse(dev)
+    feats = [f.to(dev) for f in kitti_feats(1, 192, 640, seed=1)]
+    check_packed(sp(feats, thr, _force_masks=force), gold, NET_TOL)
+
+
+def _operating_point_masks(kind, B):
+    """Config 4's named operating point (README.md:97 of the reference: ~10 % of the pixels): injected masks per level
+    i = 3, 2, 1 on that level's coarse grid -- thin contours at 10 / 3 / 1 % (what depth edges look like) or i.i.d. 10 %."""
+    shapes = {3: (12, 40), 2: (24, 80), 1: (48, 160)}
+    dens = {3: 0.10, 2: 0.03, 1: 0.01}
+    masks = {}
+    for i, (h, w) in shapes.items():
+        frames = []
+        for f in range(B):
+            if kind == "contour":
+                frames.append(synth.contour_mask(h, w, dens[i], seed=100 + f))
+            else:
+                frames.append((synth.uniform((h, w), "iid_mask%d" % i, 200 + f, 0.0, 1.0) < 0.10).astype(np.uint8))
+        masks[i] = np.stack(frames)
+    return masks
+
+
+@pytest.mark.parametrize("tiles", ["1", "0"], ids=["tiles", "gather"])
+@pytest.mark.parametrize("B", [1, 12])
+@pytest.mark.parametrize("kind", ["contour", "iid"])
+def test_config4_operating_point_vs_oracle(dev, kind, B, tiles, monkeypatch):
+    """BASELINE config 4 at its operating point against the ORACLE (whose mask-injection path is pinned to the reference's
+    fixtures by tests/test_oracle_golden.py): R18 640x192, contour masks 0.10 / 0.03 / 0.01 and i.i.d. 10 %, one frame and a
+    batch of 12 (every frame its own masks), tile form and gather form, eager and hipGraph replay.  Maps <= 1e-4, the five
+    mask families and the integer op model exact."""
+    monkeypatch.setenv("WMD_SPARSE_TILES", tiles)
+    masks = _operating_point_masks(kind, B)
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    feats = kitti_feats(B, 192, 640, seed=4)
+    sp = _sparse(dev)
+    gfeats = [f.to(dev) for f in feats]
+    force = {i: t(m).to(dev) for i, m in masks.items()}
+    check = sorted(set([0, B - 1, B // 2]))
+    refs = {}
+    with torch.no_grad():
+        for f in check:
+            refs[f] = R.kitti_sparse_decoder([x[f:f + 1] for x in feats], sd, 0.05, force_masks={i: m[f] for i, m in masks.items()})
+    for graph in (False, True):
+        sp.enable_graph(graph)
+        for _ in range(2 if graph else 1):
+            out = sp(gfeats, 0.05, _force_masks=force)
+        for f in check:
+            ref = refs[f]
+            for k, v in ref.items():
+                got = out[k]
+                if torch.is_tensor(v) and v.dtype == torch.bool:
+                    assert torch.equal(got[f:f + 1].cpu(), v), "frame %d %s" % (f, key_str(k))
+                elif torch.is_tensor(v):
+                    assert_close(got[f:f + 1], v, NET_TOL, "frame %d %s (%s, graph=%s)" % (f, key_str(k), kind, graph))
+                else:
+                    g = got[f] if isinstance(got, list) else got
+                    assert int(g) == int(v), "frame %d %s: %d vs %d" % (f, key_str(k), int(g), int(v))
+            # north_star: "<= 1e-4 relative on depth maps" -- per pixel on depth = 1 / scaled disparity, not norm-wise
+            for s_ in range(4):
+                assert_depth_close(out[("disp", s_)][f:f + 1], ref[("disp", s_)], NET_TOL, "frame %d depth %d" % (f, s_))
+    sp.enable_graph(False)
 
 
 @pytest.mark.parametrize("thr", [0.01, 0.05, 0.1])

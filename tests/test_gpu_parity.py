@@ -9,7 +9,7 @@ import torch
 
 from oracle import decoder_ref as R
 from wavelet_monodepth_amd import synth
-from util import R18, assert_close, key_str, kitti_feats, load_golden, max_rel, t
+from util import R18, assert_close, assert_depth_close, key_str, kitti_feats, load_golden, max_rel, t
 
 pytestmark = pytest.mark.gpu
 
@@ -498,6 +498,8 @@ def test_config2_in_the_benchmarked_execution_mode_vs_oracle(dev):
             assert set(ref) == set(out)
             for k, v in ref.items():
                 assert_close(out[k][fr:fr + 1], v, 1e-4, "frame %d %s" % (fr, key_str(k)))
+            for s_ in range(4):      # per pixel on DEPTH (north_star's wording), not norm-wise on the disparity
+                assert_depth_close(out[("disp", s_)][fr:fr + 1], ref[("disp", s_)], 1e-4, "frame %d depth %d" % (fr, s_))
 
 
 def test_bound_static_inputs_replay_fresh_tensors_without_recapturing(dev):

@@ -145,6 +145,34 @@ def test_kitti_sparse_decoder_config4_full_size(thr):
     check_packed(out, load_golden("kitti_sparse_r18_640x192_thr%g.npz" % thr), 5e-6)
 
 
+@pytest.mark.parametrize("name,hw,seed,thr", [("64x64", (64, 64), 1, 0.05), ("64x64", (64, 64), 1, 0.1), ("64x64", (64, 64), 1, 2.0),
+                                              ("96x160", (96, 160), 2, 0.15), ("96x160", (96, 160), 2, 0.2)])
+def test_kitti_sparse_decoder_force_masks_reproduces_the_reference(name, hw, seed, thr):
+    """The oracle's mask-injection hook (force_masks=) is pinned by the reference: with the REFERENCE's own threshold masks
+    injected (wavelet_mask = up2(mask), so mask = wavelet_mask[::2, ::2]) and a threshold that would otherwise give
+    different masks (thresh_ratio 7: nothing passes), every output of the fixture -- maps, the five mask families, the
+    integer op model -- must come out exactly as the reference produced it."""
+    gold = load_golden("kitti_sparse_r18_%s_thr%g.npz" % (name, thr))
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    feats = [f[:1] for f in kitti_feats(2 if name == "64x64" else 1, hw[0], hw[1], seed=seed)]
+    force = {i: t(gold["wavelet_mask|%d" % (i - 1)])[0, 0, ::2, ::2] for i in (3, 2, 1)}
+    with torch.no_grad():
+        out = R.kitti_sparse_decoder(feats, sd, 7.0, force_masks=force)
+    check_outputs(out, gold)
+
+
+@pytest.mark.parametrize("thr", [0.05, 0.1])
+def test_kitti_sparse_decoder_force_masks_config4_full_size(thr):
+    """Same at BASELINE config 4's real size (R18 640x192), against the packed fixtures."""
+    from util import check_packed, unpack_mask
+    gold = load_golden("kitti_sparse_r18_640x192_thr%g.npz" % thr)
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    force = {i: t(unpack_mask(gold, "wavelet_mask|%d" % (i - 1)))[0, 0, ::2, ::2] for i in (3, 2, 1)}
+    with torch.no_grad():
+        out = R.kitti_sparse_decoder(kitti_feats(1, 192, 640, seed=1), sd, 7.0, force_masks=force)
+    check_packed(out, gold, 5e-6)
+
+
 @pytest.mark.parametrize("scales", [[0, 1], [1, 2], [0]])
 def test_kitti_sparse_decoder_non_default_sparse_scales(scales):
     """depth_decoder.py:292,331: levels outside `sparse_scales` run densely inside the sparse decoder (the reference only

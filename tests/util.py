@@ -54,6 +54,16 @@ def assert_close(a, b, rtol, what=""):
     assert err <= rtol, "%s: max relative error %.3e > %.1e" % (what, err, rtol)
 
 
+def assert_depth_close(disp_got, disp_ref, rtol, what="", min_depth=0.1, max_depth=100.0):
+    """north_star's tolerance is "<= 1e-4 relative on depth maps": checked PER PIXEL on depth = 1 / (min_disp + (max_disp -
+    min_disp) * disp) (KITTI/layers.py:16-25), where a norm-wise bound on the disparity is blind at small disparities."""
+    to = lambda v: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float64)
+    lo, hi = 1.0 / max_depth, 1.0 / min_depth
+    dg, dr = 1.0 / (lo + (hi - lo) * to(disp_got)), 1.0 / (lo + (hi - lo) * to(disp_ref))
+    rel = float((np.abs(dg - dr) / np.abs(dr)).max())
+    assert rel <= rtol, "%s: per-pixel relative depth error %.3e > %.1e" % (what, rel, rtol)
+
+
 def photo_case(B=2, H=24, W=40, seed=31):
     """Two frames, a depth map, KITTI-like intrinsics and a small rigid motion — shared with the tests."""
     tgt = synth.uniform((B, 3, H, W), "ph_tgt", seed, 0.0, 1.0).astype(np.float32)
