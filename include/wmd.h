@@ -159,7 +159,22 @@ typedef struct {
     const float* x1_shift;
     int x1_pre_act;
     float x1_pre_slope;
+    /* Work-list form of the block-sparse execution (round 4; wmd_mask_level_lists builds the list).  out_tiles holds the
+     * indices ((b * tiles_y + ty) * tiles_x + tx, tiles of out_tile_h x out_tile_w pixels) of the pixel tiles that contain
+     * an active pixel of out_mask, in any order; *out_tile_count (device scalar) is their number.  Only listed tiles are
+     * dispatched to a matrix-pipe workgroup -- an unlisted tile costs nothing and, as before, is not written -- and the
+     * split of the input-channel reduction is chosen ON THE DEVICE from the count (few active tiles: every tile's K loop is
+     * spread over many workgroups, whose partial sums meet in a list-driven second pass; many: no split, no second pass
+     * work), so that the time follows the active work.  Needs out_mask, a 3x3 layer, wp_wino, a `pure` channel layout
+     * (C1, C2 multiples of 8; an upsampled x1 needs in_mask_2x2) and a tile shape the library has a list kernel for
+     * (wmd_conv_list_tile_supported); workspace: wmd_conv_fwd_workspace_floats.  Values: identical to the mask form.     */
+    const int32_t* out_tiles;
+    const int32_t* out_tile_count;
+    int out_tile_h, out_tile_w;
 } wmd_conv_args;
+
+/* != 0 when wmd_conv_fwd has a work-list kernel for pixel tiles of tile_h x tile_w */
+int wmd_conv_list_tile_supported(int tile_h, int tile_w);
 
 /* Fused  upsample(x1) ++ x2  ->  pad  ->  conv kxk  ->  + bias  ->  activation.
  * Replaces ConvBlock/Conv3x3/Conv1x1 (KITTI/layers.py:120-173), `upsample` (:233-236),
@@ -311,6 +326,10 @@ typedef struct {
                                [27, C/4, 1, 1] image whose rows 0..8 hold the nine taps -> t planes 54..62 of an 81-plane t,
                                completed by wmd_head_shiftsum_fwd(yl_out).  C = 256 only (WMD_ERR_UNSUPPORTED otherwise)   */
     int t_planes;        /* planes per image of t: 0 or 54, or 81 when the low-pass chain shares the buffer              */
+    /* optional [B,H,W] bytes (round 4, chain = 0 on the chained kernel): a run of pixels without a set byte is skipped (its
+     * t planes are not written).  The sparse decoders pass the upconv1 mask = the 3x3 dilation of the wavelet mask: exactly
+     * the pixels whose tap-partials a surviving output of wmd_head_shiftsum_fwd(yh_mask) gathers.                          */
+    const uint8_t* run_mask;
 } wmd_head_fused_args;
 int wmd_head_fused_fwd(const wmd_head_fused_args* args, void* stream);
 
@@ -337,6 +356,11 @@ typedef struct {
     /* optional [B,H,W] bytes: yh is zeroed where the mask is 0 before it is stored and synthesised (the wavelet mask of the
      * sparse decoders' dense branch, depth_decoder.py:272)                                                              */
     const uint8_t* yh_mask;
+    /* optional [B][2] uint32 (round 4): the order-preserving keys of the running (min, max) of every frame's `out` (the new
+     * low-pass plane) are folded in with one atomic pair per wavefront -- the range the NEXT level's threshold needs
+     * (depth_decoder.py:308: yl.max() - yl.min()) without a reduction pass of its own.  key(f) = bits(f) ^ (f < 0 ?
+     * 0xFFFFFFFF : 0x80000000); armed state (0xFFFFFFFF, 0); consumed by wmd_mask_level_lists.                             */
+    uint32_t* range_keys;
 } wmd_head_shiftsum_args;
 int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* args, void* stream);
 
@@ -473,6 +497,57 @@ int wmd_mask_level(const float* yl, size_t n_yl, const float* yh, float thresh_r
  * [B,2] device floats -- with it the ranges come from one extra launch instead of a whole-plane reduction in every block */
 int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, float thresh_ratio, int B, int h, int w,
                      const wmd_dilate_spec* specs, int n, float* minmax_scratch, void* stream);
+
+/* ---- Work-list form of a sparse level's mask launch (round 4) --------------------------------------------------------
+ * One launch per decoder level, as wmd_mask_level_b / wmd_mask_dilate_multi_b, that ALSO
+ *   * compacts, per spec that asks for it, the pixel tiles (tile_h x tile_w) holding at least one set pixel into a work
+ *     list for wmd_conv_args.out_tiles: every workgroup finds the active tiles of its own 16x16-cell region (a bit per
+ *     tile: wavefront OR-reduction + popcount = the offsets inside its run) and reserves a run of the list with one atomic;
+ *     the launch's last workgroup (ticket counter) publishes the total.  List order is unspecified, values never depend
+ *     on it.  Tile shapes must nest in the region: tile_h, tile_w divide 16 * up, at most 32 tiles per region.
+ *   * publishes the per-frame pixel counts of the specs that ask for it WITHOUT a zero-initialised accumulator of the
+ *     caller's and without a copy: accumulators live in `scratch` (all zero at rest: the last workgroup moves them out and
+ *     re-arms them) and are written to slot (seq % ring_slots) of the int32 ring `counts` [ring_slots][slot_ints] at
+ *     [1 + counts_off + frame * ncounts + (count - 1)]; seq is a launch counter kept in scratch and advanced by the launch
+ *     that has `advance` set (the last mask launch of a decoder forward), which also stamps slot[0] = seq + 1 -- so a host
+ *     that counts its forwards the same way can fetch the counts of forward k from slot k % ring_slots whenever it wants
+ *     them (and verify the stamp), and a forward that nobody asks pays neither a fill, nor a copy, nor a sync.
+ *   * takes the LL range from `range_keys` when given: [B][2] order-preserving uint32 keys of (min, max) that the head
+ *     kernels' epilogues maintain with atomics (wmd_head_shiftsum_args.range_keys); consumed and re-armed
+ *     (0xFFFFFFFF, 0) by this launch.  Else `minmax` [B,2] floats, else every block reduces yl itself.
+ * scratch: wmd_mask_level_scratch_ints(B) int32, zero-initialised ONCE by the caller, private to one stream.            */
+typedef struct {
+    int up, radius;        /* as wmd_dilate_spec                                                                      */
+    uint8_t* out;          /* [B, h*up, w*up]                                                                         */
+    int count;             /* k > 0: this spec's pixel count is published as count column k - 1 (k <= ncounts <= 8)    */
+    int tile_h, tile_w;    /* != 0: build the active-tile list of this spec's mask                                     */
+    int32_t* tile_list;    /* capacity B * ceil(h*up / tile_h) * ceil(w*up / tile_w)                                   */
+    int32_t* tile_count;   /* device scalar, overwritten                                                               */
+    const uint8_t* and_mask; /* optional [B, h*up, w*up]: out = dilation AND and_mask.  The never-refilled activation planes
+                              of the work-list form hold stale values outside the previous level's support; the reference
+                              reads 0 there (sparse_select, KITTI/layers.py:392-400: a pixel absent from the previous index
+                              map gathers the prepended zero), so the input mask of upconv(i,0) is lowres AND the previous
+                              level's upconv1 mask -- a no-op for thresholded masks, which are nested by construction   */
+} wmd_level_spec;
+
+typedef struct {
+    int B, h, w;
+    const float* yl;       /* [B, n_yl]   threshold form (depth_decoder.py:308-309) ...                                */
+    size_t n_yl;
+    const float* yh;       /* [B, 3, h, w]                                                                            */
+    float thresh_ratio;
+    const uint8_t* mask0;  /* ... or an injected base mask [B, h, w] (yl / yh unused)                                  */
+    const float* minmax;   /* optional [B, 2]                                                                          */
+    uint32_t* range_keys;  /* optional [B, 2], see above                                                               */
+    const wmd_level_spec* specs;
+    int n;                 /* <= 8                                                                                     */
+    int32_t* scratch;
+    int32_t* counts;       /* the ring (NULL when ncounts == 0)                                                        */
+    int ring_slots, slot_ints, counts_off, ncounts;
+    int advance;
+} wmd_mask_level_args;
+size_t wmd_mask_level_scratch_ints(int B);
+int wmd_mask_level_lists(const wmd_mask_level_args* args, void* stream);
 
 typedef struct {
     const uint8_t* mask;   /* [npix]                                                               */

@@ -70,7 +70,7 @@ def test_ctypes_structs_mirror_the_header_layout(tmp_path):
              "wmd_dwconv_args": _lib.DwConvArgs, "wmd_head_args": _lib.HeadArgs, "wmd_head_fused_args": _lib.HeadFusedArgs,
              "wmd_head_shiftsum_args": _lib.HeadShiftsumArgs, "wmd_head_level_args": _lib.HeadLevelArgs,
              "wmd_head_bwd_head": _lib.HeadBwdHead, "wmd_head3x3_bwd_args": _lib.Head3x3BwdArgs, "wmd_head1x1_bwd_args": _lib.Head1x1BwdArgs,
-             "wmd_pack_item": _lib.PackItem, "wmd_dilate_spec": _lib.DilateSpec, "wmd_compact_spec": _lib.CompactSpec, "wmd_sparse_conv_args": _lib.SparseConvArgs,
+             "wmd_pack_item": _lib.PackItem, "wmd_dilate_spec": _lib.DilateSpec, "wmd_level_spec": _lib.LevelSpec, "wmd_mask_level_args": _lib.MaskLevelArgs, "wmd_compact_spec": _lib.CompactSpec, "wmd_sparse_conv_args": _lib.SparseConvArgs,
              "wmd_eval_kitti_args": _lib.EvalKittiArgs, "wmd_warp_args": _lib.WarpArgs}
     header = os.path.join(ROOT, "include", "wmd.h")
     declared = set(re.findall(r"^\} (wmd_\w+);", open(header).read(), flags=re.M)) - {"wmd_status"}

@@ -24,7 +24,8 @@ class ConvArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
                 ("wp_wino", C.c_void_p), ("gate", C.c_void_p), ("gate_act", C.c_int), ("gate_slope", C.c_float),
                 ("in_mask", C.c_void_p), ("out_mask", C.c_void_p), ("in_mask_2x2", C.c_int),
-                ("x1_scale", C.c_void_p), ("x1_shift", C.c_void_p), ("x1_pre_act", C.c_int), ("x1_pre_slope", C.c_float)]
+                ("x1_scale", C.c_void_p), ("x1_shift", C.c_void_p), ("x1_pre_act", C.c_int), ("x1_pre_slope", C.c_float),
+                ("out_tiles", C.c_void_p), ("out_tile_count", C.c_void_p), ("out_tile_h", C.c_int), ("out_tile_w", C.c_int)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -55,7 +56,7 @@ class HeadArgs(C.Structure):
 class HeadFusedArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("slope", C.c_float),
                 ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p), ("t", C.c_void_p),
-                ("chain", C.c_int), ("t_planes", C.c_int)]
+                ("chain", C.c_int), ("t_planes", C.c_int), ("run_mask", C.c_void_p)]
 
 
 class HeadLevelArgs(C.Structure):
@@ -107,7 +108,20 @@ class HeadShiftsumArgs(C.Structure):
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
                 ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
                 ("clamp01", C.c_int), ("bias_ll", C.c_void_p), ("scale_ll", C.c_float), ("yl_out", C.c_void_p),
-                ("yh_mask", C.c_void_p)]
+                ("yh_mask", C.c_void_p), ("range_keys", C.c_void_p)]
+
+
+class LevelSpec(C.Structure):
+    _fields_ = [("up", C.c_int), ("radius", C.c_int), ("out", C.c_void_p), ("count", C.c_int), ("tile_h", C.c_int),
+                ("tile_w", C.c_int), ("tile_list", C.c_void_p), ("tile_count", C.c_void_p), ("and_mask", C.c_void_p)]
+
+
+class MaskLevelArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("h", C.c_int), ("w", C.c_int), ("yl", C.c_void_p), ("n_yl", C.c_size_t), ("yh", C.c_void_p),
+                ("thresh_ratio", C.c_float), ("mask0", C.c_void_p), ("minmax", C.c_void_p), ("range_keys", C.c_void_p),
+                ("specs", C.POINTER(LevelSpec)), ("n", C.c_int), ("scratch", C.c_void_p), ("counts", C.c_void_p),
+                ("ring_slots", C.c_int), ("slot_ints", C.c_int), ("counts_off", C.c_int), ("ncounts", C.c_int),
+                ("advance", C.c_int)]
 
 
 class DilateSpec(C.Structure):
@@ -184,6 +198,9 @@ SIGNATURES = {
     "wmd_mask_level_b": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(DilateSpec), C.c_int,
                          C.c_void_p, C.c_void_p]),
     "wmd_mask_compact_multi_b": (C.c_int, [C.POINTER(CompactSpec), C.c_int, C.c_int, C.c_void_p]),
+    "wmd_mask_level_scratch_ints": (C.c_size_t, [C.c_int]),
+    "wmd_mask_level_lists": (C.c_int, [C.POINTER(MaskLevelArgs), C.c_void_p]),
+    "wmd_conv_list_tile_supported": (C.c_int, [C.c_int, C.c_int]),
     "wmd_sparse_conv": (C.c_int, [C.POINTER(SparseConvArgs), C.c_void_p]),
     "wmd_upsample_bilinear_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),
     "wmd_upsample_bilinear_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]),

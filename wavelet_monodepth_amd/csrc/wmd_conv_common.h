@@ -48,7 +48,27 @@ struct ConvKArgs {
     float x1_pre_slope;
     // out-channel slabs per pixel tile when the grid is 1-D (0: the slab is blockIdx.y -- the fused-head launches)
     int cob;
+    // work-list form of the block-sparse execution (wmd_conv_args.out_tiles; LIST instantiations of conv_wino32_kernel): item i
+    // of the launch = (tile_list[i / cob], slab i % cob) for i < *tile_count * cob; the K split is chosen on the device
+    // (list_ksplit) up to ksmax = gridDim.z slices; ksplit slices > 1 write partial sums to `y` (workspace), one slice the final
+    // result to y_final
+    const int* tile_list;
+    const int* tile_count;
+    int ksmax;
+    float* y_final;
 };
+
+// Device-chosen split of the input-channel reduction of a work-list launch: the same function in the convolution and in its
+// second pass.  Fills the machine (kListSlots workgroup slots) when few tiles are active, at least two chunks per slice.
+constexpr int kListSlots = 768;
+__host__ __device__ inline void list_ksplit(int n_items, int nchunks, int ksmax, int& ks, int& cps) {
+    int want = n_items > 0 ? kListSlots / n_items : 1;
+    want = want < 1 ? 1 : (want > ksmax ? ksmax : want);
+    cps = (nchunks + want - 1) / want;
+    const int floor_cps = nchunks < 2 ? nchunks : 2;
+    if (cps < floor_cps) cps = floor_cps;
+    ks = (nchunks + cps - 1) / cps;
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -105,6 +125,10 @@ inline bool wino32_pure(const ConvKArgs& a, int CK) {
 
 template <int TH, int TW, int WN, int CK>
 void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s);   // explicit instantiations: wmd_conv_wino32_table.inc
+// tile shapes with a LIST instantiation (work-list form): small tiles that nest in wmd_mask_level_lists' regions
+constexpr bool wino32_has_list(int TH, int TW, int WN, int CK) {
+    return CK == 8 && ((TH == 8 && TW == 16 && WN == 1) || (TH == 16 && TW == 16 && WN == 2));
+}
 
 // weight-gradient kernels (wmd_conv_bwd.hip, wmd_conv_wgrad32.hip)
 struct WgradKArgs {

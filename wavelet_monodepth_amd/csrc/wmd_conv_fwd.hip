@@ -440,6 +440,47 @@ __global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, con
     }
 }
 
+// Second pass of a work-list launch (wmd_conv_args.out_tiles): one block per listed tile sums the ks partial planes of its
+// TH x TW x Cout outputs in the fixed order s = 0 .. ks-1, adds the bias, applies the activation and the out-mask select.
+// ks comes from the same device-side rule as in the convolution (list_ksplit); ks == 1 means the convolution already wrote the
+// final values and every block returns at once.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_list_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                                      float* __restrict__ y, const int* __restrict__ tile_list,
+                                                                      const int* __restrict__ tile_count, const uint8_t* __restrict__ out_mask,
+                                                                      int B, int Cout, int H, int W, int TH, int TW, int tiles_x, int tiles_y,
+                                                                      int cob, int nchunks, int ksmax, int act, float slope) {
+    const int n_act = *tile_count;
+    if ((int)blockIdx.x >= n_act) return;
+    int ks, cps;
+    list_ksplit(n_act * cob, nchunks, ksmax, ks, cps);
+    if (ks == 1) return;
+    int t = tile_list[blockIdx.x];
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const size_t plane = (size_t)H * W, n = (size_t)B * Cout * plane;
+    const int per = TH * TW;
+    for (int e = threadIdx.x; e < per * Cout; e += 256) {
+        const int c = e / per, p = e - c * per;
+        const int yy = y0 + p / TW, xx = x0 + p % TW;
+        if (yy >= H || xx >= W) continue;
+        const size_t i = ((size_t)b * Cout + c) * plane + (size_t)yy * W + xx;
+        float v = 0.f;
+        int s = 0;
+        for (; s + 4 <= ks; s += 4) {
+            const float p0 = partial[(size_t)s * n + i], p1 = partial[(size_t)(s + 1) * n + i];
+            const float p2 = partial[(size_t)(s + 2) * n + i], p3 = partial[(size_t)(s + 3) * n + i];
+            v = (((v + p0) + p1) + p2) + p3;
+        }
+        for (; s < ks; ++s) v += partial[(size_t)s * n + i];
+        if (bias) v += bias[c];
+        v = act_apply(v, act, slope);
+        if (out_mask && out_mask[(size_t)b * plane + (size_t)yy * W + xx] == 0) v = 0.f;
+        y[i] = v;
+    }
+}
+
 // ================================================================================================
 // Winograd F(2x2, 3x3) form of the same convolution: 2.25x fewer MFMAs per output.
 //
@@ -983,6 +1024,11 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         const bool wino = c.TAPS >= 16;
         if (wino ? (taps != 9 || !g->wp_wino) : c.TAPS != taps) continue;
         if ((g->in_mask || g->out_mask) && !wino) continue;   // block-sparse execution lives in the Winograd kernels
+        if (g->gate && wino) continue;                        // the output gate lives in the direct kernels (and the split-K reduce)
+        if (g->out_tiles) {   // work-list form: the LIST instantiations of conv_wino32_kernel on the list's own tile shape
+            if (c.TAPS != 17 || c.TH != g->out_tile_h || c.TW != g->out_tile_w || !wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK)) continue;
+            if (Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK) || (g->in_mask && g->up1 == 2 && !g->in_mask_2x2)) continue;   // wino32_pure
+        }
         if (c.pre != (g->x1_pre_act != 0 || g->x1_scale || g->x1_shift)) continue;   // encoder edge: the PRE instantiations, and only then
         if (force >= 0 && force != i) continue;
         const int tiles_x = (W + c.TW - 1) / c.TW, tiles_y = (H + c.TH - 1) / c.TH;
@@ -995,6 +1041,24 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         int bpc = std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, 8 / waves));
         bpc = std::max(bpc, 1);
         const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * c.TAPS;   // MFMA work (Winograd: 16 positions x 16 tiles)
+        if (g->out_tiles) {
+            // the device picks the split (list_ksplit) up to ksmax slices = gridDim.z: as many as could matter if every
+            // slice of every possible item had to find a workgroup slot (a batch of frames never splits)
+            const int ksmax = (int)std::max<long>(1, std::min<long>(std::min(nchunks / 2, 16), 2L * kListSlots / std::max<long>(blocks, 1)));
+            const size_t need = ksmax > 1 ? (size_t)ksmax * g->B * g->Cout * g->H * g->W : 0;
+            if (ksmax > 1 && (!have_ws || need > ws_floats)) continue;
+            found = true;
+            plan->cfg = &c;
+            plan->ksplit = ksmax;
+            plan->chunks_per_split = nchunks;
+            plan->nchunks = nchunks;
+            plan->tiles_x = tiles_x;
+            plan->tiles_y = tiles_y;
+            plan->H = H;
+            plan->W = W;
+            plan->workspace_floats = need;
+            break;
+        }
         for (int ks = 1; ks <= 32; ++ks) {
             if (force_ks > 0 ? ks != force_ks : (ks & (ks - 1)) != 0 || ks > 16) continue;  // model: powers of two
             if (ks > 1 && (!have_ws || nchunks < ks)) continue;
@@ -1260,6 +1324,14 @@ extern "C" int wmd_conv_pack_many(const wmd_pack_item* items, int n, void* strea
     return WMD_OK;
 }
 
+extern "C" int wmd_conv_list_tile_supported(int tile_h, int tile_w) {
+    for (int i = 0; i < kNumCfgs; ++i) {
+        const ConvCfg& c = kCfgs[i];
+        if (c.TAPS == 17 && c.TH == tile_h && c.TW == tile_w && wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK)) return 1;
+    }
+    return 0;
+}
+
 static int validate_conv(const wmd_conv_args* g, const char* who) {
     if (!g) return fail(WMD_ERR_BAD_ARG, "%s: null args", who);
     if (!g->x1 || !g->wp || !g->y) return fail(WMD_ERR_BAD_ARG, "%s: null tensor pointer", who);
@@ -1275,6 +1347,12 @@ static int validate_conv(const wmd_conv_args* g, const char* who) {
     // ReflectionPad2d(1) requires every padded dimension to be >= 2 (torch raises otherwise)
     if (g->ksize == 3 && g->pad_mode == WMD_PAD_REFLECT && (g->H < 2 || g->W < 2))
         return fail(WMD_ERR_BAD_SHAPE, "%s: reflect padding needs H,W >= 2 (got %dx%d)", who, g->H, g->W);
+    if (g->out_tiles) {   // work-list form
+        if (!g->out_tile_count || !g->out_mask || g->ksize != 3 || !g->wp_wino || g->gate)
+            return fail(WMD_ERR_BAD_ARG, "%s: a tile list needs its count, out_mask, a 3x3 layer with wp_wino and no gate", who);
+        if (!wmd_conv_list_tile_supported(g->out_tile_h, g->out_tile_w))
+            return fail(WMD_ERR_UNSUPPORTED, "%s: no work-list kernel for %dx%d tiles", who, g->out_tile_h, g->out_tile_w);
+    }
     if (g->x1_pre_act != WMD_ACT_NONE || g->x1_scale || g->x1_shift) {   // encoder edge
         if (g->x1_pre_act != WMD_ACT_NONE && g->x1_pre_act != WMD_ACT_LEAKY)
             return fail(WMD_ERR_UNSUPPORTED, "%s: x1_pre_act=%d (none, or LeakyReLU; ReLU = slope 0)", who, g->x1_pre_act);
@@ -1348,6 +1426,13 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.ksplit = plan.ksplit;
     a.chunks_per_split = plan.chunks_per_split;
     a.y = plan.ksplit > 1 ? g->workspace : g->y;
+    const bool list = g->out_tiles != nullptr;
+    if (list) {
+        a.tile_list = g->out_tiles;
+        a.tile_count = g->out_tile_count;
+        a.ksmax = plan.ksplit;
+        a.y_final = g->y;
+    }
     a.gate = g->gate;
     a.gate_act = g->gate_act;
     a.gate_slope = g->gate_slope;
@@ -1365,7 +1450,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     // stays resident in an XCD's 4 MB L2; for the coarse layers, whose weights are larger than that and whose patches are
     // small, the tiles of one slab run together instead (they share that slab's weights) -- the 2-D grid.
     const double wbytes = (double)a.ncot * 16 * a.nci4 * 4 * (wino ? 16 : taps) * 4;
-    const bool tile_major = cob > 1 && wbytes <= 3.0 * 1024 * 1024;
+    const bool tile_major = list || (cob > 1 && wbytes <= 3.0 * 1024 * 1024);   // (list items are always (tile, slab) pairs)
     a.cob = tile_major ? cob : 0;
     dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y * (tile_major ? cob : 1)), tile_major ? 1u : (unsigned)cob,
               (unsigned)plan.ksplit);
@@ -1387,6 +1472,17 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     }
     st = check_launch("conv_fwd_kernel");
     if (st) return st;
+    if (list) {
+        if (plan.ksplit > 1) {   // (ksmax = 1: the device can never split, no second pass)
+            const int ntiles = g->B * plan.tiles_x * plan.tiles_y;
+            ProfScope prof("conv_splitk_reduce_list_kernel", 0.0, 0.0, (hipStream_t)stream);
+            hipLaunchKernelGGL(conv_splitk_reduce_list_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, g->workspace, g->bias, g->y,
+                               g->out_tiles, g->out_tile_count, g->out_mask, g->B, g->Cout, g->H, g->W, c.TH, c.TW, plan.tiles_x,
+                               plan.tiles_y, cob, plan.nchunks, plan.ksplit, g->act, g->slope);
+            st = check_launch("conv_splitk_reduce_list_kernel");
+        }
+        return st;
+    }
     if (plan.ksplit > 1) {
         const size_t n = (size_t)g->B * g->Cout * g->H * g->W;
         const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);

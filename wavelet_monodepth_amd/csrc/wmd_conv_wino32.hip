@@ -94,12 +94,15 @@ __device__ __forceinline__ float act_const(float v, float slope) {
 //   the sparse decoders): per-channel pieces with a per-piece source choice, upsampling through the >>1 gather.
 // MASKED: the instantiation carries the block-sparse mask code (always with GENERIC; the flattened staging has a dense and a
 // masked instantiation -- the mask code in the epilogue cost the dense launches 2-3 % when they shared one).
-template <int TH, int TW, int WN, int CK, bool GENERIC, bool MASKED>
+// LIST (with MASKED, !GENERIC): the work-list form -- the block's tile comes out of a compacted list of active tiles and the
+//   K split is chosen on the device from the list's length (wmd_conv_args.out_tiles).  A block beyond the list returns at once.
+template <int TH, int TW, int WN, int CK, bool GENERIC, bool MASKED, bool LIST = false>
 __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArgs a) {
     using T = W32Tile<TH, TW, WN, CK>;
     constexpr int NT = T::NT, PWS = T::PWS, PSF = T::PSF, PWL = T::PWL, PSL = T::PSL;
     constexpr int KW = T::KW, TXB = T::TXB;
     static_assert(MASKED || !GENERIC, "the generic instantiation carries the mask code");
+    static_assert(!LIST || (MASKED && !GENERIC), "the work-list form is a masked, flattened-staging instantiation");
     // masks are tested in the prologue (input: folded into the gather offsets) and the epilogue only
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS + T::TAB_FLOATS + 16];   // + one tile-activity flag per wave
 
@@ -112,7 +115,17 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     const int hf = wave / WN;
 
     int t, by;
-    if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD (see conv_fwd_kernel)
+    int ks_n = a.ksplit, cps = a.chunks_per_split;   // LIST: chosen below from the list's length
+    if constexpr (LIST) {
+        const int n_items = *a.tile_count * a.cob;
+        if ((int)blockIdx.x >= n_items) return;
+        list_ksplit(n_items, a.nchunks, a.ksmax, ks_n, cps);
+        if ((int)blockIdx.z >= ks_n) return;
+        const int item = xcd_contiguous(blockIdx.x, n_items);
+        const int ti = item / a.cob;
+        by = item - ti * a.cob;
+        t = a.tile_list[ti];
+    } else if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD (see conv_fwd_kernel)
         const int item = xcd_contiguous(blockIdx.x, gridDim.x);
         t = item / a.cob;
         by = item - t * a.cob;
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     // the epilogue's mask code costs nothing) -- the skipped block walks an empty chunk range and stores nothing instead
     // (prologue + an epilogue over zeros: a few thousand cycles against ~50 k for a computed tile).
     bool skip = false;
-    if (MASKED && a.out_mask) {
+    if (MASKED && !LIST && a.out_mask) {
         int any = 0;
         for (int i = tid; i < TH * TW; i += NT) {
             const int yy = y0 + i / TW, xx = x0 + i % TW;
@@ -311,8 +324,8 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         }
     };
 
-    const int c_begin = ks * a.chunks_per_split;
-    const int c_end = skip ? c_begin : min(c_begin + a.chunks_per_split, a.nchunks);
+    const int c_begin = ks * cps;
+    const int c_end = skip ? c_begin : min(c_begin + cps, a.nchunks);
     if (c_begin < c_end) {
         if (is_up(c_begin)) {
             static_for<NPB_L + T::NAV>([&](auto qc) { stage_up_piece(c_begin, lds, decltype(qc)::value); });
@@ -498,8 +511,8 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 #pragma unroll
         for (int e = 0; e < 32; ++e) keep[e >> 1][e & 1] += xch[((1 - HF) * 32 + e) * 64];
 
-        const bool final_out = (a.ksplit == 1);
-        float* ybase = a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
+        const bool final_out = (ks_n == 1);
+        float* ybase = (LIST && final_out) ? a.y_final + (size_t)b * a.Cout * plane2 : a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
         const bool vec_ok = (W & 3) == 0;
         auto store_rows = [&](auto act_tag) {   // ACT < 0: split-K partial sums (no bias, no activation)
             constexpr int ACT = decltype(act_tag)::value;
@@ -547,6 +560,12 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 template <int TH, int TW, int WN, int CK>
 void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s) {
     const bool masked = a.in_mask || a.out_mask;
+    if constexpr (wino32_has_list(TH, TW, WN, CK)) {
+        if (a.tile_list) {   // (the planner only offers list launches to pure layers on these tile shapes)
+            hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, false, true, true>), grid, dim3(WN * 128), 0, s, a);
+            return;
+        }
+    }
     if (!wino32_pure(a, CK)) hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, true, true>), grid, dim3(WN * 128), 0, s, a);
     else if (masked) hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, false, true>), grid, dim3(WN * 128), 0, s, a);
     else hipLaunchKernelGGL((conv_wino32_kernel<TH, TW, WN, CK, false, false>), grid, dim3(WN * 128), 0, s, a);

@@ -301,7 +301,12 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
     const int H = a.H, W = a.W;
     const size_t plane = (size_t)H * W;
     const size_t total = (size_t)a.B * plane;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // (the loop bound is wave-uniform: the tail lanes of the last wavefront run along masked out, so that the wavefront-wide
+    //  ballots / shuffles below see every lane)
+    const size_t total_w = (total + 63) / 64 * 64;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total_w; i0 += (size_t)gridDim.x * blockDim.x) {
+        const bool live = i0 < total;
+        const size_t i = live ? i0 : total - 1;
         const int x = i % W;
         const int y = (i / W) % H;
         const size_t b = i / plane;
@@ -319,25 +324,34 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
             okf[t] = ok ? 1.f : 0.f;
         }
         const float* tb = a.t + b * (a.yl_out ? 81 : 54) * plane;
-        float vp[27], vn[27];
+        // block-sparse levels: a pixel outside the wavelet mask has yh = 0 whatever its taps hold, and a wavefront without a
+        // single mask pixel skips the 54 gathers altogether (its tap-partial planes may never have been written:
+        // wmd_head_fused_args.run_mask)
+        const bool in_mask = !a.yh_mask || a.yh_mask[b * plane + (size_t)y * W + x] != 0;
+        const bool wave_any = __builtin_amdgcn_ballot_w64(in_mask && live) != 0;
+        float yh[3] = {0.f, 0.f, 0.f};
+        if (wave_any) {
+            float vp[27], vn[27];
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            vp[k] = tb[(size_t)k * plane + off[k % 9]];
-            vn[k] = tb[(size_t)(27 + k) * plane + off[k % 9]];
-        }
-        float yh[3];
-#pragma unroll
-        for (int co = 0; co < 3; ++co) {
-            float sp = a.bias_p ? a.bias_p[co] : 0.f, sn = a.bias_n ? a.bias_n[co] : 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                sp += okf[t] * vp[co * 9 + t];
-                sn += okf[t] * vn[co * 9 + t];
+            for (int k = 0; k < 27; ++k) {
+                vp[k] = tb[(size_t)k * plane + off[k % 9]];
+                vn[k] = tb[(size_t)(27 + k) * plane + off[k % 9]];
             }
-            const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
-            yh[co] = a.scale * a1 - a.scale * a2;
-            if (a.yh_mask && a.yh_mask[b * plane + (size_t)y * W + x] == 0) yh[co] = 0.f;
-            a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                float sp = a.bias_p ? a.bias_p[co] : 0.f, sn = a.bias_n ? a.bias_n[co] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    sp += okf[t] * vp[co * 9 + t];
+                    sn += okf[t] * vn[co * 9 + t];
+                }
+                const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
+                yh[co] = in_mask ? a.scale * a1 - a.scale * a2 : 0.f;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int co = 0; co < 3; ++co) a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
         }
         float l = 0.f;
         if (a.yl_out) {   // the low-pass head of the coarsest level: third chain of the fused launch, rows 54..62
@@ -345,13 +359,34 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) sl += okf[t] * tb[(size_t)(54 + t) * plane + off[t]];
             l = a.scale_ll / (1.f + expf(-sl));
-            a.yl_out[i] = l;
+            if (live) a.yl_out[i] = l;
         } else if (a.yl) {
             l = a.yl[i];
         }
         if ((a.yl || a.yl_out) && a.out) {
             float v[4] = {(l + yh[0] + yh[1] + yh[2]) * 0.5f, (l + yh[0] - yh[1] - yh[2]) * 0.5f,
                           (l - yh[0] + yh[1] - yh[2]) * 0.5f, (l - yh[0] - yh[1] + yh[2]) * 0.5f};
+            if (a.range_keys) {
+                // the range (min, max) of every frame's new low-pass plane for the next level's threshold: wavefront reduction,
+                // one atomic pair per wavefront (a wavefront that straddles two frames lets every lane speak for itself)
+                float lo = live ? fminf(fminf(v[0], v[1]), fminf(v[2], v[3])) : INFINITY;
+                float hi = live ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
+                const int b0 = __builtin_amdgcn_readfirstlane((int)b);
+                const bool uniform = __builtin_amdgcn_ballot_w64((int)b != b0) == 0;
+                if (uniform) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        lo = fminf(lo, __shfl_xor(lo, o));
+                        hi = fmaxf(hi, __shfl_xor(hi, o));
+                    }
+                }
+                if ((uniform ? (threadIdx.x & 63) == 0 : live) && lo <= hi) {
+                    const unsigned ul = __float_as_uint(lo), uh = __float_as_uint(hi);
+                    atomicMin(&a.range_keys[2 * b], (ul & 0x80000000u) ? ~ul : (ul | 0x80000000u));
+                    atomicMax(&a.range_keys[2 * b + 1], (uh & 0x80000000u) ? ~uh : (uh | 0x80000000u));
+                }
+            }
+            if (!live) continue;
             const size_t dst = b * 4 * plane + (size_t)(2 * y) * (2 * W) + 2 * x;
             *reinterpret_cast<float2*>(a.out + dst) = make_float2(v[0], v[1]);
             *reinterpret_cast<float2*>(a.out + dst + 2 * W) = make_float2(v[2], v[3]);

@@ -38,6 +38,7 @@ struct HeadChainArgs {
     float* t;            // [B, t_planes, plane]
     int plane, tiles, t_planes;
     float slope;
+    const uint8_t* run_mask;   // optional [B, plane]: a block whose pixel run holds no set byte returns (wmd_head_fused_args.run_mask)
 };
 
 template <int C, int RS, int PG, int NT, int KC>
@@ -107,6 +108,18 @@ __global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChain
     const int side = blockIdx.y;
     const int tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
     const int pix0 = tile * PXB, plane = a.plane;
+    if (a.run_mask) {   // block-sparse levels: nothing downstream reads the tap-partials of a run without an active pixel
+        static_assert(PXB <= T::NTH, "one mask byte per thread covers the block's pixel run");
+        __shared__ int run_any[T::NW];
+        const bool mine = tid < PXB && pix0 + tid < plane && a.run_mask[(size_t)b * plane + pix0 + tid] != 0;
+        const bool wave_any = __builtin_amdgcn_ballot_w64(mine) != 0;
+        if (lane == 0) run_any[wave] = wave_any ? 1 : 0;
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int w = 0; w < T::NW; ++w) all |= run_any[w];
+        if (all == 0) return;
+    }
     const float* xb = a.x + (size_t)b * C * plane;
     const float* w1 = a.wp1 + (size_t)side * T::MTS * KS * 64;   // fragments [row tile][K-step][64 lanes]
     const float* w2 = a.wp2 + (size_t)side * 2 * KS * 64;        // fragments [tap-row tile 0..1][K-step][64 lanes]
@@ -245,6 +258,7 @@ bool head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s
     a.tiles = 0;
     a.t_planes = t_planes;
     a.slope = g->slope;
+    a.run_mask = g->run_mask;
     const double pix = (double)g->B * plane;
     ProfScope prof("head_chain_kernel", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C), 4.0 * pix * (g->C + 54), s);
     // (pixel-tile / wave-count / chunk variants -- 64 to 256 pixels, 2 to 16 waves, channel split 1 / 2 / 4 / 8 -- all measured

@@ -70,6 +70,14 @@ __global__ void mask_threshold_kernel(const float* __restrict__ yh, const float*
 // 54 us per level at 12 frames).  Optional counts: the set pixels of a spec are added to spec.nnz[frame * nnz_stride] (one
 // atomic per wavefront and pass), which is all the block-sparse decoders need of a compaction.
 constexpr int ML_T = 16, ML_HALO = 3, ML_P = ML_T + 2 * ML_HALO;
+// work-list form (wmd_mask_level_lists): per spec the tile list / count column, per launch the scratch + ring protocol
+struct MaskListSpec {
+    int tile_h, tile_w;    // 0: no list
+    int32_t* tile_list;
+    int32_t* tile_count;
+    int count;             // k > 0: pixel count column k - 1
+    const uint8_t* and_mask;   // optional: out = dilation AND and_mask (wmd_level_spec.and_mask)
+};
 struct MaskLevelKArgs {
     const float* mm;       // optional [B,2] precomputed (min, max) of every frame's yl: skips the in-block reduction
     const float* yl;
@@ -78,17 +86,34 @@ struct MaskLevelKArgs {
     float ratio;
     int n_yl, h, w, n, tiles_x;
     wmd_dilate_spec s[8];
+    // ---- work-list form ----
+    unsigned* range_keys;  // optional [B][2] ordered keys of (min, max), consumed and re-armed
+    int32_t* scratch;      // non-null = work-list form
+    int32_t* ring;
+    int ring_slots, slot_ints, counts_off, ncounts, advance, B;
+    MaskListSpec ls[8];
 };
+// scratch layout (int32, all zero at rest): [0] ticket, [1] forward sequence number, [2 + spec] tile accumulators,
+// [kMlCnt0 + frame * 8 + column] pixel-count accumulators
+constexpr int kMlTicket = 0, kMlSeq = 1, kMlTile0 = 2, kMlCnt0 = 16;
+
+__device__ __forceinline__ float key_to_float(unsigned k) {   // inverse of wmd_head_shiftsum_args.range_keys' encoding
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
 
 // One spec over one tile: a pixel's window covers coarse rows cy0..cy1 (at most NC) and columns cx0..cx1; the OR over the
 // window is the OR of the rows' bit words masked to the column range -- NC LDS words per pixel, no inner loops (a wave64
 // VALU instruction takes four cycles: the per-cell loop of the first tiled version spent 8 k cycles per wavefront).
+// (tbits: bit k = work-list tile k of the block's region holds a set pixel; tile_h = 0: no list)
 template <int NC>
-__device__ __forceinline__ int mask_tile_spec(const wmd_dilate_spec& sp, const unsigned* rows, int f, int h, int w, int ty0, int tx0) {
+__device__ __forceinline__ int mask_tile_spec(const wmd_dilate_spec& sp, const unsigned* rows, int f, int h, int w, int ty0, int tx0,
+                                              int tile_h, int tile_w, unsigned& tbits, const uint8_t* and_mask) {
     const int up = sp.up, r = sp.radius, sh = up == 2 ? 1 : 0;
     const int H = h * up, W = w * up, lts = 4 + sh;     // log2 of the tile side in output pixels
     uint8_t* out = sp.out + (size_t)f * H * W;
+    if (and_mask) and_mask += (size_t)f * H * W;
     int cnt = 0;
+    const int ntx_l = tile_w ? (1 << lts) / tile_w : 1;
     for (int p = threadIdx.x; p < (1 << (2 * lts)); p += 256) {
         const int y = ty0 * up + (p >> lts), x = tx0 * up + (p & ((1 << lts) - 1));
         if (y < H && x < W) {
@@ -97,9 +122,11 @@ __device__ __forceinline__ int mask_tile_spec(const wmd_dilate_spec& sp, const u
             unsigned acc = 0;
 #pragma unroll
             for (int k = 0; k < NC; ++k) acc |= rows[min(cy0 + k, cy1)];
-            const uint8_t v = ((acc >> cx0) & ((2u << (cx1 - cx0)) - 1u)) != 0;
+            uint8_t v = ((acc >> cx0) & ((2u << (cx1 - cx0)) - 1u)) != 0;
+            if (and_mask && and_mask[(size_t)y * W + x] == 0) v = 0;
             out[(size_t)y * W + x] = v;
             cnt += v;
+            if (tile_h && v) tbits |= 1u << (((p >> lts) / tile_h) * ntx_l + (p & ((1 << lts) - 1)) / tile_w);
         }
     }
     return cnt;
@@ -119,7 +146,10 @@ __global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a)
     const uint8_t* mask0 = FROM_MASK ? a.mask0 + (size_t)f * npix : nullptr;
     if constexpr (!FROM_MASK) {
         float lo, hi;
-        if (a.mm) {          // batched decode: every block re-reducing its frame's whole LL plane was 40 us per level at 12 frames
+        if (a.range_keys) {  // the range the previous level's head epilogue left behind (re-armed by this launch's last block)
+            lo = key_to_float(a.range_keys[2 * f]);
+            hi = key_to_float(a.range_keys[2 * f + 1]);
+        } else if (a.mm) {   // batched decode: every block re-reducing its frame's whole LL plane was 40 us per level at 12 frames
             lo = a.mm[2 * f];
             hi = a.mm[2 * f + 1];
         } else {
@@ -170,14 +200,83 @@ __global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a)
     // blockIdx.z = spec: the specs of a tile run side by side (each block rebuilds the small base tile; at batch 1 a level
     // has 3 to 30 tiles and the launch is a latency chain, not a throughput problem)
     const wmd_dilate_spec sp = a.s[blockIdx.z];
+    const int lth = a.scratch ? a.ls[blockIdx.z].tile_h : 0, ltw = a.scratch ? a.ls[blockIdx.z].tile_w : 0;
+    const uint8_t* andm = a.scratch ? a.ls[blockIdx.z].and_mask : nullptr;
+    unsigned tbits = 0;
     int cnt = 0;
     switch (sp.up == 2 ? sp.radius + 1 : 2 * sp.radius + 1) {   // coarse rows a window can span (clamped re-reads are harmless)
-        case 1: cnt = mask_tile_spec<1>(sp, rows, f, h, w, ty0, tx0); break;
-        case 2: cnt = mask_tile_spec<2>(sp, rows, f, h, w, ty0, tx0); break;
-        case 3: cnt = mask_tile_spec<3>(sp, rows, f, h, w, ty0, tx0); break;
+        case 1: cnt = mask_tile_spec<1>(sp, rows, f, h, w, ty0, tx0, lth, ltw, tbits, andm); break;
+        case 2: cnt = mask_tile_spec<2>(sp, rows, f, h, w, ty0, tx0, lth, ltw, tbits, andm); break;
+        case 3: cnt = mask_tile_spec<3>(sp, rows, f, h, w, ty0, tx0, lth, ltw, tbits, andm); break;
         case 4:
-        case 5: cnt = mask_tile_spec<5>(sp, rows, f, h, w, ty0, tx0); break;
-        default: cnt = mask_tile_spec<7>(sp, rows, f, h, w, ty0, tx0); break;
+        case 5: cnt = mask_tile_spec<5>(sp, rows, f, h, w, ty0, tx0, lth, ltw, tbits, andm); break;
+        default: cnt = mask_tile_spec<7>(sp, rows, f, h, w, ty0, tx0, lth, ltw, tbits, andm); break;
+    }
+    if (a.scratch) {
+        // ---- work-list form: the block's pixel count and active-tile bits -> accumulators; the last block publishes --------
+        __shared__ int s_cnt, s_last;
+        __shared__ unsigned s_bits;
+        if (threadIdx.x == 0) {
+            s_cnt = 0;
+            s_bits = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o);
+            tbits |= (unsigned)__shfl_xor((int)tbits, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (cnt) atomicAdd(&s_cnt, cnt);
+            if (tbits) atomicOr(&s_bits, tbits);
+        }
+        __syncthreads();
+        const MaskListSpec ls = a.ls[blockIdx.z];
+        const unsigned bits = s_bits;
+        if (ls.tile_list && bits) {   // reserve a run of the list with one atomic; bit k's entry sits at popcount(bits below k)
+            __shared__ int s_base;
+            if (threadIdx.x == 0) s_base = atomicAdd(&a.scratch[kMlTile0 + blockIdx.z], __popc(bits));
+            __syncthreads();
+            const int k = threadIdx.x;
+            if (k < 32 && ((bits >> k) & 1u)) {
+                const int up = sp.up, R = ML_T * up, ntx_l = R / ls.tile_w;
+                const int gty = (ty0 * up) / ls.tile_h + k / ntx_l, gtx = (tx0 * up) / ls.tile_w + k % ntx_l;
+                const int tiles_xg = (w * up + ls.tile_w - 1) / ls.tile_w, tiles_yg = (h * up + ls.tile_h - 1) / ls.tile_h;
+                ls.tile_list[s_base + __popc(bits & ((1u << k) - 1u))] = (f * tiles_yg + gty) * tiles_xg + gtx;
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (ls.count && s_cnt) atomicAdd(&a.scratch[kMlCnt0 + f * 8 + ls.count - 1], s_cnt);
+            __threadfence();   // this block's atomics and list entries before its ticket
+            const int total = gridDim.x * gridDim.y * gridDim.z;
+            s_last = atomicAdd(&a.scratch[kMlTicket], 1) == total - 1;
+        }
+        __syncthreads();
+        if (s_last) {          // every other block has drawn its ticket: all accumulators are final
+            __threadfence();
+            const int seq = __hip_atomic_load(&a.scratch[kMlSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int32_t* slot = a.ring ? a.ring + (size_t)(seq % max(a.ring_slots, 1)) * a.slot_ints : nullptr;
+            for (int i = threadIdx.x; i < a.B * a.ncounts; i += 256) {
+                const int v = atomicExch(&a.scratch[kMlCnt0 + (i / a.ncounts) * 8 + i % a.ncounts], 0);
+                if (slot) slot[1 + a.counts_off + i] = v;
+            }
+            if (threadIdx.x == 0)   // (uniform index: a per-thread index into the by-value argument block would become scratch memory)
+                for (int i = 0; i < a.n; ++i)
+                    if (a.ls[i].tile_list) *a.ls[i].tile_count = atomicExch(&a.scratch[kMlTile0 + i], 0);
+            if (a.range_keys)
+                for (int i = threadIdx.x; i < a.B; i += 256) {
+                    a.range_keys[2 * i] = 0xFFFFFFFFu;
+                    a.range_keys[2 * i + 1] = 0u;
+                }
+            if (threadIdx.x == 0) {
+                atomicExch(&a.scratch[kMlTicket], 0);
+                if (a.advance) {
+                    if (slot) slot[0] = seq + 1;
+                    atomicExch(&a.scratch[kMlSeq], seq + 1);
+                }
+            }
+        }
+        return;
     }
     if (sp.nnz) {   // one atomic per block: a frame's blocks all add to the same word
         __shared__ int blk_cnt;
@@ -599,6 +698,68 @@ extern "C" int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, f
     const double maxpix = (double)h * up * w * up;
     ProfScope prof("mask_level_kernel", 25.0 * maxpix * n * B, (2.0 * maxpix * n + 16.0 * h * w) * B, (hipStream_t)stream);
     hipLaunchKernelGGL(mask_level_kernel<false>, dim3(a.tiles_x * ((h + ML_T - 1) / ML_T), B, n), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("mask_level_kernel");
+}
+
+extern "C" size_t wmd_mask_level_scratch_ints(int B) { return B > 0 ? (size_t)kMlCnt0 + 8 * (size_t)B : 0; }
+
+extern "C" int wmd_mask_level_lists(const wmd_mask_level_args* g, void* stream) {
+    if (!g || !g->specs || !g->scratch) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level_lists: null pointer");
+    if (g->B <= 0 || g->B > 65535 || g->h <= 0 || g->w <= 0 || g->n <= 0 || g->n > 8)
+        return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level_lists: B=%d h=%d w=%d n=%d", g->B, g->h, g->w, g->n);
+    if (!g->mask0 && (!g->yl || !g->yh)) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level_lists: neither a base mask nor yl / yh");
+    if (!g->mask0 && (g->n_yl == 0 || g->n_yl > (size_t)1 << 24)) return fail(WMD_ERR_BAD_SHAPE, "wmd_mask_level_lists: n_yl=%zu", g->n_yl);
+    if (g->ncounts < 0 || g->ncounts > 8) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level_lists: ncounts=%d", g->ncounts);
+    if (g->ncounts > 0 && g->counts &&
+        (g->ring_slots <= 0 || g->counts_off < 0 || 1 + g->counts_off + g->B * g->ncounts > g->slot_ints))
+        return fail(WMD_ERR_BAD_ARG, "wmd_mask_level_lists: counts do not fit a ring slot (off %d + %d x %d > %d ints)", g->counts_off,
+                    g->B, g->ncounts, g->slot_ints - 1);
+    MaskLevelKArgs a;
+    memset(&a, 0, sizeof(a));
+    wmd_dilate_spec plain[8];
+    for (int i = 0; i < g->n; ++i) {
+        const wmd_level_spec& sp = g->specs[i];
+        plain[i] = wmd_dilate_spec{sp.up, sp.radius, sp.out, nullptr, 0};
+        if (sp.count < 0 || sp.count > g->ncounts) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level_lists: spec %d count column %d", i, sp.count);
+        if (sp.tile_h || sp.tile_w) {
+            const int R = ML_T * sp.up;
+            if (sp.tile_h <= 0 || sp.tile_w <= 0 || R % sp.tile_h || R % sp.tile_w || (R / sp.tile_h) * (R / sp.tile_w) > 32)
+                return fail(WMD_ERR_UNSUPPORTED, "wmd_mask_level_lists: spec %d: %dx%d tiles do not nest in a %dx%d region (<= 32 of them)",
+                            i, sp.tile_h, sp.tile_w, R, R);
+            if (!sp.tile_list || !sp.tile_count) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level_lists: spec %d asks for a tile list without buffers", i);
+        }
+        a.ls[i] = MaskListSpec{sp.tile_h, sp.tile_w, sp.tile_list, sp.tile_count, sp.count, sp.and_mask};
+    }
+    int up;
+    if (int st = mask_specs_ok("wmd_mask_level_lists", plain, g->n, &up)) return st;
+    for (int i = 0; i < g->n; ++i) a.s[i] = plain[i];
+    a.mask0 = g->mask0;
+    a.yl = g->yl;
+    a.yh = g->yh;
+    a.mm = g->minmax;
+    a.range_keys = g->range_keys;   // (an injected mask does not read them, but its last block re-arms them all the same)
+    a.ratio = g->thresh_ratio;
+    a.n_yl = (int)g->n_yl;
+    a.h = g->h;
+    a.w = g->w;
+    a.n = g->n;
+    a.tiles_x = (g->w + ML_T - 1) / ML_T;
+    a.scratch = g->scratch;
+    a.ring = g->ncounts > 0 ? g->counts : nullptr;
+    a.ring_slots = g->ring_slots;
+    a.slot_ints = g->slot_ints;
+    a.counts_off = g->counts_off;
+    a.ncounts = g->ncounts;
+    a.advance = g->advance;
+    a.B = g->B;
+    const double maxpix = (double)g->h * up * g->w * up;
+    ProfScope prof("mask_level_kernel", 25.0 * maxpix * g->n * g->B, (2.0 * maxpix * g->n + 16.0 * g->h * g->w) * g->B, (hipStream_t)stream);
+    const dim3 grid(a.tiles_x * ((g->h + ML_T - 1) / ML_T), g->B, g->n);
+    if (g->mask0) {
+        hipLaunchKernelGGL(mask_level_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(mask_level_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     return check_launch("mask_level_kernel");
 }
 

@@ -102,6 +102,7 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         self._edge = None
         self._side = None          # stream of the activation-pool fill
         self._ones = {}            # all-ones mask constants of the coarsest level, per (device, B, h, w)
+        self._states = {}          # sparse_ops.LevelState of the work-list form, per input signature
 
     # ------------------------------------------------------------------------------------------
     def _dense_coefficients(self, x, i, with_ll):
@@ -135,6 +136,8 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         per (inputs, threshold, scales) and replay it; only the python-int op model is computed on the host after."""
         self._graph_mode = bool(on)
         self._graphs.clear()
+        self._states.clear()
+        self._ones.clear()
         return self
 
     @torch.no_grad()
@@ -145,22 +148,74 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         # output equals the batch-1 result, and the `total_ops` entries become lists with one integer per frame.
         input_features, edge = split_edge(input_features)       # encoder edge: the last feature may be a pre-activation
         self._edge = edge
+        S._on_gpu(*input_features)      # fails loudly on CPU tensors: there is no fallback path
         forced_on_device = _force_masks is None or all(m.is_cuda for m in _force_masks.values())
-        if self._graph_mode and forced_on_device:
+        graph = self._graph_mode and forced_on_device
+        state = self._level_state(input_features, sparse_scales, _force_masks, graph)
+        if state is not None:
+            state.before_forward()
+        if graph:
             thr, scales = float(thresh_ratio), tuple(sparse_scales)
             lv = sorted(_force_masks) if _force_masks else []      # injected masks are live inputs of the graph too
             nf = len(input_features)
-            res = self._graphs.run(lambda f: self._device_chain(f[:nf], thr, scales, dict(zip(lv, f[nf:])) if lv else None),
+            res = self._graphs.run(lambda f: self._device_chain(f[:nf], thr, scales, dict(zip(lv, f[nf:])) if lv else None, state),
                                    list(input_features) + [_force_masks[i] for i in lv], self.parameters(),
-                                   extra_key=(thr, scales, tuple(lv)) + (("edge",) + edge.key() if edge is not None else ()))
+                                   extra_key=(thr, scales, tuple(lv), state is not None) + (("edge",) + edge.key() if edge is not None else ()))
             out, counters, static_ops = dict(res[0]), res[1], res[2]
+            if state is not None:
+                state.seq += 1          # the replay (the warm-up executions of a capture counted themselves)
         else:
-            out, counters, static_ops = self._device_chain(input_features, thresh_ratio, sparse_scales, _force_masks)
-        res = self._host_op_model(out, counters, static_ops)
+            out, counters, static_ops = self._device_chain(input_features, thresh_ratio, sparse_scales, _force_masks, state)
+        res = self._host_op_model(out, counters, static_ops, state)
         self.outputs = res      # depth_decoder.py:293,379,423,427: the op counts live in self.outputs too
         return res
 
-    def _device_chain(self, input_features, thresh_ratio, sparse_scales, _force_masks):
+    # ------------------------------------------------------------------------------------------
+    def _lists_ok(self, sparse_scales, _force_masks):
+        """The work-list form (default) serves the tile form when the sparse levels are the finest ones (a dense level BELOW a
+        sparse one would read the never-refilled activation pool), every sparse level's heads run on the fused kernels and
+        level 4 is not injected.  WMD_SPARSE_LISTS=0: the round-3 tile form (pool fill + per-block mask tests + count copy)."""
+        if os.environ.get("WMD_SPARSE_LISTS", "1") == "0" or not self._block_sparse(0) or not self.use_skips:
+            return False
+        if _force_masks is not None and 4 in _force_masks:
+            return False
+        lv = sorted(i for i in set(sparse_scales) if 1 <= i <= 3)
+        if not lv or lv != list(range(1, lv[-1] + 1)):
+            return False
+        widths = [int(self.convs[("upconv", i, 1)].conv.conv.weight.shape[0]) for i in lv]
+        return all(wd in ops.FUSED_HEAD_WIDTHS and wd % 8 == 0 for wd in widths) and int(self.num_ch_dec[4]) in ops.FUSED_HEAD_WIDTHS
+
+    def _level_state(self, input_features, sparse_scales, _force_masks, graph):
+        """The persistent device state of the work-list form for this input signature (None: another form runs).  In graph
+        mode one state per captured graph (keyed like the graph: the captured launches hold its pointers; kept alive by the
+        graph entry), else one per (stream, shapes)."""
+        if not self._lists_ok(sparse_scales, _force_masks):
+            return None
+        x = input_features[-1]
+        B, dev = x.shape[0], x.device
+        lv = sorted(i for i in set(sparse_scales) if 1 <= i <= 3)
+        shapes = tuple(tuple(f.shape) for f in input_features)
+        if graph:
+            key = ("g", tuple(f.data_ptr() for f in input_features), shapes, tuple(lv))
+        else:
+            key = ("e", torch.cuda.current_stream(dev).cuda_stream, shapes, tuple(lv))
+        st = self._states.get(key)
+        if st is None:
+            if len(self._states) >= 64:
+                self._states.clear()
+                self._graphs.clear()       # captured launches hold the states' pointers
+            pool_floats = 0
+            for i in lv:
+                hh, ww = input_features[i].shape[-2:]
+                c0, c1 = (self.convs[("upconv", i, j)].conv.conv.weight.shape[0] for j in (0, 1))
+                pool_floats += _round64(B * c0 * hh * ww) + _round64(B * c1 * 4 * hh * ww)
+            st = S.LevelState(dev, B, len(lv), pool_floats)
+            self._states[key] = st
+        return st
+
+    def _device_chain(self, input_features, thresh_ratio, sparse_scales, _force_masks, state=None):
+        if state is not None:
+            return self._device_chain_lists(input_features, thresh_ratio, sparse_scales, _force_masks, state)
         out = {}
         S._on_gpu(*input_features)      # fails loudly on CPU tensors: there is no fallback path
         x = input_features[-1].contiguous()
@@ -358,12 +413,145 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 break
         return out, counters, static_ops
 
+    def _device_chain_lists(self, input_features, thresh_ratio, sparse_scales, _force_masks, state):
+        """The work-list form of the sparse levels (round 4).  Per level: ONE mask launch (threshold from the range keys the
+        previous level's head epilogue left behind, the five masks, the active-tile lists of both trunk convolutions, the
+        pixel counts into the ring) -> upconv(i,0) and upconv(i,1) over the listed tiles only, K split chosen on the device
+        -> the fused head kernels, skipping pixel runs / wavefronts without an active pixel.  No pool fill, no count copy."""
+        out = {}
+        S._on_gpu(*input_features)
+        x = input_features[-1].contiguous()
+        dev, B = x.device, x.shape[0]
+        lv = sorted((i for i in set(sparse_scales) if 1 <= i <= 3), reverse=True)
+        capturing = torch.cuda.is_current_stream_capturing()
+        pool_used = [0]
+
+        def plane(*shape):
+            n = int(np.prod(shape))
+            v = state.pool[pool_used[0]:pool_used[0] + n].view(*shape)
+            pool_used[0] += _round64(n)
+            return v
+
+        th, tw = (int(v) for v in os.environ.get("WMD_SPARSE_TILE", "8x16").split("x"))
+        unpack = lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias)
+        counters, static_ops = [], {}
+        yl = yh = None
+        xbuf = None
+        keys_armed = False      # the head of the level above folded its LL range into state.keys
+        prev_upconv1 = None     # upconv1 mask of the sparse level above (= the support of the activations this level reads)
+        for i in range(4, 0, -1):
+            h, w = x.shape[-2:] if xbuf is None else xbuf.shape[-2:]
+            H2, W2 = 2 * h, 2 * w
+            c0, c1 = self.convs[("upconv", i, 0)].conv.conv, self.convs[("upconv", i, 1)].conv.conv
+            forced = _force_masks is not None and i in _force_masks
+            next_sparse = (i - 1) in lv
+            want_keys = next_sparse and not (_force_masks is not None and (i - 1) in _force_masks)
+            if i in lv:
+                k = lv.index(i)
+                specs = [(1, 1, 0, None), (1, 2, 1, (th, tw)), (2, 2, 0, None), (2, 1, 2, (th, tw)), (2, 0, 3, None)]
+                if prev_upconv1 is not None:     # input support of upconv(i,0): lowres AND the previous sparse level's support
+                    specs.append((1, 1, 0, None, prev_upconv1))
+                if forced:
+                    m0 = _force_masks[i].to(dev).reshape(-1, h, w).to(torch.uint8)
+                    if m0.shape[0] != B:
+                        m0 = m0.expand(B, h, w)
+                    masks, lists = S.mask_level_lists(state, B, h, w, specs, mask0=m0, use_keys=keys_armed, counts_off=k * B * 3,
+                                                      advance=(i == lv[-1]))
+                else:
+                    masks, lists = S.mask_level_lists(state, B, h, w, specs, thresh_ratio, yl=yl, yh=yh, use_keys=keys_armed,
+                                                      counts_off=k * B * 3, advance=(i == lv[-1]))
+                lowres, upconv0, upsample_m, upconv1, wavelet = masks[:5]
+                lowres_in = masks[5] if prev_upconv1 is not None else lowres
+                src = xbuf if xbuf is not None else x
+                C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
+                x0 = plane(B, C0, h, w)
+                x1 = plane(B, C1_, H2, W2)
+                skip = input_features[i - 1].contiguous()
+                ops._conv_fwd_raw(src, None, ops.pack_weights(c0.weight), c0.bias, C0, 3, "reflect", "elu", 0.0, 1,
+                                  ops.pack_weights_wino(c0.weight), in_mask=lowres_in, out_mask=upconv0, out=x0, out_tiles=lists[1])
+                ops._conv_fwd_raw(x0, skip, ops.pack_weights(c1.weight), c1.bias, C1_, 3, "reflect", "elu", 0.0, 2,
+                                  ops.pack_weights_wino(c1.weight), in_mask=upsample_m, out_mask=upconv1, out=x1,
+                                  in_mask_2x2=True, out_tiles=lists[3])
+                hp, hn = self.convs[("waveconv", i, 1)], self.convs[("waveconv", i, -1)]
+                fold = want_keys and ops.head_level_folds_range_keys(C1_)
+                yh, yl_next, disp_i = ops.head_fused_level_nograd(x1, unpack(hp), unpack(hn), scale=2.0 ** (i - 1), yl=yl,
+                                                                  disp_scale=1.0 / 2 ** (i - 1), clamp01=True, yh_mask=wavelet,
+                                                                  run_mask=upconv1, range_keys=state.keys if fold else None)
+                keys_armed = fold
+                prev_upconv1 = upconv1
+                static_ops[i] = level_static_ops(i, h, w, True)
+                counters.append((i, None, (c0.weight.shape[1], C0), (c1.weight.shape[1], C1_),
+                                 (hp[0].conv.weight.shape[1], hp[0].conv.weight.shape[0]), (hp[2].conv.weight.shape[1], 3)))
+                xbuf = x1
+            else:
+                # dense level (the coarsest one, and any level above the first sparse one)
+                if i == 4:
+                    ones = self._ones.get((dev, B, h, w))
+                    if ones is None:
+                        ones = self._ones[(dev, B, h, w)] = torch.ones(B * (2 * h * w + 3 * 4 * h * w), device=dev, dtype=torch.uint8)
+                    lowres, upconv0 = ones[:B * h * w].view(B, h, w), ones[B * h * w:2 * B * h * w].view(B, h, w)
+                    o4 = 2 * B * h * w
+                    upsample_m, upconv1, wavelet = (ones[o4 + k * 4 * B * h * w:o4 + (k + 1) * 4 * B * h * w].view(B, H2, W2)
+                                                    for k in range(3))
+                else:
+                    SPECS = [(1, 1), (1, 2), (2, 2), (2, 1), (2, 0)]
+                    if forced:
+                        m0 = _force_masks[i].to(dev).reshape(-1, h, w).to(torch.uint8)
+                        if m0.shape[0] != B:
+                            m0 = m0.expand(B, h, w)
+                        lowres, upconv0, upsample_m, upconv1, wavelet = S.dilate_multi(m0.contiguous(), SPECS)
+                    else:
+                        lowres, upconv0, upsample_m, upconv1, wavelet = [m.reshape(B, *m.shape[-2:]) for m in
+                                                                         S.mask_level(yl, yh, thresh_ratio, SPECS)]
+                src = xbuf if xbuf is not None else x
+                if xbuf is None and getattr(self, "_edge", None) is not None:
+                    xd = ops.conv2d_pre_activated(src, self._edge.pre(), c0.weight, c0.bias, pad="reflect", act="elu")
+                else:
+                    xd = ops.conv2d_fused(src, c0.weight, c0.bias, pad="reflect", act="elu")
+                skip = input_features[i - 1]
+                ux = ops.conv2d_fused(xd, c1.weight, c1.bias, x2=skip, up1=2, pad="reflect", act="elu")
+                hds = [self.convs[("waveconv", i, j)] for j in ([0] if i == 4 else []) + [-1, 1]]
+                static_ops[i] = level_static_ops(
+                    i, h, w, False, ((src.shape[1], c0.weight.shape[0]), (xd.shape[1] + skip.shape[1], c1.weight.shape[0])),
+                    [(hd[0].conv.weight.shape[1], hd[0].conv.weight.shape[0], hd[2].conv.weight.shape[1],
+                      hd[2].conv.weight.shape[0]) for hd in hds])
+                fold = want_keys and ops.head_level_folds_range_keys(ux.shape[1])
+                res = ops.head_fused_level_nograd(
+                    ux, unpack(self.convs[("waveconv", i, 1)]), unpack(self.convs[("waveconv", i, -1)]), scale=2.0 ** (i - 1),
+                    yl=None if i == 4 else yl, disp_scale=1.0 / 2 ** (i - 1), clamp01=True,
+                    head_ll=unpack(self.convs[("waveconv", 4, 0)]) if i == 4 else None, scale_ll=2.0 ** 4,
+                    yh_mask=None if i == 4 else wavelet.contiguous(), range_keys=state.keys if fold else None)
+                keys_armed = fold
+                if i == 4:
+                    yh, yl_next, disp_i, yl = res
+                else:
+                    yh, yl_next, disp_i = res
+                xbuf = ux
+            b = lambda m: m.view(torch.bool).reshape(B, 1, *m.shape[-2:])
+            out[("lowres_mask", i - 1)] = b(lowres)
+            out[("upconv0_mask", i - 1)] = b(upconv0)
+            out[("upsample_mask", i - 1)] = b(upsample_m)
+            out[("upconv1_mask", i - 1)] = b(upconv1)
+            out[("wavelet_mask", i - 1)] = b(wavelet)
+            out[("wavelets", i - 1, "LL")] = yl
+            out[("wavelets", i - 1, "LH")] = yh[:, :, 0]
+            out[("wavelets", i - 1, "HL")] = yh[:, :, 1]
+            out[("wavelets", i - 1, "HH")] = yh[:, :, 2]
+            out[("disp", i - 1)] = disp_i
+            yl = yl_next
+        if not capturing:
+            state.seq += 1      # an eager execution advanced the device's forward counter (a capture executes nothing)
+        return out, counters, static_ops
+
     @staticmethod
-    def _host_op_model(out, counters, static_ops):
+    def _host_op_model(out, counters, static_ops, state=None):
         # ---- the reference's op model needs the pixel counts as python ints.  They are copied to pinned host memory
         # asynchronously and turned into the `total_ops` entries on first access: the forward itself never waits for the GPU
         out = S.LazyOpsDict(out)
-        fetch = S.counts_to_host([nnz for (_lvl, nnz, *_rest) in counters])
+        if state is not None:      # work-list form: the counts wait in the ring slot of this forward (number state.seq - 1)
+            fetch = state.counts_fetcher(state.seq - 1)
+        else:
+            fetch = S.counts_to_host([nnz for (_lvl, nnz, *_rest) in counters])
         levels = [lvl for (lvl, *_rest) in counters]
 
         def resolver():

@@ -194,9 +194,11 @@ def pack_weights_wino(weight, dgrad=False):
 # ---------------------------------------------------------------------------------------------
 
 def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None, in_mask=None, out_mask=None, out=None,
-                  in_mask_2x2=False, x1_pre=None):
+                  in_mask_2x2=False, x1_pre=None, out_tiles=None):
     """in_mask / out_mask (uint8 [B,H,W]) + out (zero-initialised [B,cout,H,W]): block-sparse execution, see
     wmd_conv_args.in_mask in include/wmd.h; in_mask_2x2: the caller's promise that in_mask is constant on 2x2 blocks.
+    out_tiles = (list int32, count int32 scalar, tile_h, tile_w): the work-list form (wmd_conv_args.out_tiles, built by
+    sparse_ops.mask_level_lists) -- only listed tiles are computed, the split of the reduction is chosen on the device.
     x1_pre = (scale [C1] or None, shift [C1] or None, act, slope): x1 is read through act(x1 * scale + shift)
     (wmd_conv_args.x1_pre_act: the encoder edge)."""
     l = _lib.lib()
@@ -212,6 +214,9 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
                       slope=float(slope), x1=ptr(x1), x2=ptr(x2), wp=ptr(wp), bias=ptr(bias), y=ptr(y),
                       workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, wp_wino=ptr(wp_wino),
                       in_mask=ptr(in_mask), out_mask=ptr(out_mask), in_mask_2x2=int(bool(in_mask_2x2)))
+    if out_tiles is not None:
+        tl, tc, th, tw = out_tiles
+        a.out_tiles, a.out_tile_count, a.out_tile_h, a.out_tile_w = ptr(tl), ptr(tc), int(th), int(tw)
     if x1_pre is not None:
         psc, psh, pact, pslope = x1_pre
         _require_gpu(psc, psh)
@@ -235,7 +240,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
         return l.wmd_conv_fwd(C.byref(a), stream)
 
     choice = (0, 0)
-    if tuner.enabled:
+    if tuner.enabled and out_tiles is None:     # (a work list fixes the tile shape; the K split is the device's decision)
         key = "conv|%d|%d|%d|%d|%d|%d|%d|%d" % (B, H, W, C1, up1, C2, cout, ksize)  # str: JSON-cacheable
         if x1_pre is not None:
             key += "|pre"      # encoder edge: its own instantiations of the direct kernel
@@ -821,8 +826,14 @@ _TWO_LAUNCH_HEAD = os.environ.get("WMD_TWO_LAUNCH_HEAD", "0") == "1"   # develop
 _LL_FOLD = os.environ.get("WMD_LL_FOLD", "1") != "0"                   # 0: the low-pass head on its own three launches
 
 
+def head_level_folds_range_keys(C_):
+    """True when head_fused_level_nograd(range_keys=...) at this width runs the two-launch form, whose second launch maintains
+    the keys (the one-launch kernel of the finest level has no level after it that could want them)."""
+    return not (bool(_lib.lib().wmd_head_level_supported(int(C_))) and not _TWO_LAUNCH_HEAD)
+
+
 def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False, head_ll=None, scale_ll=1.0,
-                            yh_mask=None):
+                            yh_mask=None, run_mask=None, range_keys=None):
     """Inference form of one level's high-frequency heads + (optionally) the Haar IDWT in one launch (C = 32:
     wmd_head_level_fwd, every intermediate in LDS) or two: wmd_head_fused_fwd (1x1 -> LeakyReLU -> 27 tap-partials per
     side, intermediate stays on chip) and wmd_head_shiftsum_fwd (9-tap gather, bias, sigmoid, combine, IDWT).
@@ -830,6 +841,9 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
     it is a small third launch of the same fused kernel (tap-partials into planes 54..62 of the shared buffer) that the
     shift-sum completes and feeds to the synthesis as its low-pass input (yl must be None); other widths: own operators.
     yh_mask (uint8 [B,H,W]): yh is zeroed outside it before the store and the synthesis (depth_decoder.py:272).
+    run_mask (uint8 [B,H,W], two-launch form): pixel runs without a set byte skip the GEMMs (wmd_head_fused_args.run_mask);
+    range_keys (int32 [B,2], two-launch form): the (min, max) of the new low-pass plane are folded into it by the second
+    launch's epilogue (wmd_head_shiftsum_args.range_keys) -- returns None for them when the one-launch kernel ran.
     Returns (yh [B,1,3,H,W], out or None, disp or None[, yl_ll [B,1,H,W] when head_ll is given])."""
     l = _lib.lib()
     x = _c(x)
@@ -867,7 +881,7 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
         planes = 81 if head_ll is not None else 54
         t = torch.empty((B, planes, H, W), device=x.device, dtype=torch.float32)
         a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t),
-                               chain=0, t_planes=planes)
+                               chain=0, t_planes=planes, run_mask=ptr(run_mask))
         check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
         if head_ll is not None:     # the low-pass chain: a small second launch over the same x into planes 54..62
             wpl1, wpl2 = _ll_chain_pack(w1l, w3l)
@@ -879,7 +893,8 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
                                   bias_n=ptr(b3n), yh=ptr(yh), yl=ptr(yl), out=ptr(out), disp=ptr(disp),
                                   disp_scale=float(disp_scale or 1.0), clamp01=int(clamp01),
                                   bias_ll=ptr(b3l) if head_ll is not None else None, scale_ll=float(scale_ll),
-                                  yl_out=ptr(yl_ll) if head_ll is not None else None, yh_mask=ptr(yh_mask))
+                                  yl_out=ptr(yl_ll) if head_ll is not None else None, yh_mask=ptr(yh_mask),
+                                  range_keys=ptr(range_keys) if out is not None else None)
         check(l.wmd_head_shiftsum_fwd(C.byref(g), s), "wmd_head_shiftsum_fwd")
     if yl_ll is not None:
         return yh.unsqueeze(1), out, disp, yl_ll

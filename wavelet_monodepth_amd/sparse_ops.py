@@ -82,6 +82,108 @@ def mask_level(yl, yh, thresh_ratio, specs, counts=None):
     return outs
 
 
+class LevelState:
+    """Device-side state of the work-list form of the sparse levels (wmd_mask_level_lists), private to one decoder and one
+    input signature, used in stream order:
+      scratch  accumulators + ticket + forward counter of the mask launches (all zero at rest, never refilled),
+      ring     RING slots of pixel counts: forward k's counts are published to slot k % RING by the mask launches' last
+               workgroups and stamped k + 1 -- fetched only if somebody reads `total_ops` (no fill, no copy, no sync in a forward),
+      keys     order-preserving (min, max) keys of every frame's low-pass plane, maintained by the head epilogues,
+      pool     the activation planes of the sparse levels: zero-filled ONCE.  A tile the block-sparse kernels skip keeps the
+               (finite) values of an earlier forward; nothing reads them -- every consumer masks its reads or selects on
+               its mask (wmd_conv_args.in_mask, wmd_head_shiftsum_args.yh_mask)."""
+    RING = 64
+
+    def __init__(self, dev, B, n_levels, pool_floats):
+        self.B, self.n_levels = B, n_levels
+        self.scratch = torch.zeros(int(_lib.lib().wmd_mask_level_scratch_ints(B)), device=dev, dtype=torch.int32)
+        self.slot_ints = 1 + max(n_levels, 1) * B * 3
+        self.ring = torch.zeros(self.RING * self.slot_ints, device=dev, dtype=torch.int32)
+        self.keys = torch.tensor([[-1, 0]] * B, device=dev, dtype=torch.int32)      # 0xFFFFFFFF, 0: the armed state
+        self.pool = torch.zeros(max(int(pool_floats), 1), device=dev, dtype=torch.float32)
+        self.lists = {}
+        self.seq = 0               # host mirror of the device's forward counter
+        self.pending = {}          # ring slot -> weak reference to the fetch of the forward that used it last
+
+    def tile_list(self, key, capacity):
+        hit = self.lists.get(key)
+        if hit is None or hit[0].numel() < capacity:
+            dev = self.scratch.device
+            hit = self.lists[key] = (torch.zeros(max(int(capacity), 1), device=dev, dtype=torch.int32),
+                                     torch.zeros(1, device=dev, dtype=torch.int32))
+        return hit
+
+    def counts_fetcher(self, k):
+        """-> callable returning forward k's [n_levels][B*3] counts (python ints); to be called after forward k was
+        enqueued.  The slot is read when the counts are wanted; a forward RING later would overwrite it, so the fetch of
+        forward k is forced (cheaply: that forward is long complete) when forward k + RING is about to start."""
+        import weakref
+        ev = torch.cuda.Event()
+        ev.record()
+        slot = k % self.RING
+        box = {}
+        ring, slot_ints, n_levels, B = self.ring, self.slot_ints, self.n_levels, self.B
+
+        def fetch():
+            if "v" not in box:
+                ev.synchronize()
+                vals = ring[slot * slot_ints:(slot + 1) * slot_ints].cpu().tolist()
+                if vals[0] != k + 1:
+                    raise _lib.WmdError("sparse decoder: the pixel counts of forward %d are gone (ring slot stamped %d): "
+                                        "read total_ops within %d forwards" % (k, vals[0] - 1, LevelState.RING))
+                box["v"] = [[int(v) for v in vals[1 + l * B * 3:1 + (l + 1) * B * 3]] for l in range(n_levels)]
+            return box["v"]
+        self.pending[slot] = weakref.ref(fetch)
+        return fetch
+
+    def before_forward(self):
+        """Called when forward number self.seq is about to be enqueued: the slot it will publish to must have been read."""
+        for ahead in range(3):       # (a graph capture executes two warm-up forwards before the replay)
+            old = self.pending.pop((self.seq + ahead) % self.RING, None)
+            fetch = old() if old is not None else None
+            if fetch is not None:
+                fetch()
+
+
+def mask_level_lists(state, B, h, w, specs, thresh_ratio=0.0, yl=None, yh=None, mask0=None, use_keys=False, counts_off=0,
+                     advance=False):
+    """One launch: threshold (or injected base mask [B,h,w]) -> every dilated variant + the active-tile work lists + the
+    pixel counts, see wmd_mask_level_lists in include/wmd.h.  specs = [(up, radius, count column or 0, (tile_h, tile_w) or
+    None[, and_mask uint8 [B,h*up,w*up]]), ...] -> (masks [B,h*up,w*up] uint8, lists [(list, count, tile_h, tile_w) or None])."""
+    _on_gpu(yl, yh, mask0)
+    dev = state.scratch.device
+    outs, lists, arr = [], [], []
+    ncounts = 0
+    for j, spec in enumerate(specs):
+        up, r, col, tile = spec[:4]
+        andm = spec[4] if len(spec) > 4 else None
+        if andm is not None and (andm.dtype != torch.uint8 or andm.numel() != B * h * up * w * up or not andm.is_contiguous()):
+            raise _lib.WmdError("mask_level_lists: and_mask must be a contiguous uint8 [B,%d,%d] tensor" % (h * up, w * up))
+        o = torch.empty((B, h * up, w * up), device=dev, dtype=torch.uint8)
+        outs.append(o)
+        ncounts = max(ncounts, col)
+        if tile is not None:
+            th, tw = tile
+            tl, tc = state.tile_list((h * up, w * up, th, tw, j), B * (-(-h * up // th)) * (-(-w * up // tw)))
+            lists.append((tl, tc, th, tw))
+            arr.append(_lib.LevelSpec(up, r, ptr(o), col, th, tw, ptr(tl), ptr(tc), ptr(andm)))
+        else:
+            lists.append(None)
+            arr.append(_lib.LevelSpec(up, r, ptr(o), col, 0, 0, None, None, ptr(andm)))
+    if mask0 is not None:
+        mask0 = mask0.contiguous()
+    else:
+        yl, yh = yl.contiguous(), yh.contiguous()
+    a = _lib.MaskLevelArgs(B=B, h=h, w=w, yl=ptr(yl), n_yl=(yl.numel() // B) if yl is not None else 0, yh=ptr(yh),
+                           thresh_ratio=float(thresh_ratio), mask0=ptr(mask0), minmax=None,
+                           range_keys=ptr(state.keys) if use_keys else None,
+                           specs=(_lib.LevelSpec * len(arr))(*arr), n=len(arr), scratch=ptr(state.scratch), counts=ptr(state.ring),
+                           ring_slots=state.RING, slot_ints=state.slot_ints, counts_off=int(counts_off), ncounts=ncounts,
+                           advance=int(bool(advance)))
+    check(_lib.lib().wmd_mask_level_lists(C.byref(a), current_stream()), "wmd_mask_level_lists")
+    return outs, lists
+
+
 def compact_multi(masks, nnz_out=None):
     """uint8 masks [h,w] (or [B,h,w]) -> (list of int32 coordinate lists [npix capacity] (or [B,npix]), int32 tensor of
     counts [n] (or [B,n])) in one launch; raster order, counts stay on the device.  nnz_out: a contiguous int32 tensor of that
@@ -166,13 +268,14 @@ class LazyOpsDict(dict):
         return dict(self.resolve())
 
     # CPython copies a dict subclass through the raw hash table -- `dict(out)`, `{**out}`, `out | x`, dict.update(x, out) --
-    # unless the subclass overrides __iter__: then it goes through keys() + __getitem__, i.e. through the resolver.  The
-    # remaining readers of the raw storage resolve first.
-    def __iter__(self):
-        return dict.__iter__(self.resolve())
+    # unless the subclass overrides __iter__: then it goes through keys() + __getitem__, i.e. the lazy VALUES resolve on access
+    # while plain key iteration (`for k in out`, `list(out)`) never synchronises.  The remaining readers of the raw storage
+    # resolve first.
+    def __iter__(self):         # keys are known up front: iterating them costs no synchronisation (the values resolve in __getitem__)
+        return dict.__iter__(self)
 
     def keys(self):
-        return dict.keys(self.resolve())
+        return dict.keys(self)
 
     def pop(self, *a):
         return dict.pop(self.resolve(), *a)
