@@ -161,7 +161,8 @@ typedef struct {
     float x1_pre_slope;
     /* Work-list form of the block-sparse execution (round 4; wmd_mask_level_lists builds the list).  out_tiles holds the
      * indices ((b * tiles_y + ty) * tiles_x + tx, tiles of out_tile_h x out_tile_w pixels) of the pixel tiles that contain
-     * an active pixel of out_mask, in any order; *out_tile_count (device scalar) is their number.  Only listed tiles are
+     * an active pixel of out_mask, per frame: out_tiles [B][tiles_y * tiles_x], out_tile_count [B] (frame f's tiles are the
+     * first out_tile_count[f] entries of its segment, in any order).  Only listed tiles are
      * dispatched to a matrix-pipe workgroup -- an unlisted tile costs nothing and, as before, is not written -- and the
      * split of the input-channel reduction is chosen ON THE DEVICE from the count (few active tiles: every tile's K loop is
      * spread over many workgroups, whose partial sums meet in a list-driven second pass; many: no split, no second pass
@@ -503,7 +504,7 @@ int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, float thresh
  *   * compacts, per spec that asks for it, the pixel tiles (tile_h x tile_w) holding at least one set pixel into a work
  *     list for wmd_conv_args.out_tiles: every workgroup finds the active tiles of its own 16x16-cell region (a bit per
  *     tile: wavefront OR-reduction + popcount = the offsets inside its run) and reserves a run of the list with one atomic;
- *     the launch's last workgroup (ticket counter) publishes the total.  List order is unspecified, values never depend
+ *     the frame's last workgroup (ticket counter) publishes the frame's total.  List order is unspecified, values never depend
  *     on it.  Tile shapes must nest in the region: tile_h, tile_w divide 16 * up, at most 32 tiles per region.
  *   * publishes the per-frame pixel counts of the specs that ask for it WITHOUT a zero-initialised accumulator of the
  *     caller's and without a copy: accumulators live in `scratch` (all zero at rest: the last workgroup moves them out and
@@ -521,8 +522,8 @@ typedef struct {
     uint8_t* out;          /* [B, h*up, w*up]                                                                         */
     int count;             /* k > 0: this spec's pixel count is published as count column k - 1 (k <= ncounts <= 8)    */
     int tile_h, tile_w;    /* != 0: build the active-tile list of this spec's mask                                     */
-    int32_t* tile_list;    /* capacity B * ceil(h*up / tile_h) * ceil(w*up / tile_w)                                   */
-    int32_t* tile_count;   /* device scalar, overwritten                                                               */
+    int32_t* tile_list;    /* [B][ceil(h*up / tile_h) * ceil(w*up / tile_w)]: frame f's tiles fill the head of its segment */
+    int32_t* tile_count;   /* [B], overwritten                                                                         */
     const uint8_t* and_mask; /* optional [B, h*up, w*up]: out = dilation AND and_mask.  The never-refilled activation planes
                               of the work-list form hold stale values outside the previous level's support; the reference
                               reads 0 there (sparse_select, KITTI/layers.py:392-400: a pixel absent from the previous index

@@ -52,17 +52,17 @@ struct ConvKArgs {
     // of the launch = (tile_list[i / cob], slab i % cob) for i < *tile_count * cob; the K split is chosen on the device
     // (list_ksplit) up to ksmax = gridDim.z slices; ksplit slices > 1 write partial sums to `y` (workspace), one slice the final
     // result to y_final
-    const int* tile_list;
-    const int* tile_count;
+    const int* tile_list;    // [B][tiles_y * tiles_x]: frame f's active tiles are the first tile_count[f] entries of its segment
+    const int* tile_count;   // [B]
     int ksmax;
+    int list_slots;          // workgroup slots of the machine for this kernel (blocks per CU x CUs): the device's K-split target
     float* y_final;
 };
 
 // Device-chosen split of the input-channel reduction of a work-list launch: the same function in the convolution and in its
-// second pass.  Fills the machine (kListSlots workgroup slots) when few tiles are active, at least two chunks per slice.
-constexpr int kListSlots = 768;
-__host__ __device__ inline void list_ksplit(int n_items, int nchunks, int ksmax, int& ks, int& cps) {
-    int want = n_items > 0 ? kListSlots / n_items : 1;
+// second pass.  Fills the machine (`slots` workgroup slots) when few tiles are active, at least two chunks per slice.
+__host__ __device__ inline void list_ksplit(int n_items, int nchunks, int ksmax, int slots, int& ks, int& cps) {
+    int want = n_items > 0 ? slots / n_items : 1;
     want = want < 1 ? 1 : (want > ksmax ? ksmax : want);
     cps = (nchunks + want - 1) / want;
     const int floor_cps = nchunks < 2 ? nchunks : 2;
@@ -125,6 +125,22 @@ inline bool wino32_pure(const ConvKArgs& a, int CK) {
 
 template <int TH, int TW, int WN, int CK>
 void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s);   // explicit instantiations: wmd_conv_wino32_table.inc
+// Position `ti` of the concatenated per-frame tile lists -> the tile id; total = the number of listed tiles (sum of the counts).
+__device__ __forceinline__ int list_total(const int* __restrict__ tile_count, int B) {
+    int n = 0;
+    for (int f = 0; f < B; ++f) n += tile_count[f];
+    return n;
+}
+__device__ __forceinline__ int list_entry(const int* __restrict__ tile_list, const int* __restrict__ tile_count, int B, int cap, int ti) {
+    int f = 0, base = 0;
+    for (; f < B - 1; ++f) {
+        const int c = tile_count[f];
+        if (ti < base + c) break;
+        base += c;
+    }
+    return tile_list[(size_t)f * cap + (ti - base)];
+}
+
 // tile shapes with a LIST instantiation (work-list form): small tiles that nest in wmd_mask_level_lists' regions
 constexpr bool wino32_has_list(int TH, int TW, int WN, int CK) {
     return CK == 8 && ((TH == 8 && TW == 16 && WN == 1) || (TH == 16 && TW == 16 && WN == 2));

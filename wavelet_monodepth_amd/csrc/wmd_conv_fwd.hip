@@ -440,44 +440,74 @@ __global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, con
     }
 }
 
-// Second pass of a work-list launch (wmd_conv_args.out_tiles): one block per listed tile sums the ks partial planes of its
-// TH x TW x Cout outputs in the fixed order s = 0 .. ks-1, adds the bias, applies the activation and the out-mask select.
-// ks comes from the same device-side rule as in the convolution (list_ksplit); ks == 1 means the convolution already wrote the
-// final values and every block returns at once.
+// Second pass of a work-list launch (wmd_conv_args.out_tiles): a block = (listed tile, group of kRedCh out channels) sums the ks
+// partial planes of its outputs in the fixed order s = 0 .. ks-1 (all ks loads of an element in flight together: 16-byte pieces
+// along the row), adds the bias, applies the activation and the out-mask select.  ks comes from the same device-side rule as in
+// the convolution (list_ksplit); ks == 1 means the convolution already wrote the final values and every block returns at once.
+// (The first version gave a block a whole tile x Cout: 64 dependent rounds of ks loads per thread, 114-126 us per launch at
+// one frame against 13-20 us for the convolution itself.)
+constexpr int kRedCh = 8;
 __global__ __launch_bounds__(256) void conv_splitk_reduce_list_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                                                       float* __restrict__ y, const int* __restrict__ tile_list,
                                                                       const int* __restrict__ tile_count, const uint8_t* __restrict__ out_mask,
                                                                       int B, int Cout, int H, int W, int TH, int TW, int tiles_x, int tiles_y,
-                                                                      int cob, int nchunks, int ksmax, int act, float slope) {
-    const int n_act = *tile_count;
+                                                                      int cob, int nchunks, int ksmax, int slots, int act, float slope) {
+    const int n_act = list_total(tile_count, B);
     if ((int)blockIdx.x >= n_act) return;
     int ks, cps;
-    list_ksplit(n_act * cob, nchunks, ksmax, ks, cps);
+    list_ksplit(n_act * cob, nchunks, ksmax, slots, ks, cps);
     if (ks == 1) return;
-    int t = tile_list[blockIdx.x];
+    int t = list_entry(tile_list, tile_count, B, tiles_x * tiles_y, blockIdx.x);
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y, b = t / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
+    const int y0 = ty * TH, x0 = tx * TW, c0 = blockIdx.y * kRedCh;
     const size_t plane = (size_t)H * W, n = (size_t)B * Cout * plane;
-    const int per = TH * TW;
-    for (int e = threadIdx.x; e < per * Cout; e += 256) {
-        const int c = e / per, p = e - c * per;
-        const int yy = y0 + p / TW, xx = x0 + p % TW;
-        if (yy >= H || xx >= W) continue;
+    const int vpr = TW / 4, per_ch = TH * vpr;   // 16-byte pieces per tile row / per channel (TW % 4 == 0: the list kernels' tiles)
+    const bool vec = (W & 3) == 0;
+    for (int e = threadIdx.x; e < kRedCh * per_ch; e += 256) {
+        const int c = c0 + e / per_ch, r = e % per_ch;
+        const int yy = y0 + r / vpr, xx = x0 + (r % vpr) * 4;
+        if (c >= Cout || yy >= H || xx >= W) continue;
         const size_t i = ((size_t)b * Cout + c) * plane + (size_t)yy * W + xx;
-        float v = 0.f;
-        int s = 0;
-        for (; s + 4 <= ks; s += 4) {
-            const float p0 = partial[(size_t)s * n + i], p1 = partial[(size_t)(s + 1) * n + i];
-            const float p2 = partial[(size_t)(s + 2) * n + i], p3 = partial[(size_t)(s + 3) * n + i];
-            v = (((v + p0) + p1) + p2) + p3;
+        const float bv = bias ? bias[c] : 0.f;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {   // xx % 4 == 0 and W % 4 == 0: the piece is aligned and inside the row
+            float4 p[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (s < ks) p[s] = *reinterpret_cast<const float4*>(partial + (size_t)s * n + i);
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (s < ks) {
+                    v[0] += p[s].x;
+                    v[1] += p[s].y;
+                    v[2] += p[s].z;
+                    v[3] += p[s].w;
+                }
+        } else {
+            for (int s = 0; s < ks; ++s)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (xx + k < W) v[k] += partial[(size_t)s * n + i + k];
         }
-        for (; s < ks; ++s) v += partial[(size_t)s * n + i];
-        if (bias) v += bias[c];
-        v = act_apply(v, act, slope);
-        if (out_mask && out_mask[(size_t)b * plane + (size_t)yy * W + xx] == 0) v = 0.f;
-        y[i] = v;
+        uint8_t mv[4] = {1, 1, 1, 1};
+        if (out_mask) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mv[k] = out_mask[(size_t)b * plane + (size_t)yy * W + min(xx + k, W - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = act_apply(v[k] + bv, act, slope);
+            if (!mv[k]) v[k] = 0.f;
+        }
+        if (vec) {
+            *reinterpret_cast<float4*>(y + i) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (xx + k < W) y[i + k] = v[k];
+        }
     }
 }
 
@@ -1044,7 +1074,9 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         if (g->out_tiles) {
             // the device picks the split (list_ksplit) up to ksmax slices = gridDim.z: as many as could matter if every
             // slice of every possible item had to find a workgroup slot (a batch of frames never splits)
-            const int ksmax = (int)std::max<long>(1, std::min<long>(std::min(nchunks / 2, 16), 2L * kListSlots / std::max<long>(blocks, 1)));
+            // (measured at one frame: leaving the 8- and 12-chunk layers of the finest level unsplit -- no second pass -- cost
+            //  20.4 + 24.7 us against 12.4 + 4.9 + 16.4 + 6.7 us split and reduced: the split stays on offer wherever it fits)
+            const int ksmax = (int)std::max<long>(1, std::min<long>(std::min(nchunks / 2, 16), 2L * kNumCU * bpc / std::max<long>(blocks, 1)));
             const size_t need = ksmax > 1 ? (size_t)ksmax * g->B * g->Cout * g->H * g->W : 0;
             if (ksmax > 1 && (!have_ws || need > ws_floats)) continue;
             found = true;
@@ -1431,6 +1463,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
         a.tile_list = g->out_tiles;
         a.tile_count = g->out_tile_count;
         a.ksmax = plan.ksplit;
+        a.list_slots = kNumCU * std::max(1, std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, 8 / (c.WM * c.WN))));
         a.y_final = g->y;
     }
     a.gate = g->gate;
@@ -1476,9 +1509,9 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
         if (plan.ksplit > 1) {   // (ksmax = 1: the device can never split, no second pass)
             const int ntiles = g->B * plan.tiles_x * plan.tiles_y;
             ProfScope prof("conv_splitk_reduce_list_kernel", 0.0, 0.0, (hipStream_t)stream);
-            hipLaunchKernelGGL(conv_splitk_reduce_list_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, g->workspace, g->bias, g->y,
+            hipLaunchKernelGGL(conv_splitk_reduce_list_kernel, dim3(ntiles, (g->Cout + kRedCh - 1) / kRedCh), dim3(256), 0, (hipStream_t)stream, g->workspace, g->bias, g->y,
                                g->out_tiles, g->out_tile_count, g->out_mask, g->B, g->Cout, g->H, g->W, c.TH, c.TW, plan.tiles_x,
-                               plan.tiles_y, cob, plan.nchunks, plan.ksplit, g->act, g->slope);
+                               plan.tiles_y, cob, plan.nchunks, plan.ksplit, a.list_slots, g->act, g->slope);
             st = check_launch("conv_splitk_reduce_list_kernel");
         }
         return st;

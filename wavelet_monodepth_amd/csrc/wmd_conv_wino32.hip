@@ -117,14 +117,14 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     int t, by;
     int ks_n = a.ksplit, cps = a.chunks_per_split;   // LIST: chosen below from the list's length
     if constexpr (LIST) {
-        const int n_items = *a.tile_count * a.cob;
+        const int n_items = list_total(a.tile_count, a.B) * a.cob;
         if ((int)blockIdx.x >= n_items) return;
-        list_ksplit(n_items, a.nchunks, a.ksmax, ks_n, cps);
+        list_ksplit(n_items, a.nchunks, a.ksmax, a.list_slots, ks_n, cps);
         if ((int)blockIdx.z >= ks_n) return;
         const int item = xcd_contiguous(blockIdx.x, n_items);
         const int ti = item / a.cob;
         by = item - ti * a.cob;
-        t = a.tile_list[ti];
+        t = list_entry(a.tile_list, a.tile_count, a.B, a.tiles_x * a.tiles_y, ti);
     } else if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD (see conv_fwd_kernel)
         const int item = xcd_contiguous(blockIdx.x, gridDim.x);
         t = item / a.cob;

@@ -93,9 +93,11 @@ struct MaskLevelKArgs {
     int ring_slots, slot_ints, counts_off, ncounts, advance, B;
     MaskListSpec ls[8];
 };
-// scratch layout (int32, all zero at rest): [0] ticket, [1] forward sequence number, [2 + spec] tile accumulators,
-// [kMlCnt0 + frame * 8 + column] pixel-count accumulators
-constexpr int kMlTicket = 0, kMlSeq = 1, kMlTile0 = 2, kMlCnt0 = 16;
+// scratch layout (int32, all zero at rest): [0] ticket of the frames, [1] forward sequence number; per frame f at
+// kMlFrame0 + f * kMlFrameInts: [0] ticket of the frame's blocks, [1 + column] pixel-count accumulators, [16 + spec] tile
+// accumulators.  Everything is per frame so that no address sees more than a few hundred atomics per launch: one ticket for
+// the whole launch serialised 2 160 blocks at ~14 ns each (38 us at 12 frames).
+constexpr int kMlTicket = 0, kMlSeq = 1, kMlFrame0 = 16, kMlFrameInts = 32, kMlFTicket = 0, kMlFCnt0 = 1, kMlFTile0 = 16;
 
 __device__ __forceinline__ float key_to_float(unsigned k) {   // inverse of wmd_head_shiftsum_args.range_keys' encoding
     return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
@@ -233,46 +235,53 @@ __global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a)
         __syncthreads();
         const MaskListSpec ls = a.ls[blockIdx.z];
         const unsigned bits = s_bits;
-        if (ls.tile_list && bits) {   // reserve a run of the list with one atomic; bit k's entry sits at popcount(bits below k)
+        int32_t* fs = a.scratch + kMlFrame0 + (size_t)f * kMlFrameInts;    // this frame's accumulators
+        const int up_ = sp.up;
+        const int tiles_xg = ls.tile_w ? (w * up_ + ls.tile_w - 1) / ls.tile_w : 0, tiles_yg = ls.tile_h ? (h * up_ + ls.tile_h - 1) / ls.tile_h : 0;
+        if (ls.tile_list && bits) {   // reserve a run of the frame's list with one atomic; bit k's entry sits at popcount(bits below k)
             __shared__ int s_base;
-            if (threadIdx.x == 0) s_base = atomicAdd(&a.scratch[kMlTile0 + blockIdx.z], __popc(bits));
+            if (threadIdx.x == 0) s_base = atomicAdd(&fs[kMlFTile0 + blockIdx.z], __popc(bits));
             __syncthreads();
             const int k = threadIdx.x;
             if (k < 32 && ((bits >> k) & 1u)) {
-                const int up = sp.up, R = ML_T * up, ntx_l = R / ls.tile_w;
-                const int gty = (ty0 * up) / ls.tile_h + k / ntx_l, gtx = (tx0 * up) / ls.tile_w + k % ntx_l;
-                const int tiles_xg = (w * up + ls.tile_w - 1) / ls.tile_w, tiles_yg = (h * up + ls.tile_h - 1) / ls.tile_h;
-                ls.tile_list[s_base + __popc(bits & ((1u << k) - 1u))] = (f * tiles_yg + gty) * tiles_xg + gtx;
+                const int R = ML_T * up_, ntx_l = R / ls.tile_w;
+                const int gty = (ty0 * up_) / ls.tile_h + k / ntx_l, gtx = (tx0 * up_) / ls.tile_w + k % ntx_l;
+                ls.tile_list[(size_t)f * tiles_yg * tiles_xg + s_base + __popc(bits & ((1u << k) - 1u))] = (f * tiles_yg + gty) * tiles_xg + gtx;
             }
         }
         if (threadIdx.x == 0) {
-            if (ls.count && s_cnt) atomicAdd(&a.scratch[kMlCnt0 + f * 8 + ls.count - 1], s_cnt);
-            __threadfence();   // this block's atomics and list entries before its ticket
-            const int total = gridDim.x * gridDim.y * gridDim.z;
-            s_last = atomicAdd(&a.scratch[kMlTicket], 1) == total - 1;
+            // Ordering without a fence: the accumulators are only ever touched by device-scope atomics (performed at the level
+            // that is coherent across the XCDs), so all the ticket needs is that THIS thread's accumulator updates have been
+            // performed before it draws -- their returned values are awaited (the empty asm consumes them).  A __threadfence()
+            // here is a release at agent scope = a write-back of this XCD's L2, dirty with the masks just written.  The list
+            // entries and masks are plain stores for LATER launches and need no ordering inside this one.
+            int old = 0;
+            if (ls.count && s_cnt) old = atomicAdd(&fs[kMlFCnt0 + ls.count - 1], s_cnt);
+            asm volatile("" ::"v"(old) : "memory");
+            s_last = atomicAdd(&fs[kMlFTicket], 1) == (int)(gridDim.x * gridDim.z) - 1;
         }
         __syncthreads();
-        if (s_last) {          // every other block has drawn its ticket: all accumulators are final
-            __threadfence();
+        if (s_last) {          // every other block of the frame has drawn its ticket: the frame's accumulators are final
             const int seq = __hip_atomic_load(&a.scratch[kMlSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int32_t* slot = a.ring ? a.ring + (size_t)(seq % max(a.ring_slots, 1)) * a.slot_ints : nullptr;
-            for (int i = threadIdx.x; i < a.B * a.ncounts; i += 256) {
-                const int v = atomicExch(&a.scratch[kMlCnt0 + (i / a.ncounts) * 8 + i % a.ncounts], 0);
-                if (slot) slot[1 + a.counts_off + i] = v;
+            if (threadIdx.x < a.ncounts) {
+                const int v = atomicExch(&fs[kMlFCnt0 + threadIdx.x], 0);
+                if (slot) slot[1 + a.counts_off + f * a.ncounts + threadIdx.x] = v;
             }
-            if (threadIdx.x == 0)   // (uniform index: a per-thread index into the by-value argument block would become scratch memory)
+            if (threadIdx.x == 0) {   // (uniform index: a per-thread index into the by-value argument block would become scratch memory)
                 for (int i = 0; i < a.n; ++i)
-                    if (a.ls[i].tile_list) *a.ls[i].tile_count = atomicExch(&a.scratch[kMlTile0 + i], 0);
-            if (a.range_keys)
-                for (int i = threadIdx.x; i < a.B; i += 256) {
-                    a.range_keys[2 * i] = 0xFFFFFFFFu;
-                    a.range_keys[2 * i + 1] = 0u;
+                    if (a.ls[i].tile_list) a.ls[i].tile_count[f] = atomicExch(&fs[kMlFTile0 + i], 0);
+                if (a.range_keys) {
+                    a.range_keys[2 * f] = 0xFFFFFFFFu;
+                    a.range_keys[2 * f + 1] = 0u;
                 }
-            if (threadIdx.x == 0) {
-                atomicExch(&a.scratch[kMlTicket], 0);
-                if (a.advance) {
-                    if (slot) slot[0] = seq + 1;
-                    atomicExch(&a.scratch[kMlSeq], seq + 1);
+                atomicExch(&fs[kMlFTicket], 0);
+                if (atomicAdd(&a.scratch[kMlTicket], 1) == a.B - 1) {   // the last frame: the launch is complete
+                    atomicExch(&a.scratch[kMlTicket], 0);
+                    if (a.advance) {
+                        if (slot) slot[0] = seq + 1;
+                        atomicExch(&a.scratch[kMlSeq], seq + 1);
+                    }
                 }
             }
         }
@@ -701,7 +710,7 @@ extern "C" int wmd_mask_level_b(const float* yl, size_t n_yl, const float* yh, f
     return check_launch("mask_level_kernel");
 }
 
-extern "C" size_t wmd_mask_level_scratch_ints(int B) { return B > 0 ? (size_t)kMlCnt0 + 8 * (size_t)B : 0; }
+extern "C" size_t wmd_mask_level_scratch_ints(int B) { return B > 0 ? (size_t)kMlFrame0 + (size_t)kMlFrameInts * B : 0; }
 
 extern "C" int wmd_mask_level_lists(const wmd_mask_level_args* g, void* stream) {
     if (!g || !g->specs || !g->scratch) return fail(WMD_ERR_BAD_ARG, "wmd_mask_level_lists: null pointer");

@@ -432,7 +432,18 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             pool_used[0] += _round64(n)
             return v
 
-        th, tw = (int(v) for v in os.environ.get("WMD_SPARSE_TILE", "8x16").split("x"))
+        # Tile shape of a work-list launch: 8x16 (128-pixel workgroups: the finest granularity, most parallelism for one frame)
+        # until the launch could hold more than WMD_SPARSE_BIG_FROM (item = tile x 32-channel slab) of them, 16x16 beyond (a batch
+        # of frames: at full density the 8x16 form costs 35 % more than 256-pixel workgroups, while on contour masks both skip
+        # about the same share of the work); WMD_SPARSE_TILE=HxW forces one shape.
+        forced_tile = os.environ.get("WMD_SPARSE_TILE")
+        big_from = int(os.environ.get("WMD_SPARSE_BIG_FROM", "700"))
+
+        def tile_for(hh, ww, cout):
+            if forced_tile:
+                return tuple(int(v) for v in forced_tile.split("x"))
+            items = B * (-(-hh // 8)) * (-(-ww // 16)) * (-(-cout // 32))
+            return (16, 16) if items > big_from else (8, 16)
         unpack = lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias)
         counters, static_ops = [], {}
         yl = yh = None
@@ -448,7 +459,8 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             want_keys = next_sparse and not (_force_masks is not None and (i - 1) in _force_masks)
             if i in lv:
                 k = lv.index(i)
-                specs = [(1, 1, 0, None), (1, 2, 1, (th, tw)), (2, 2, 0, None), (2, 1, 2, (th, tw)), (2, 0, 3, None)]
+                C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
+                specs = [(1, 1, 0, None), (1, 2, 1, tile_for(h, w, C0)), (2, 2, 0, None), (2, 1, 2, tile_for(H2, W2, C1_)), (2, 0, 3, None)]
                 if prev_upconv1 is not None:     # input support of upconv(i,0): lowres AND the previous sparse level's support
                     specs.append((1, 1, 0, None, prev_upconv1))
                 if forced:
@@ -463,7 +475,6 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
                 lowres, upconv0, upsample_m, upconv1, wavelet = masks[:5]
                 lowres_in = masks[5] if prev_upconv1 is not None else lowres
                 src = xbuf if xbuf is not None else x
-                C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
                 x0 = plane(B, C0, h, w)
                 x1 = plane(B, C1_, H2, W2)
                 skip = input_features[i - 1].contiguous()

@@ -110,7 +110,7 @@ class LevelState:
         if hit is None or hit[0].numel() < capacity:
             dev = self.scratch.device
             hit = self.lists[key] = (torch.zeros(max(int(capacity), 1), device=dev, dtype=torch.int32),
-                                     torch.zeros(1, device=dev, dtype=torch.int32))
+                                     torch.zeros(self.B, device=dev, dtype=torch.int32))
         return hit
 
     def counts_fetcher(self, k):
