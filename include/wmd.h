@@ -331,6 +331,13 @@ typedef struct {
      * t planes are not written).  The sparse decoders pass the upconv1 mask = the 3x3 dilation of the wavelet mask: exactly
      * the pixels whose tap-partials a surviving output of wmd_head_shiftsum_fwd(yh_mask) gathers.                          */
     const uint8_t* run_mask;
+    /* optional (round 4, chain = 0, C = 256, t_planes = 81): the low-pass chain's operands (what a chain = 1 call would take as
+     * wp1 / bias1 / wp2).  The same call then fills planes 54..62 too -- on the chained kernel as a third group of workgroups
+     * of the SAME launch (a quarter of a side's first product: an LL workgroup walks four pixel tiles, so the launch stays
+     * inside one round of workgroup slots), otherwise as a second launch issued by the library.                            */
+    const float* ll_wp1;
+    const float* ll_bias1;
+    const float* ll_wp2;
 } wmd_head_fused_args;
 int wmd_head_fused_fwd(const wmd_head_fused_args* args, void* stream);
 

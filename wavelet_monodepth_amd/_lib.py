@@ -56,7 +56,8 @@ class HeadArgs(C.Structure):
 class HeadFusedArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("slope", C.c_float),
                 ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p), ("t", C.c_void_p),
-                ("chain", C.c_int), ("t_planes", C.c_int), ("run_mask", C.c_void_p)]
+                ("chain", C.c_int), ("t_planes", C.c_int), ("run_mask", C.c_void_p), ("ll_wp1", C.c_void_p),
+                ("ll_bias1", C.c_void_p), ("ll_wp2", C.c_void_p)]
 
 
 class HeadLevelArgs(C.Structure):

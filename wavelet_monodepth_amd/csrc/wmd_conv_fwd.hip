@@ -1141,7 +1141,26 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     const int t_planes = g->t_planes ? g->t_planes : 54;
     if (g->chain == 1 && (g->C != 256 || t_planes != 81))
         return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: the low-pass chain needs C = 256 and an 81-plane t (C=%d, t_planes=%d)", g->C, t_planes);
-    if (g->chain == 0 && head_chain_launch(g, t_planes, (hipStream_t)stream)) return check_launch("head_chain_kernel");
+    const bool want_ll = g->chain == 0 && g->ll_wp1 && g->ll_wp2;
+    if (want_ll && (g->C != 256 || t_planes != 81))
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: the low-pass chain needs C = 256 and an 81-plane t (C=%d, t_planes=%d)", g->C, t_planes);
+    if (g->chain == 0) {
+        const int took = head_chain_launch(g, t_planes, (hipStream_t)stream);
+        int st = took ? check_launch("head_chain_kernel") : WMD_OK;
+        if (st) return st;
+        if (want_ll && took != 2) {   // the chained kernel did not take the low-pass chain along: a launch of its own
+            wmd_head_fused_args l = *g;
+            l.wp1 = g->ll_wp1;
+            l.bias1 = g->ll_bias1;
+            l.wp2 = g->ll_wp2;
+            l.chain = 1;
+            l.run_mask = nullptr;
+            l.ll_wp1 = l.ll_wp2 = l.ll_bias1 = nullptr;
+            st = wmd_head_fused_fwd(&l, stream);
+            if (st) return st;
+        }
+        if (took) return WMD_OK;
+    }
     const int rows = g->chain == 1 ? g->C / 4 : 2 * g->C;   // stacked mid channels of this launch
     ConvKArgs a;
     memset(&a, 0, sizeof(a));

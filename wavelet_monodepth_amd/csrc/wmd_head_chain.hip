@@ -39,6 +39,12 @@ struct HeadChainArgs {
     int plane, tiles, t_planes;
     float slope;
     const uint8_t* run_mask;   // optional [B, plane]: a block whose pixel run holds no set byte returns (wmd_head_fused_args.run_mask)
+    // the coarsest level's low-pass chain (C = 256 only; wmd_head_fused_args.ll_wp1) rides in the blocks of side 0: W1_ll
+    // [C/4, C] = four more row tiles of the first product over the SAME staged x chunks (one per channel slice), W3'_ll = one
+    // [27 -> 32, C/4] image with nine rows in use -> planes 54..62
+    const float* ll_wp1;
+    const float* ll_bias1;
+    const float* ll_wp2;
 };
 
 template <int C, int RS, int PG, int NT, int KC>
@@ -55,17 +61,24 @@ struct HeadChainTile {
     static constexpr int NBUF = NCH > 1 ? 2 : 1;
     static constexpr int WV = WF / 4 / NTH;                      // float4 per thread and weight chunk
     static constexpr int XV = (KC * PXB + NTH - 1) / NTH;        // float4 per thread and x chunk (last one may be partial)
-    static constexpr int RED = RS > 1 ? NW * 2 * NT * 256 : 0;   // floats of the cross-wave reduction (aliases the chunks)
-    static constexpr int STAGE = NBUF * (WF + XF);
+    static constexpr int RED = RS > 1 ? NW * 3 * NT * 256 : 0;   // floats of the cross-wave reduction (aliases the chunks; third tile: the low-pass rows)
+    static constexpr int WFL = (C == 256 && RS == 4) ? RS * KC * 64 : 0;   // the low-pass chain's part of a weight chunk (C = 256 only): one row tile per channel slice
+    static constexpr int STAGE = NBUF * (WF + WFL + XF);
     static constexpr int LDS_FLOATS = STAGE > RED ? STAGE : RED;
     static_assert(C % 16 == 0 && MTS % RS == 0 && KS % KC == 0, "whole tiles");
     static_assert(WF % (4 * NTH) == 0, "weight chunk = whole float4 per thread");
     static_assert(XS % 32 == 16 && PXB % 4 == 0, "bank-conflict-free x rows");
 };
 
-template <class T, int KC>
-__device__ __forceinline__ void chain_fetch(float4 (&wreg)[T::WV], float4 (&xreg)[T::XV], const float* __restrict__ w1,
-                                            const float* __restrict__ xb, int c, int tid, int pix0, int plane) {
+// (LLX: the block also stages the low-pass chain's row tiles of the chunk -- WFL floats, one float4 for the first WFL/4 threads)
+template <class T, int KC, bool LLX>
+__device__ __forceinline__ void chain_fetch(float4 (&wreg)[T::WV], float4 (&xreg)[T::XV], float4& lreg, const float* __restrict__ w1,
+                                            const float* __restrict__ wl, const float* __restrict__ xb, int c, int tid, int pix0, int plane) {
+    if constexpr (LLX) {
+        static_assert(T::WFL > 0 && T::WFL / 4 <= T::NTH, "one float4 per thread covers the low-pass part of a chunk");
+        const int f = tid * 4, m = f / (KC * 64), rem = f % (KC * 64);
+        if (f < T::WFL) lreg = *reinterpret_cast<const float4*>(wl + ((size_t)m * T::KS + c * KC) * 64 + rem);
+    }
 #pragma unroll
     for (int v = 0; v < T::WV; ++v) {
         const int f = (v * T::NTH + tid) * 4;                     // float index inside the chunk: [row tile][KC*64]
@@ -83,9 +96,12 @@ __device__ __forceinline__ void chain_fetch(float4 (&wreg)[T::WV], float4 (&xreg
     }
 }
 
-template <class T, int KC>
-__device__ __forceinline__ void chain_commit(const float4 (&wreg)[T::WV], const float4 (&xreg)[T::XV], float* ws, int tid) {
-    float* xs = ws + T::WF;
+template <class T, int KC, bool LLX>
+__device__ __forceinline__ void chain_commit(const float4 (&wreg)[T::WV], const float4 (&xreg)[T::XV], const float4& lreg, float* ws, int tid) {
+    float* xs = ws + T::WF + T::WFL;
+    if constexpr (LLX) {
+        if (tid * 4 < T::WFL) *reinterpret_cast<float4*>(ws + T::WF + tid * 4) = lreg;
+    }
 #pragma unroll
     for (int v = 0; v < T::WV; ++v) *reinterpret_cast<float4*>(ws + (v * T::NTH + tid) * 4) = wreg[v];
 #pragma unroll
@@ -95,11 +111,14 @@ __device__ __forceinline__ void chain_commit(const float4 (&wreg)[T::WV], const 
     }
 }
 
-template <int C, int RS, int PG, int NT, int KC>
-__global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChainArgs a) {
+// One block's work.  LLX = the block also carries the low-pass chain (side 0 of the C = 256 launch): compiled as a second body
+// so that every size stays a compile-time constant of its body.
+template <int C, int RS, int PG, int NT, int KC, bool LLX>
+__device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* lds) {
     using T = HeadChainTile<C, RS, PG, NT, KC>;
     constexpr int MT = T::MT, KS = T::KS, XS = T::XS, PXB = T::PXB;
-    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    constexpr int MTX = MT + (LLX ? 1 : 0);   // row tiles of the first product per wave
+    static_assert(!LLX || (C / 4) / 16 == RS, "the low-pass chain: C/4 mid channels = one row tile per channel slice");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,36 +144,39 @@ __global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChain
     const float* w2 = a.wp2 + (size_t)side * 2 * KS * 64;        // fragments [tap-row tile 0..1][K-step][64 lanes]
 
     // ---- staging: chunk c = K-steps [c*KC, (c+1)*KC) of every row tile of W1_side, and channels [c*KC*4, +KC*4) of x ----
-    float4 wreg[T::WV], xreg[T::XV];
+    float4 wreg[T::WV], xreg[T::XV], lreg = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int BUF = T::WF + T::WFL + T::XF;
 
-    // ---- GEMM 1: acc[m][n] = rows 16(r*MT+m) .. +15 of W1_side x, pixels of group pg*NT + n ----------------------------
-    f32x4 acc[MT][NT];
+    // ---- GEMM 1: acc[m][n] = rows 16(r*MT+m) .. +15 of W1_side x, pixels of group pg*NT + n (LLX: acc[MT] = row tile r of
+    //      the low-pass chain's W1) -------------------------------------------------------------------------------------
+    f32x4 acc[MTX][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MTX; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    chain_fetch<T, KC>(wreg, xreg, w1, xb, 0, tid, pix0, plane);
-    chain_commit<T, KC>(wreg, xreg, lds, tid);
+    chain_fetch<T, KC, LLX>(wreg, xreg, lreg, w1, a.ll_wp1, xb, 0, tid, pix0, plane);
+    chain_commit<T, KC, LLX>(wreg, xreg, lreg, lds, tid);
     __syncthreads();
     for (int c = 0; c < T::NCH; ++c) {
-        if (c + 1 < T::NCH) chain_fetch<T, KC>(wreg, xreg, w1, xb, c + 1, tid, pix0, plane);
-        const float* ws = lds + (c & (T::NBUF - 1)) * (T::WF + T::XF);
-        const float* xs = ws + T::WF;
+        if (c + 1 < T::NCH) chain_fetch<T, KC, LLX>(wreg, xreg, lreg, w1, a.ll_wp1, xb, c + 1, tid, pix0, plane);
+        const float* ws = lds + (c & (T::NBUF - 1)) * BUF;
+        const float* xs = ws + T::WF + T::WFL;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-            float xf[NT], wf[MT];
+            float xf[NT], wf[MTX];
 #pragma unroll
             for (int n = 0; n < NT; ++n) xf[n] = xs[(kk * 4 + g) * XS + (pg * NT + n) * 16 + lc];
 #pragma unroll
             for (int m = 0; m < MT; ++m) wf[m] = ws[((r * MT + m) * KC + kk) * 64 + lane];
+            if constexpr (LLX) wf[MT] = ws[T::WF + (r * KC + kk) * 64 + lane];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MTX; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[m], xf[n], acc[m][n], 0, 0, 0);
         }
         if (c + 1 < T::NCH) {
-            chain_commit<T, KC>(wreg, xreg, lds + ((c + 1) & (T::NBUF - 1)) * (T::WF + T::XF), tid);
+            chain_commit<T, KC, LLX>(wreg, xreg, lreg, lds + ((c + 1) & (T::NBUF - 1)) * BUF, tid);
             __syncthreads();
         }
     }
@@ -189,29 +211,55 @@ __global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChain
         }
     }
 
+    // ---- the low-pass chain's second product (LLX): mid_ll = LeakyReLU(acc[MT] + b1_ll) is the B operand of the K-steps
+    //      (r, i) of W3'_ll (16 K-steps: fragment 4 r + g of tap-row tile 0; rows 9..15 of the tile are zero) -----------------
+    f32x4 acc2l[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc2l[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LLX) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.ll_bias1) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.ll_bias1 + r * 16 + g * 4);
+            bv[0] = b4.x, bv[1] = b4.y, bv[2] = b4.z, bv[3] = b4.w;
+        }
+        float w2l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w2l[i] = a.ll_wp2[((size_t)4 * r + g) * 64 + i * 16 + lc];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float mid = act_apply(acc[MT][n][i] + bv[i], WMD_ACT_LEAKY, a.slope);
+                acc2l[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2l[i], mid, acc2l[n], 0, 0, 0);
+            }
+    }
+
     // ---- the channel slices of a pixel group meet in LDS (RS > 1), fixed order r = 0 .. RS-1 ------------------------------
     if constexpr (RS > 1) {
+        constexpr int NJ = LLX ? 3 : 2;   // reduction tiles per pixel group: the two tap-row tiles (+ the low-pass rows)
         __syncthreads();   // every wave is done with the staged chunks
-        float* red = lds + (size_t)wave * 2 * NT * 256;
+        float* red = lds + (size_t)wave * 3 * NT * 256;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                *reinterpret_cast<float4*>(red + ((j * NT + n) * 64 + lane) * 4) =
-                    make_float4(acc2[j][n][0], acc2[j][n][1], acc2[j][n][2], acc2[j][n][3]);
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 v = j < 2 ? acc2[j < 2 ? j : 0][n] : acc2l[n];
+                *reinterpret_cast<float4*>(red + ((j * NT + n) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         __syncthreads();
         if (r != 0) return;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                float4 s = *reinterpret_cast<const float4*>(lds + (size_t)(pg * RS) * 2 * NT * 256 + ((j * NT + n) * 64 + lane) * 4);
+                float4 s = *reinterpret_cast<const float4*>(lds + (size_t)(pg * RS) * 3 * NT * 256 + ((j * NT + n) * 64 + lane) * 4);
 #pragma unroll
                 for (int rr = 1; rr < RS; ++rr) {
-                    const float4 p = *reinterpret_cast<const float4*>(lds + (size_t)(pg * RS + rr) * 2 * NT * 256 + ((j * NT + n) * 64 + lane) * 4);
+                    const float4 p = *reinterpret_cast<const float4*>(lds + (size_t)(pg * RS + rr) * 3 * NT * 256 + ((j * NT + n) * 64 + lane) * 4);
                     s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;
                 }
-                acc2[j][n] = f32x4{s.x, s.y, s.z, s.w};
+                if (j < 2) acc2[j < 2 ? j : 0][n] = f32x4{s.x, s.y, s.z, s.w};
+                else acc2l[n] = f32x4{s.x, s.y, s.z, s.w};
             }
     }
 
@@ -228,7 +276,27 @@ __global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChain
                 const int row = j * 16 + g * 4 + i;
                 if (row < 27) tb[(size_t)row * plane + px] = acc2[j][n][i];
             }
+        if constexpr (LLX) {   // rows 0..8 of the low-pass tile -> planes 54..62
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = g * 4 + i;
+                if (row < 9) tb[(size_t)(54 + row) * plane + px] = acc2l[n][i];
+            }
+        }
     }
+}
+
+template <int C, int RS, int PG, int NT, int KC, bool LLC = false>
+__global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChainArgs a) {
+    using T = HeadChainTile<C, RS, PG, NT, KC>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    if constexpr (LLC) {
+        if (blockIdx.y == 0) {
+            head_chain_body<C, RS, PG, NT, KC, true>(a, lds);
+            return;
+        }
+    }
+    head_chain_body<C, RS, PG, NT, KC, false>(a, lds);
 }
 
 template <int C, int RS, int PG, int NT, int KC>
@@ -236,18 +304,24 @@ static void launch_chain(const HeadChainArgs& a, int B, hipStream_t s) {
     using T = HeadChainTile<C, RS, PG, NT, KC>;
     HeadChainArgs k = a;
     k.tiles = (a.plane + T::PXB - 1) / T::PXB;
+    if constexpr (C == 256 && RS == 4) {
+        if (a.ll_wp1) {
+            hipLaunchKernelGGL((head_chain_kernel<C, RS, PG, NT, KC, true>), dim3((unsigned)(B * k.tiles), 2), dim3(T::NTH), 0, s, k);
+            return;
+        }
+    }
     hipLaunchKernelGGL((head_chain_kernel<C, RS, PG, NT, KC>), dim3((unsigned)(B * k.tiles), 2), dim3(T::NTH), 0, s, k);
 }
 
 // -> true when the chained form took the launch (C = 64 / 128 / 256, image planes of a multiple of 4 pixels; WMD_HEAD_CHAIN=0
 // keeps the FUSE form of conv_fwd_kernel)
-bool head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s) {
+int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s) {
     static const bool on = [] {
         const char* e = getenv("WMD_HEAD_CHAIN");
         return !(e && atoi(e) == 0);
     }();
     const long plane = (long)g->H * g->W;
-    if (!on || (plane & 3) || plane > (1L << 28) || (g->C != 64 && g->C != 128 && g->C != 256)) return false;
+    if (!on || (plane & 3) || plane > (1L << 28) || (g->C != 64 && g->C != 128 && g->C != 256)) return 0;
     HeadChainArgs a;
     a.x = g->x;
     a.wp1 = g->wp1;
@@ -259,6 +333,10 @@ bool head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s
     a.t_planes = t_planes;
     a.slope = g->slope;
     a.run_mask = g->run_mask;
+    const bool with_ll = g->ll_wp1 && g->ll_wp2 && g->C == 256 && t_planes == 81 && !g->run_mask;
+    a.ll_wp1 = with_ll ? g->ll_wp1 : nullptr;
+    a.ll_bias1 = with_ll ? g->ll_bias1 : nullptr;
+    a.ll_wp2 = with_ll ? g->ll_wp2 : nullptr;
     const double pix = (double)g->B * plane;
     ProfScope prof("head_chain_kernel", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C), 4.0 * pix * (g->C + 54), s);
     // (pixel-tile / wave-count / chunk variants -- 64 to 256 pixels, 2 to 16 waves, channel split 1 / 2 / 4 / 8 -- all measured
@@ -269,7 +347,7 @@ bool head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s
         launch_chain<128, 1, 4, 1, 8>(a, g->B, s);    // 64 pixels, 4 chunks of 32 channels
     else
         launch_chain<256, 4, 2, 1, 4>(a, g->B, s);    // 32 pixels, 4 waves share a pixel group's 256 channels, 16 chunks
-    return true;
+    return with_ll ? 2 : 1;
 }
 
 }  // namespace wmd

@@ -79,6 +79,7 @@ __device__ __forceinline__ bool pad_coord(int& g, int n, int pad_mode) {
 }
 
 // wmd_head_chain.hip: the chained-GEMM form of wmd_head_fused_fwd (chain = 0); false = not taken (unsupported shape / switched off)
-bool head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s);
+// -> 0 not taken, 1 taken, 2 taken together with the low-pass chain (wmd_head_fused_args.ll_wp1)
+int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s);
 
 }  // namespace wmd

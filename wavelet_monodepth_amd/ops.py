@@ -824,6 +824,7 @@ _HEAD_BWD1_MIN_PIXELS = int(os.environ.get("WMD_HEAD_BWD1_MIN_PIXELS", "196608")
 # its kernels walk the whole channel sum per 64-pixel wave tile and only win where a level has thousands of tiles (the finest one)
 _TWO_LAUNCH_HEAD = os.environ.get("WMD_TWO_LAUNCH_HEAD", "0") == "1"   # development switch: A/B the two forms
 _LL_FOLD = os.environ.get("WMD_LL_FOLD", "1") != "0"                   # 0: the low-pass head on its own three launches
+_LL_MERGE = os.environ.get("WMD_LL_MERGE", "1") != "0"                 # 0: the low-pass chain as a launch of its own (round 3)
 
 
 def head_level_folds_range_keys(C_):
@@ -882,11 +883,15 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
         t = torch.empty((B, planes, H, W), device=x.device, dtype=torch.float32)
         a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t),
                                chain=0, t_planes=planes, run_mask=ptr(run_mask))
-        check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
-        if head_ll is not None:     # the low-pass chain: a small second launch over the same x into planes 54..62
-            wpl1, wpl2 = _ll_chain_pack(w1l, w3l)
+        if head_ll is not None:     # the low-pass chain rides in the same call (planes 54..62): a third group of workgroups of
+            wpl1, wpl2 = _ll_chain_pack(w1l, w3l)       # the chained kernel's launch, or a second launch issued by the library
             yl_ll = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
-            a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wpl1), bias1=ptr(_c(b1l.detach())), wp2=ptr(wpl2),
+            b1l_c = _c(b1l.detach())
+            if _LL_MERGE:
+                a.ll_wp1, a.ll_bias1, a.ll_wp2 = ptr(wpl1), ptr(b1l_c), ptr(wpl2)
+        check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
+        if head_ll is not None and not _LL_MERGE:
+            a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wpl1), bias1=ptr(b1l_c), wp2=ptr(wpl2),
                                    t=ptr(t), chain=1, t_planes=planes)
             check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
         g = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scale), t=ptr(t), bias_p=ptr(b3p),
