@@ -631,6 +631,8 @@ int wmd_comm_init(wmd_comm** comm, const void* unique_id_128, int world, int ran
 int wmd_comm_allreduce(wmd_comm* comm, float* buf, size_t n, float scale, void* stream);
 /* in-place broadcast of n floats from rank `root` (initial parameter / BatchNorm-buffer synchronisation of the replicas) */
 int wmd_comm_broadcast(wmd_comm* comm, float* buf, size_t n, int root, void* stream);
+/* what the communicator itself reports: the RCCL version code (ncclGetVersion), ncclCommCount, ncclCommUserRank */
+int wmd_comm_info(wmd_comm* comm, int* rccl_version, int* world, int* rank);
 int wmd_comm_destroy(wmd_comm* comm);
 
 /* ------------------------------------------------------------------ *

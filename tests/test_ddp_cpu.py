@@ -73,6 +73,14 @@ def _worker(rank, world, port, out_dir):
     net(shard[1:]).pow(2).mean().mul(0.5).backward()
     gx.finish()
     grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # what bench.py's `train` object reports about the exchange itself: the communicator each rank went through and the
+    # stand-alone all-reduce time / bus bandwidth of every bucket (scratch buffers: the gradients must be untouched)
+    info = gx.comm_info()
+    assert info["comm_world"] == world and info["comm_rank"] == rank and info["backend"].startswith("torch")
+    timing = gx.bucket_timing(reps=1)
+    assert list(timing) == [b["name"] for b in gx.buckets]
+    assert all(v["bytes"] == 4 * b["flat"].numel() and v["ms"] > 0 for v, b in zip(timing.values(), gx.buckets))
+    assert all(torch.equal(grads[n], p.grad) for n, p in net.named_parameters() if p.grad is not None)
     torch.save(grads, os.path.join(out_dir, "g%d.pt" % rank))
     gx.close()
     dist.destroy_process_group()

@@ -76,6 +76,26 @@ def merged(per_grid):
             "by_grid_size": per_grid}
 
 
+def conv_plan():
+    """conv_plan.txt = stderr of one eager bench step under WMD_CONV_VERBOSE=1: the problem signature of every trunk layer with
+    the kernel and grid it ran on -> {signature: (kernel, rocprof Grid_Size)} (Grid_Size = total work-items of the launch)."""
+    f = os.path.join(src, "conv_plan.txt")
+    plan = {}
+    if os.path.exists(f):
+        for ln in open(f):
+            m = re.search(r"cfg (\S+) grid (\d+),(\d+),(\d+) block (\d+) sig (\S+)", ln)
+            if m:
+                plan[m.group(6)] = (m.group(1), str(int(m.group(2)) * int(m.group(3)) * int(m.group(4)) * int(m.group(5))))
+    return plan
+
+
+def algorithmic_bytes(sig):
+    """inputs + weights + outputs once, fp32 (what bench.py's per-launch `bytes` is): sig = conv|B|H|W|C1|up1|C2|Cout|k"""
+    B, H, W, C1, up1, C2, Cout, k = (int(v) for v in sig.split("|")[1:9])
+    pix = B * H * W
+    return int(4 * (pix * C1 / (up1 * up1) + pix * C2 + (C1 + C2) * k * k * Cout + pix * Cout))
+
+
 def copy(rel, dst):
     files = glob.glob(os.path.join(src, rel))
     if files:
@@ -91,6 +111,8 @@ for f in glob.glob(os.path.join(src, "train_profile_*.txt")):
 copy("sparse_workloads.txt", tag + "_sparse_workloads.txt")
 copy("sparse_profile_thr0.15.txt", tag + "_sparse_profile_thr0.15.txt")
 copy("sparse_timelines.txt", tag + "_sparse_timelines.txt")
+copy("sparse_workloads_r03form.txt", tag + "_sparse_workloads_r03form.txt")
+copy("tune_cache.json", tag + "_tune_cache.json")
 copy("gpu_tests.txt", tag + "_gpu_tests.txt")
 method = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc <SQ counters> GRBM_GUI_ACTIVE in separate passes (tools/profile_session.sh); "
           "per-launch averages; HBM-side bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE reports half of the fetched bytes on gfx950)")
@@ -102,8 +124,22 @@ for kind, what in (("fwd", "WMD_BENCH_GRAPH=0 python bench.py --steps 3 --warmup
         continue
     json.dump({"_method": method, "command": what, "session": tag, "kernels": summ}, open(os.path.join(P, "%s_pmc_%s.json" % (tag, kind)), "w"), indent=1)
     if kind == "fwd":
+        # trunk layers by PROBLEM SIGNATURE (what bench.py's roofline.traffic reads): joined on (kernel, grid) with the plan dump;
+        # two layers that share a kernel AND a grid cannot be told apart by the counters and are flagged instead of guessed
+        layers, plan = {}, conv_plan()
+        for sig, (kern, grid) in sorted(plan.items()):
+            twins = [s2 for s2, kg in plan.items() if kg == (kern, grid)]
+            row = summ.get(kern, {}).get(grid)
+            if row is None:
+                continue
+            layers[sig] = {"kernel": kern, "grid_size": grid, "hbm_bytes_per_launch": row["hbm_bytes_per_launch"],
+                           "fetch_kib_raw": row["fetch_kib_raw"], "write_kib": row["write_kib"], "algorithmic_bytes": algorithmic_bytes(sig),
+                           "mfma_busy_frac": row.get("mfma_busy_frac"), "ambiguous_with": [t for t in twins if t != sig] or None}
         json.dump({"_method": method, "session": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, session " + tag,
-                   "kernels": {k: merged(v) for k, v in summ.items()}}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+                   "layers": layers, "kernels": {k: merged(v) for k, v in summ.items()}}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+        for sig, v in layers.items():
+            print("  layer %-38s %-34s %7.1f MB HBM vs %6.1f MB algorithmic (%.2fx)" % (sig, v["kernel"], v["hbm_bytes_per_launch"] / 1e6,
+                                                                                      v["algorithmic_bytes"] / 1e6, v["hbm_bytes_per_launch"] / v["algorithmic_bytes"]))
     print("==", kind)
     for name, grids in sorted(summ.items()):
         for g, r in grids.items():

@@ -21,8 +21,14 @@ pmc_passes() {   # $1 = name prefix, rest = command: FETCH_SIZE / WRITE_SIZE / S
 }
 for w in $WHAT; do
 case $w in
+retune)   # regenerate the committed tile / split-K choices (every workload bench.py touches): profiles/<tag>_tune_cache.json
+    WMD_BENCH_RETUNE=1 WMD_TUNE_CACHE=$OUT/tune_cache.json timeout 1500 python bench.py --no-cpu-baseline > $OUT/bench_retune.json 2> $OUT/bench_retune.err
+    tail -c 300 $OUT/bench_retune.json; echo; python -c "import json; print(len(json.load(open('$OUT/tune_cache.json'))), 'tuned keys')" ;;
 fwd)
+    [ -f $OUT/tune_cache.json ] && cp $OUT/tune_cache.json profiles/${TAG}_tune_cache.json     # this session's retune, if any
     python bench.py > $OUT/bench.json 2> $OUT/bench.err
+    # the trunk layers' problem signatures with the kernel + grid each ran on (joins the counters to layers, not to grid sizes)
+    WMD_CONV_VERBOSE=1 WMD_BENCH_GRAPH=0 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train 2>&1 >/dev/null | grep "sig conv" | sort -u > $OUT/conv_plan.txt
     tail -c 400 $OUT/bench.json; echo
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $REPO/bench.py --no-cpu-baseline --no-train > $OUT/stats.log 2>&1)
     cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv; rm -rf $OUT/stats
@@ -37,6 +43,7 @@ bwd)   # WMD_TUNE_CACHE: the first run tunes and stores its choices, the counter
     unset WMD_TUNE_CACHE ;;
 sparse)
     python tools/config_bench.py sparse sparse-throughput > $OUT/sparse_workloads.txt 2>&1
+    WMD_SPARSE_LISTS=0 python tools/config_bench.py sparse sparse-throughput > $OUT/sparse_workloads_r03form.txt 2>&1    # round-3 tile form, same box
     grep "sparse\|throughput" $OUT/sparse_workloads.txt | tail -n 50
     bash tools/sparse_timeline_session.sh > $OUT/sparse_timelines.txt 2>&1      # one graph replay each, kernel by kernel
     for f in dense_b1 sparse_b1_tiles sparse_b1_gather dense_b12 sparse_b12_d0.1 sparse_b12_contour; do

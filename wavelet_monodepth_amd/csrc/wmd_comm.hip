@@ -71,6 +71,19 @@ extern "C" int wmd_comm_broadcast(wmd_comm* comm, float* buf, size_t n, int root
     return WMD_OK;
 }
 
+extern "C" int wmd_comm_info(wmd_comm* comm, int* rccl_version, int* world, int* rank) {
+    if (!comm) return fail(WMD_ERR_BAD_ARG, "wmd_comm_info: null communicator");
+    int v = 0, w = 0, r = 0;
+    ncclResult_t e = ncclGetVersion(&v);
+    if (e == ncclSuccess) e = ncclCommCount(comm->comm, &w);
+    if (e == ncclSuccess) e = ncclCommUserRank(comm->comm, &r);
+    if (e != ncclSuccess) return nccl_fail("wmd_comm_info", e);
+    if (rccl_version) *rccl_version = v;
+    if (world) *world = w;
+    if (rank) *rank = r;
+    return WMD_OK;
+}
+
 extern "C" int wmd_comm_destroy(wmd_comm* comm) {
     if (!comm) return WMD_OK;
     ncclResult_t r = ncclCommDestroy(comm->comm);

@@ -1507,8 +1507,10 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y * (tile_major ? cob : 1)), tile_major ? 1u : (unsigned)cob,
               (unsigned)plan.ksplit);
     if (env_int("WMD_CONV_VERBOSE", 0))
-        fprintf(stderr, "[wmd] conv %dx%d C%d+%d->%d k%d: cfg %s grid %u,%u,%u\n", g->H, g->W, g->C1, g->C2, g->Cout,
-                g->ksize, c.name, grid.x, grid.y, grid.z);
+        // (sig = the autotuner's problem signature: profiles key the counters of a launch by it, see tools/make_profile_summary.py)
+        fprintf(stderr, "[wmd] conv %dx%d C%d+%d->%d k%d: cfg %s grid %u,%u,%u block %d sig conv|%d|%d|%d|%d|%d|%d|%d|%d%s\n", g->H, g->W, g->C1,
+                g->C2, g->Cout, g->ksize, c.name, grid.x, grid.y, grid.z, c.WM * c.WN * 64, g->B, g->H, g->W, g->C1, g->up1, g->C2, g->Cout,
+                g->ksize, shift1 ? "|dgrad" : "");
     const double pix = (double)g->B * g->H * g->W;
     {
         // algorithmic work: 2*Cin*k*k*Cout FLOP per output pixel; bytes: inputs + weights + outputs once

@@ -27,9 +27,7 @@ import contextlib
 import ctypes as C
 import os
 
-# dmabuf IPC: without it RCCL's communicator set-up fails on this driver (hipIpcGetMemHandle: invalid argument).  Read by the
-# HIP runtime when it initialises, so import this module (or set the variable) before the first HIP call of the process.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -58,6 +56,12 @@ class _RcclBackend:
         from . import _lib
         self._lib = _lib
         l = _lib.lib()
+        # dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's communicator set-up fails on this driver (hipIpcGetMemHandle:
+        # invalid argument).  The HIP runtime reads the variable when it initialises, so it belongs in the launcher's
+        # environment (bench.py sets it before its first HIP call); setting it here would be too late -- say so instead.
+        if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY=0 is not set in this process: RCCL communicator set-up between processes is "
+                          "known to fail on this driver without it (export it before the first HIP call)")
         uid = C.create_string_buffer(128)
         if rank == 0:
             _lib.check(l.wmd_comm_unique_id(uid), "wmd_comm_unique_id")
@@ -86,6 +90,24 @@ class _RcclBackend:
     def wait(self):
         torch.cuda.current_stream().wait_stream(self.side)
 
+    def info(self):
+        v, w, r = C.c_int(), C.c_int(), C.c_int()
+        self._lib.check(self._lib.lib().wmd_comm_info(self.comm, C.byref(v), C.byref(w), C.byref(r)), "wmd_comm_info")
+        return {"backend": "rccl", "rccl_version": v.value, "comm_world": w.value, "comm_rank": r.value}
+
+    def timed_allreduce(self, buf, reps):
+        """-> mean milliseconds of `reps` all-reduces of buf on the side stream (hipEvents on that stream)."""
+        self._fork()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        l = self._lib.lib()
+        self._lib.check(l.wmd_comm_allreduce(self.comm, buf.data_ptr(), buf.numel(), 1.0, self.side.cuda_stream), "wmd_comm_allreduce")
+        e0.record(self.side)
+        for _ in range(reps):
+            self._lib.check(l.wmd_comm_allreduce(self.comm, buf.data_ptr(), buf.numel(), 1.0, self.side.cuda_stream), "wmd_comm_allreduce")
+        e1.record(self.side)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     def close(self):
         if self.comm:
             self._lib.lib().wmd_comm_destroy(self.comm)
@@ -110,6 +132,22 @@ class _TorchBackend:
             if scale != 1.0:
                 buf.mul_(scale)
         self.work = []
+
+    def info(self):
+        return {"backend": "torch:" + str(dist.get_backend(self.group)), "comm_world": dist.get_world_size(self.group),
+                "comm_rank": dist.get_rank(self.group)}
+
+    def timed_allreduce(self, buf, reps):
+        import time
+        dist.all_reduce(buf, group=self.group)
+        if buf.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf, group=self.group)
+        if buf.is_cuda:
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
 
     def close(self):
         pass
@@ -302,6 +340,25 @@ class GradientExchange:
 
     def message_bytes(self):
         return {b["name"]: 4 * b["flat"].numel() for b in self.buckets}
+
+    def comm_info(self):
+        """What the communicator this rank exchanges through reports about itself (backend, RCCL version code, world, rank)."""
+        return self.backend.info() if hasattr(self.backend, "info") else {"backend": "none", "comm_world": 1, "comm_rank": 0}
+
+    def bucket_timing(self, reps=3):
+        """Stand-alone all-reduce time of every bucket's message size (a scratch buffer, nothing overlapped; every rank must
+        call it at the same point): -> {bucket: {"bytes", "ms", "bus_GBps"}}, bus bandwidth = 2 (W - 1) / W x bytes / time,
+        the figure a ring is bound by per link (xGMI: ~153 GB/s per link and direction)."""
+        out = {}
+        if not hasattr(self.backend, "timed_allreduce"):
+            return out
+        for b in self.buckets:
+            scratch = torch.zeros_like(b["flat"])
+            ms = self.backend.timed_allreduce(scratch, reps)
+            nbytes = 4 * scratch.numel()
+            out[b["name"]] = {"bytes": nbytes, "ms": round(ms, 4),
+                              "bus_GBps": round(2.0 * (self.world - 1) / max(self.world, 1) * nbytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+        return out
 
     def close(self):
         for h in self._hooks:
