@@ -146,19 +146,6 @@ typedef struct {
     const uint8_t* in_mask;
     const uint8_t* out_mask;
     int in_mask_2x2;
-    /* Encoder edge: x1 is the encoder's last PRE-activation and is read through
-     *     x1'[c] = pre_act(x1[c] * x1_scale[c] + x1_shift[c])        (scale / shift optional: NULL = 1 / 0)
-     * between its LDS read and its MFMA -- the eval-mode BatchNorm affine + ReLU that ends DenseNet161's features
-     * (NYUv2/networks/encoders/densenet_encoder.py: norm5 + relu) or the ReLU that ends ResNet's last block
-     * (KITTI/networks/encoders/resnet_encoder.py:87-98), so the encoder does not write, and the first decoder convolution
-     * (depth_decoder.py:142-145 upconv(4,0); densedepth_decoder.py conv2) does not re-read, the activated map.
-     * x1_pre_act: WMD_ACT_NONE or WMD_ACT_LEAKY (ReLU = slope 0).  One source tensor (C2 = 0, C1 <= 2304), no masks / gate,
-     * no zero padding of a 3x3 (a padded 0 would become act(shift)); inference path (the data / weight gradients take the
-     * activated tensor).  Served by dedicated instantiations of the direct kernel ("...,pre>" in the configuration table). */
-    const float* x1_scale;
-    const float* x1_shift;
-    int x1_pre_act;
-    float x1_pre_slope;
     /* Work-list form of the block-sparse execution (round 4; wmd_mask_level_lists builds the list).  out_tiles holds the
      * indices ((b * tiles_y + ty) * tiles_x + tx, tiles of out_tile_h x out_tile_w pixels) of the pixel tiles that contain
      * an active pixel of out_mask, per frame: out_tiles [B][tiles_y * tiles_x], out_tile_count [B] (frame f's tiles are the

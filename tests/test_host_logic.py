@@ -319,14 +319,6 @@ def test_round3_entry_points_validate_arguments_without_gpu():
     a1.dz = 1
     a3.head[0].nrows, a3.n_out = 1, 6
     assert lib.wmd_head_bwd(C.byref(a3), C.byref(a1), None) == -3                                  # the merged form: 3-channel heads only
-    # encoder edge of wmd_conv_fwd
-    c = _lib.ConvArgs(B=1, H=8, W=8, C1=16, up1=1, C2=0, Cout=16, ksize=3, pad_mode=0, act=0, slope=0.0, x1=1, x2=None, wp=1,
-                      bias=None, y=1, workspace=None, workspace_floats=0, tune_cfg=0, tune_ksplit=0, x1_pre_act=2, x1_pre_slope=0.0)
-    assert lib.wmd_conv_fwd(C.byref(c), None) == -3 and b"zero padding" in lib.wmd_last_error()
-    c.pad_mode, c.x1_pre_act = 1, 1
-    assert lib.wmd_conv_fwd(C.byref(c), None) == -3                                                # ELU on load: not offered
-    c.x1_pre_act, c.C2, c.x2 = 2, 8, 1
-    assert lib.wmd_conv_fwd(C.byref(c), None) == -3 and b"one source tensor" in lib.wmd_last_error()
 
 
 # ---- NYUv2 Model(opts) (NYUv2/model.py:12-71) ------------------------------------------------------------------------------

@@ -24,7 +24,6 @@ class ConvArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("tune_cfg", C.c_int), ("tune_ksplit", C.c_int),
                 ("wp_wino", C.c_void_p), ("gate", C.c_void_p), ("gate_act", C.c_int), ("gate_slope", C.c_float),
                 ("in_mask", C.c_void_p), ("out_mask", C.c_void_p), ("in_mask_2x2", C.c_int),
-                ("x1_scale", C.c_void_p), ("x1_shift", C.c_void_p), ("x1_pre_act", C.c_int), ("x1_pre_slope", C.c_float),
                 ("out_tiles", C.c_void_p), ("out_tile_count", C.c_void_p), ("out_tile_h", C.c_int), ("out_tile_w", C.c_int)]
 
 

@@ -795,6 +795,7 @@ struct WgradWinoCfg {
     void (*launch)(const WgradKArgs&, dim3, hipStream_t);
     const char* name;
     int bpc;      // blocks that share a CU (the pixel split aims at this many rounds-free blocks per CU)
+    bool w32;     // the 32x32x2 family (conv_wgrad_wino32_kernel): ~2x the rate of the 16x16x4 form in the cost model
 };
 template <int TH, int TW, int MR, int NC, int WM, int WN>
 static void launch_wgrad_wino(const WgradKArgs& a, dim3 grid, hipStream_t s) {
@@ -803,13 +804,13 @@ static void launch_wgrad_wino(const WgradKArgs& a, dim3 grid, hipStream_t s) {
 #define WMD_WWCFG(TH, TW, MR, NC, WM, WN)                                                  \
     WgradWinoCfg {                                                                         \
         TH, TW, MR, NC, WM, WN, &launch_wgrad_wino<TH, TW, MR, NC, WM, WN>,                \
-            "conv_wgrad_wino_kernel<" #TH "," #TW "," #MR "," #NC "," #WM "," #WN ">", 2   \
+            "conv_wgrad_wino_kernel<" #TH "," #TW "," #MR "," #NC "," #WM "," #WN ">", 2, false \
     }
 // conv_wgrad_wino32_kernel (wmd_conv_wgrad32.hip): WCO x WCI slabs of 32 channels; the table's tile arithmetic sees them as
 // MR = NC = 2 sixteen-channel tiles per "wave row / column"
 #define WMD_WG32_INST(TH, TW, WCO, WCI)                                                                           \
     WgradWinoCfg{TH, TW, 2, 2, WCO, WCI, &launch_wgrad_wino32<TH, TW, WCO, WCI>,                                  \
-                 "conv_wgrad_wino32_kernel<" #TH "," #TW "," #WCO "," #WCI ">", (WCO) * (WCI) >= 4 ? 1 : 2},
+                 "conv_wgrad_wino32_kernel<" #TH "," #TW "," #WCO "," #WCI ">", (WCO) * (WCI) >= 4 ? 1 : 2, true},
 static const WgradWinoCfg kWWCfgs[] = {
     WMD_WWCFG(2, 32, 1, 1, 4, 1),   // co64 x ci16, 64-pixel tiles (55 KB: 2 blocks / CU)
     WMD_WWCFG(2, 32, 1, 1, 2, 2),   // co32 x ci32
@@ -865,8 +866,7 @@ static bool plan_wgrad_wino(const wmd_conv_wgrad_args* g, WgradWinoPlan* p) {
         if (g->tune_nsplit > 0) nsplit = std::min<long>(g->tune_nsplit, std::max<long>(1, ntiles));
         const double rounds = std::ceil((double)gx * gy * nsplit / ((double)c.bpc * kNumCU));
         // two ci tiles / two co tiles per wave amortise the transforms: small bonus; the 32x32x2 family runs ~2x the rate
-        const bool w32 = c.launch != nullptr && c.name[16] == '3';     // "conv_wgrad_wino32_kernel<..."
-        const double eff = w32 ? 0.5 : ((c.MR * c.NC > 1) ? 0.93 : 1.0);
+        const double eff = c.w32 ? 0.5 : ((c.MR * c.NC > 1) ? 0.93 : 1.0);
         const double cost = eff * waste * rounds * (double)c.bpc * kNumCU / ((double)gx * gy * nsplit);
         if (cost < best) {
             best = cost;

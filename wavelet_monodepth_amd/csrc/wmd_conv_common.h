@@ -40,12 +40,6 @@ struct ConvKArgs {
     const uint8_t* in_mask;
     const uint8_t* out_mask;
     int in_mask_2x2;   // in_mask is constant on aligned 2x2 blocks (wmd_conv_args.in_mask_2x2)
-    // encoder edge (wmd_conv_args.x1_scale ...): x1 is read through act(x1 * scale[c] + shift[c]) -- PRE instantiations of
-    // conv_fwd_kernel only
-    const float* x1_scale;
-    const float* x1_shift;
-    int x1_pre_act;
-    float x1_pre_slope;
     // out-channel slabs per pixel tile when the grid is 1-D (0: the slab is blockIdx.y -- the fused-head launches)
     int cob;
     // work-list form of the block-sparse execution (wmd_conv_args.out_tiles; LIST instantiations of conv_wino32_kernel): item i

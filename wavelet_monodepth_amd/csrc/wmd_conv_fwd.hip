@@ -54,11 +54,10 @@ struct ConvTile {
     static_assert(TW % 4 == 0, "four consecutive pixels of an accumulator row must not straddle image rows");
 };
 
-// PRE (encoder edge, wmd_conv_args.x1_scale / x1_shift / x1_pre_act): the only source tensor x1 is an encoder's last
-// PRE-activation; every value is passed through act(v * scale[c] + shift[c]) between its LDS read and its MFMA (the per-channel
-// constants of the block's K range sit in LDS), so the encoder never writes -- and this kernel never re-reads -- the activated
-// feature map.  Padding must not be zero padding (a padded 0 would become act(shift)).
-template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, bool FUSE = false, int NBUF = 2, bool PRE = false>
+// (Round 3's PRE instantiations -- the encoder edge: act(v * scale[c] + shift[c]) applied to every operand between its LDS
+//  read and its MFMA -- were measured slower than activating the map in a pass of its own and running the tuned kernel
+//  (R18: 75.4 vs 66.9 us, R50: 432.9 vs 170.5 us) and are gone; layers.DeferredActivation activates explicitly.)
+template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS, bool FUSE = false, int NBUF = 2>
 __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a) {
     using T = ConvTile<TH, TW, MR, NR, WM, WN, CK, TAPS, NBUF>;
     constexpr int NT = T::NT, HALO = T::HALO, PW = T::PW, PS = T::PS, NPOS = T::NPOS;
@@ -67,8 +66,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
     constexpr int MID_FLOATS = FUSE ? WM * MR * 16 * T::PS : 0;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS > MID_FLOATS ? T::LDS_FLOATS : MID_FLOATS];
     float* ldsA = lds + NBUF * T::B_FLOATS;
-    constexpr int PRE_MAXC = 2304;      // channels of x1 a PRE launch accepts (DenseNet161: 2208)
-    __shared__ float pre_sc[PRE ? PRE_MAXC : 1], pre_sh[PRE ? PRE_MAXC : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,13 +196,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
 #pragma unroll
         for (int q = 0; q < NPIECES; ++q) stage_piece(c_begin, 0, q);
     }
-    const bool pre_relu_only = PRE && !a.x1_scale && !a.x1_shift && a.x1_pre_act == WMD_ACT_LEAKY && a.x1_pre_slope == 0.f;
-    if constexpr (PRE) {     // per-channel constants of this block's K range (the barrier below publishes them)
-        for (int ch = c_begin * CK + tid; ch < min(c_end * CK, PRE_MAXC); ch += WM * WN * 64) {
-            pre_sc[ch] = (a.x1_scale && ch < a.C1) ? a.x1_scale[ch] : 1.f;
-            pre_sh[ch] = (a.x1_shift && ch < a.C1) ? a.x1_shift[ch] : 0.f;
-        }
-    }
     // epilogue operands requested now: a global load at the start of the epilogue is an exposed round trip per block
     float bias_v[MR];
 #pragma unroll
@@ -230,15 +220,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
         const float* bsrc = lds + buf * T::B_FLOATS;
         const float* asrc = ldsA + buf * T::A_FLOATS + a_lane;
         float pf[RS][NR], wf[RS][MR];
-        float psc[PRE ? KSTEPS : 1], psh[PRE ? KSTEPS : 1];     // this lane's channel of every K-step of the chunk
-        if constexpr (PRE) {
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                const int ch = min(c * CK + kk * 4 + (lane >> 4), PRE_MAXC - 1);
-                psc[kk] = pre_sc[ch];
-                psh[kk] = pre_sh[ch];
-            }
-        }
         auto fetch = [&](int s) {
             const int kk = s / TAPS, tp = s % TAPS, slot = s % RS;
             const int ky = (TAPS == 9) ? tp / 3 : 0, kx = (TAPS == 9) ? tp % 3 : 0;
@@ -258,18 +239,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvKArgs a
             }
             if (s + D < S) fetch(s + D);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PRE) {
-                if (pre_relu_only) {     // ResNet's edge: one v_max per operand
-#pragma unroll
-                    for (int n = 0; n < NR; ++n) pf[s % RS][n] = fmaxf(pf[s % RS][n], 0.f);
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NR; ++n) {
-                        const float v = fmaf(pf[s % RS][n], psc[s / TAPS], psh[s / TAPS]);
-                        pf[s % RS][n] = a.x1_pre_act == WMD_ACT_LEAKY ? (v > 0.f ? v : v * a.x1_pre_slope) : v;
-                    }
-                }
-            }
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -901,25 +870,12 @@ struct ConvCfg {
     int lds_bytes;
     void (*launch)(const ConvKArgs&, dim3, hipStream_t);
     const char* name;
-    bool pre = false;     // the PRE instantiation (encoder edge): only considered when the call asks for it, and then alone
 };
 
 template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
 static void launch_cfg(const ConvKArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((conv_fwd_kernel<TH, TW, MR, NR, WM, WN, CK, TAPS>), grid, dim3(WM * WN * 64), 0, s, a);
 }
-
-template <int TH, int TW, int MR, int NR, int WM, int WN, int CK, int TAPS>
-static void launch_cfg_pre(const ConvKArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_fwd_kernel<TH, TW, MR, NR, WM, WN, CK, TAPS, false, 2, true>), grid, dim3(WM * WN * 64), 0, s, a);
-}
-#define WMD_CFG_PRE(TH, TW, MR, NR, WM, WN, CK, TAPS)                                                   \
-    ConvCfg {                                                                                           \
-        TH, TW, MR, NR, WM, WN, CK, TAPS,                                                               \
-            (int)sizeof(float) * (ConvTile<TH, TW, MR, NR, WM, WN, CK, TAPS>::LDS_FLOATS + 2 * 2304),   \
-            &launch_cfg_pre<TH, TW, MR, NR, WM, WN, CK, TAPS>,                                          \
-            "conv_fwd_kernel<" #TH "," #TW "," #MR "," #NR "," #WM "," #WN "," #CK "," #TAPS ",pre>", true \
-    }
 
 #define WMD_CFG(TH, TW, MR, NR, WM, WN, CK, TAPS)                                                       \
     ConvCfg {                                                                                           \
@@ -1014,11 +970,6 @@ static const ConvCfg kCfgs[] = {
     WMD_WINO(16, 32, 1, 2, 8, 8),   // co32 x 512px, 16 waves
     // Winograd on 32x32x2 MFMAs, two position halves per tile group
 #include "wmd_conv_wino32_table.inc"
-    // encoder edge: x1 read through act(x1 * scale + shift) (wmd_conv_args.x1_pre_act); chosen only when asked for
-    WMD_CFG_PRE(6, 20, 2, 4, 2, 2, 8, 9),    // the 6x20 / 12x40 coarsest maps of 640x192
-    WMD_CFG_PRE(5, 32, 4, 5, 2, 2, 8, 9),    // 10x32 (1024x320)
-    WMD_CFG_PRE(4, 16, 4, 4, 1, 1, 8, 9),    // any W
-    WMD_CFG_PRE(1, 64, 4, 4, 1, 1, 32, 1),   // 1x1 (NYUv2 conv2 on 15x20)
     // 1x1 on the flattened image (TH = 1)
     WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
     WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px
@@ -1059,7 +1010,6 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             if (c.TAPS != 17 || c.TH != g->out_tile_h || c.TW != g->out_tile_w || !wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK)) continue;
             if (Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK) || (g->in_mask && g->up1 == 2 && !g->in_mask_2x2)) continue;   // wino32_pure
         }
-        if (c.pre != (g->x1_pre_act != 0 || g->x1_scale || g->x1_shift)) continue;   // encoder edge: the PRE instantiations, and only then
         if (force >= 0 && force != i) continue;
         const int tiles_x = (W + c.TW - 1) / c.TW, tiles_y = (H + c.TH - 1) / c.TH;
         const long tiles = (long)g->B * tiles_x * tiles_y;
@@ -1404,15 +1354,6 @@ static int validate_conv(const wmd_conv_args* g, const char* who) {
         if (!wmd_conv_list_tile_supported(g->out_tile_h, g->out_tile_w))
             return fail(WMD_ERR_UNSUPPORTED, "%s: no work-list kernel for %dx%d tiles", who, g->out_tile_h, g->out_tile_w);
     }
-    if (g->x1_pre_act != WMD_ACT_NONE || g->x1_scale || g->x1_shift) {   // encoder edge
-        if (g->x1_pre_act != WMD_ACT_NONE && g->x1_pre_act != WMD_ACT_LEAKY)
-            return fail(WMD_ERR_UNSUPPORTED, "%s: x1_pre_act=%d (none, or LeakyReLU; ReLU = slope 0)", who, g->x1_pre_act);
-        if (g->C2 > 0 || g->in_mask || g->out_mask || g->gate)
-            return fail(WMD_ERR_UNSUPPORTED, "%s: the pre-activation edge takes one source tensor, no masks, no gate", who);
-        if (g->ksize == 3 && g->pad_mode == WMD_PAD_ZERO)
-            return fail(WMD_ERR_UNSUPPORTED, "%s: pre-activation on load with zero padding (a padded 0 would become act(shift))", who);
-        if (g->C1 > 2304) return fail(WMD_ERR_UNSUPPORTED, "%s: pre-activation edge with C1=%d > 2304", who, g->C1);
-    }
     return WMD_OK;
 }
 
@@ -1491,10 +1432,6 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.in_mask = g->in_mask;
     a.out_mask = g->out_mask;
     a.in_mask_2x2 = g->in_mask_2x2;
-    a.x1_scale = g->x1_scale;
-    a.x1_shift = g->x1_shift;
-    a.x1_pre_act = g->x1_pre_act;
-    a.x1_pre_slope = g->x1_pre_slope;
     if ((g->out_mask || g->in_mask) && !wino)
         return fail(WMD_ERR_UNSUPPORTED, "wmd_conv: masks (block-sparse execution) need a 3x3 layer and the Winograd weight image (wp_wino)");
     const int cob = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);

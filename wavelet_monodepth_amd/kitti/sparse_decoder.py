@@ -4,6 +4,9 @@ state_dict keys as the dense decoder (checkpoints are interchangeable), `forward
 thresh_ratio=0.05, sparse_scales=[0,1,2,3])`, same output keys incl. the five mask families and the
 `total_ops` op model.  Inference only; batch 1 like the reference, or (extension) a batch of frames decoded together.
 
+The five masks of the coarsest level (always all ones) are views of one cached constant shared by every call: treat the returned
+masks as read-only.
+
 Differences that are not observable in the outputs: activations stay dense and zero-initialised instead of
 being compacted (see include/wmd.h); the forward never waits for the GPU -- the python-int `total_ops` entries are
 resolved from the device-side pixel counts on first access (sparse_ops.LazyOpsDict), so independent frames can be

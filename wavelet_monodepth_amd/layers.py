@@ -16,9 +16,10 @@ class DeferredActivation:
     """An encoder's last feature map handed over BEFORE its final activation (the encoder edge):
     `tensor` is the pre-activation, the consumer reads it as  act(tensor * scale[c] + shift[c])  (scale / shift optional
     per-channel float32 tensors: an eval-mode BatchNorm folded into the edge; act in {"none", "leaky"}, ReLU = leaky with
-    slope 0).  The decoders pass it to their first convolution, which applies it on load (ops.conv2d_pre_activated ->
-    wmd_conv_args.x1_pre_act), so the activated map is never written or re-read; under autograd they call `activate()` and
-    run the ordinary path.  encoders.ResnetEncoder(defer_last_relu=True) produces one."""
+    slope 0).  The decoders hand it to ops.conv2d_pre_activated, which activates it in one elementwise pass and runs the tuned
+    convolution (round 3's activation-on-load kernels measured slower and are gone); under autograd they call `activate()` and
+    run the ordinary path.  encoders.ResnetEncoder(defer_last_relu=True) produces one; off by default: an interface for
+    encoders that end before their activation, not a speed-up."""
 
     def __init__(self, tensor, act="leaky", slope=0.0, scale=None, shift=None):
         if act not in ("none", "leaky"):

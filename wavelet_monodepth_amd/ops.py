@@ -194,13 +194,12 @@ def pack_weights_wino(weight, dgrad=False):
 # ---------------------------------------------------------------------------------------------
 
 def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=None, in_mask=None, out_mask=None, out=None,
-                  in_mask_2x2=False, x1_pre=None, out_tiles=None):
+                  in_mask_2x2=False, out_tiles=None):
     """in_mask / out_mask (uint8 [B,H,W]) + out (zero-initialised [B,cout,H,W]): block-sparse execution, see
     wmd_conv_args.in_mask in include/wmd.h; in_mask_2x2: the caller's promise that in_mask is constant on 2x2 blocks.
     out_tiles = (list int32, count int32 scalar, tile_h, tile_w): the work-list form (wmd_conv_args.out_tiles, built by
     sparse_ops.mask_level_lists) -- only listed tiles are computed, the split of the reduction is chosen on the device.
-    x1_pre = (scale [C1] or None, shift [C1] or None, act, slope): x1 is read through act(x1 * scale + shift)
-    (wmd_conv_args.x1_pre_act: the encoder edge)."""
+    """
     l = _lib.lib()
     B, C1 = x1.shape[0], x1.shape[1]
     H, W = x1.shape[2] * up1, x1.shape[3] * up1
@@ -217,13 +216,6 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
     if out_tiles is not None:
         tl, tc, th, tw = out_tiles
         a.out_tiles, a.out_tile_count, a.out_tile_h, a.out_tile_w = ptr(tl), ptr(tc), int(th), int(tw)
-    if x1_pre is not None:
-        psc, psh, pact, pslope = x1_pre
-        _require_gpu(psc, psh)
-        for v in (psc, psh):
-            if v is not None and (v.dtype != torch.float32 or v.numel() != C1 or not v.is_contiguous()):
-                raise _lib.WmdError("x1_pre: scale / shift must be contiguous float32 tensors with one value per x1 channel")
-        a.x1_scale, a.x1_shift, a.x1_pre_act, a.x1_pre_slope = ptr(psc), ptr(psh), ACT[pact], float(pslope)
     stream = current_stream()
     keep = []
 
@@ -242,8 +234,6 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
     choice = (0, 0)
     if tuner.enabled and out_tiles is None:     # (a work list fixes the tile shape; the K split is the device's decision)
         key = "conv|%d|%d|%d|%d|%d|%d|%d|%d" % (B, H, W, C1, up1, C2, cout, ksize)  # str: JSON-cacheable
-        if x1_pre is not None:
-            key += "|pre"      # encoder edge: its own instantiations of the direct kernel
         if wp_wino is None and ksize == 3:
             key += "|direct"   # a choice made with the Winograd configurations on offer must not be reused without them
         if out_mask is not None:
@@ -253,7 +243,7 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
             if torch.cuda.is_current_stream_capturing():
                 choice = (0, 0)  # cannot time inside a capture: the library's cost model decides
             else:
-                choice = tuner.tune(key, 9 if ksize == 3 else 1, launch, suffix=",pre>" if x1_pre is not None else None)
+                choice = tuner.tune(key, 9 if ksize == 3 else 1, launch)
     check(launch(*choice), "wmd_conv_fwd")
     return y
 
@@ -339,16 +329,33 @@ def _wgrad_launch(a, device):
 
 
 def conv2d_pre_activated(x1, x1_pre, weight, bias=None, up1=1, pad="reflect", act="none", slope=0.0):
-    """Inference form of conv2d_fused for an x1 that is still a PRE-activation: act( conv( pad( nearest_up( pre(x1) ) ) ) + bias )
-    with pre(v)[c] = pre_act(v * scale[c] + shift[c]) applied on load (wmd_conv_args.x1_pre_act; x1_pre = (scale, shift, act,
-    slope), see layers.DeferredActivation).  No autograd: the training path activates the tensor and calls conv2d_fused."""
+    """conv2d_fused for an x1 that is still a PRE-activation (the encoder edge, layers.DeferredActivation):
+    act( conv( pad( nearest_up( pre(x1) ) ) ) + bias ) with pre(v)[c] = pre_act(v * scale[c] + shift[c]); x1_pre = (scale, shift,
+    act, slope).  Round 3 applied pre() on load inside dedicated instantiations of the direct kernel; that form lost the tuned
+    Winograd / split-K choice and measured SLOWER than one elementwise pass + the tuned convolution (tools/edge_microbench.py:
+    R18 640x192 b12 75.4 vs 66.9 us, R50 1024x320 b8 432.9 vs 170.5 us), so the edge is activated explicitly here and the
+    instantiations are gone (round 4).  Inference operator, like the decoders' use of it."""
     _require_gpu(x1, weight, bias)
     if torch.is_grad_enabled() and (x1.requires_grad or weight.requires_grad):
         raise _lib.WmdError("conv2d_pre_activated is an inference operator (activate the tensor and use conv2d_fused to train)")
-    ksize = weight.shape[-1]
     if weight.shape[1] != x1.shape[1]:
         raise _lib.WmdError("weight expects %d input channels, got %d" % (weight.shape[1], x1.shape[1]))
-    return _conv_fwd_raw(_c(x1), None, pack_weights(weight), _c(bias), weight.shape[0], ksize, pad, act, slope, up1, None, x1_pre=x1_pre)
+    psc, psh, pact, pslope = x1_pre
+    _require_gpu(psc, psh)
+    if pact not in ("none", "leaky", None):
+        raise _lib.WmdError("conv2d_pre_activated: the edge's activation is 'none' or 'leaky' (ReLU = slope 0), got %r" % (pact,))
+    for v in (psc, psh):
+        if v is not None and (v.dtype != torch.float32 or v.numel() != x1.shape[1]):
+            raise _lib.WmdError("x1_pre: scale / shift must be float32 tensors with one value per x1 channel")
+    with torch.no_grad():
+        v = x1
+        if psc is not None:
+            v = v * psc.view(1, -1, 1, 1)
+        if psh is not None:
+            v = v + psh.view(1, -1, 1, 1)
+        if pact == "leaky":
+            v = torch.relu(v) if pslope == 0.0 else torch.nn.functional.leaky_relu(v, pslope)
+        return conv2d_fused(v, weight, bias, up1=up1, pad=pad, act=act, slope=slope)
 
 
 def conv2d_fused(x1, weight, bias=None, x2=None, up1=1, pad="reflect", act="none", slope=0.0, x1_gate=None, grad_is_dz=False):

@@ -82,15 +82,11 @@ def _time(launch, cfg, ks, reps, e0, e1):
     return t
 
 
-def tune(key, taps, launch, suffix=None):
+def tune(key, taps, launch):
     """launch(cfg1, ks) -> status int (0 ok). Returns (cfg1, ks) with the smallest GPU time:
-    a coarse sweep (min of 2 runs each) followed by a 6-run play-off between the five best.
-    suffix: consider only the configurations whose name ends with it (the ",pre>" instantiations of the encoder edge)."""
+    a coarse sweep (min of 2 runs each) followed by a 6-run play-off between the five best."""
     names = config_names()
-    if suffix is not None:
-        cands = [i + 1 for i, n in enumerate(names) if n.endswith(",%d%s" % (taps, suffix))]
-    else:
-        cands = [i + 1 for i, n in enumerate(names) if n.endswith(",%d>" % taps) or (taps == 9 and n.startswith("conv_wino"))]
+    cands = [i + 1 for i, n in enumerate(names) if n.endswith(",%d>" % taps) or (taps == 9 and n.startswith("conv_wino"))]
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     results = []
