@@ -430,7 +430,7 @@ def main():
         torch.cuda.synchronize()
 
     # Order of the passes.  The driver's protocol is short (--steps 20 --warmup 5 = 18 ms of GPU work), and an MI355X that has
-    # idled through the model set-up spends its first milliseconds below its steady clocks (tools/bench_protocol_probe.py,
+    # idled through the model set-up spends its first milliseconds below its steady clocks (tools/probes/bench_protocol_probe.py,
     # same box: 0.750 ms/step measured cold against 0.716 after activity, 0.712 steady).  So the per-kernel roofline pass --
     # K eager steps with a hipEvent pair around every launch, needed anyway -- runs FIRST; the W warm-up replays follow
     # directly (the first of them captures the graphs), then the timed region: EXACTLY K steps between barrier + synchronize,

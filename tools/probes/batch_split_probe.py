@@ -1,6 +1,6 @@
 """Config 2 (batch 12) as ONE graph vs two half-batch graphs replayed on two streams (development aid)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from wavelet_monodepth_amd import synth, tuner

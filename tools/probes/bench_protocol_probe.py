@@ -1,12 +1,12 @@
 """What the driver's short protocol (--steps 20 --warmup 5) costs against steady state (development aid): the replayed
 config-2 forward timed over K steps after W warm-ups, with and without a per-step event record in the timed loop."""
 import os, sys, time
-ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from wavelet_monodepth_amd import synth, tuner
 from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
-tuner.preload(os.path.join(ROOT, "profiles", "r03_tune_cache.json"))
+tuner.preload(os.path.join(ROOT, "profiles", "r04_tune_cache.json"))
 dev = torch.device("cuda:0")
 R18 = [64, 64, 128, 256, 512]
 dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=1).to(dev).eval()

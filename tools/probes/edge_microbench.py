@@ -1,7 +1,7 @@
 """Encoder edge: upconv(4,0) on the encoder's last pre-activation with the ReLU applied on load, against
 ReLU (a PyTorch elementwise kernel, what the encoder would run) + the ordinary convolution (development aid)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import torch
 from wavelet_monodepth_amd import ops, synth

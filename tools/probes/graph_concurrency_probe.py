@@ -1,7 +1,7 @@
 """Does a replayed hipGraph run two independent small kernels side by side?  Two under-filling convolutions (180
 workgroups each on 256 CUs) captured (a) back to back on one stream, (b) forked onto two streams (development aid)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import torch
 from wavelet_monodepth_amd import ops, synth

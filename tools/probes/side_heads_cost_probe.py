@@ -1,7 +1,7 @@
 """How much of the replayed config-2 step do the side-stream heads (levels 4-2) and the level-1 head cost?  Replays the
 captured segments with some of them left out (outputs are then stale: timing only).  Development aid."""
 import os, sys, time
-ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from wavelet_monodepth_amd import synth, tuner

@@ -46,7 +46,7 @@ sparse)
     WMD_SPARSE_LISTS=0 python tools/config_bench.py sparse sparse-throughput > $OUT/sparse_workloads_r03form.txt 2>&1    # round-3 tile form, same box
     grep "sparse\|throughput" $OUT/sparse_workloads.txt | tail -n 50
     bash tools/sparse_timeline_session.sh > $OUT/sparse_timelines.txt 2>&1      # one graph replay each, kernel by kernel
-    for f in dense_b1 sparse_b1_tiles sparse_b1_gather dense_b12 sparse_b12_d0.1 sparse_b12_contour; do
+    for f in dense_b1 sparse_b1_gather sparse_b1_lists sparse_b1_r03form sparse_b1_lists_contour dense_b12 sparse_b12_d0.1 sparse_b12_thr0.2 sparse_b12_contour sparse_b12_contour_r03form; do
         echo "==== $f" >> $OUT/sparse_timelines.txt; cat gpurun_out/tl/$f.txt >> $OUT/sparse_timelines.txt; done
     export WMD_TUNE_CACHE=$OUT/sparse_tune_cache.json
     python tools/sparse_profile.py 0.15 > $OUT/sparse_profile_thr0.15.txt 2>&1

@@ -861,7 +861,8 @@ static bool plan_wgrad_wino(const wmd_conv_wgrad_args* g, WgradWinoPlan* p) {
         const double waste = ((double)gx * cit / Cin) * ((double)gy * cot / g->Cout) * pix_waste;
         long nsplit = std::max<long>(1, ((long)c.bpc * kNumCU + (long)gx * gy - 1) / ((long)gx * gy));
         nsplit = std::min<long>(nsplit, std::max<long>(1, ntiles / 4));
-        nsplit = std::min<long>(nsplit, 128);
+        static const long ns_cap = [] { const char* e = getenv("WMD_WGRAD_NSPLIT_CAP"); return e && atoi(e) > 0 ? (long)atoi(e) : 256L; }();   // (128 until round 4: single-slab layers -- Cout = 32 -- then ran 256 blocks on 512 slots: L14 242 -> 209 us)
+        nsplit = std::min<long>(nsplit, ns_cap);
         if (e_ns && atoi(e_ns) > 0) nsplit = std::min<long>(atoi(e_ns), std::max<long>(1, ntiles));
         if (g->tune_nsplit > 0) nsplit = std::min<long>(g->tune_nsplit, std::max<long>(1, ntiles));
         const double rounds = std::ceil((double)gx * gy * nsplit / ((double)c.bpc * kNumCU));

@@ -332,7 +332,7 @@ def conv2d_pre_activated(x1, x1_pre, weight, bias=None, up1=1, pad="reflect", ac
     """conv2d_fused for an x1 that is still a PRE-activation (the encoder edge, layers.DeferredActivation):
     act( conv( pad( nearest_up( pre(x1) ) ) ) + bias ) with pre(v)[c] = pre_act(v * scale[c] + shift[c]); x1_pre = (scale, shift,
     act, slope).  Round 3 applied pre() on load inside dedicated instantiations of the direct kernel; that form lost the tuned
-    Winograd / split-K choice and measured SLOWER than one elementwise pass + the tuned convolution (tools/edge_microbench.py:
+    Winograd / split-K choice and measured SLOWER than one elementwise pass + the tuned convolution (tools/probes/edge_microbench.py:
     R18 640x192 b12 75.4 vs 66.9 us, R50 1024x320 b8 432.9 vs 170.5 us), so the edge is activated explicitly here and the
     instantiations are gone (round 4).  Inference operator, like the decoders' use of it."""
     _require_gpu(x1, weight, bias)
