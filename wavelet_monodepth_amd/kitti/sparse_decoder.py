@@ -199,9 +199,9 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         lv = sorted(i for i in set(sparse_scales) if 1 <= i <= 3)
         shapes = tuple(tuple(f.shape) for f in input_features)
         if graph:
-            key = ("g", tuple(f.data_ptr() for f in input_features), shapes, tuple(lv))
+            key = ("g", dev.index, tuple(f.data_ptr() for f in input_features), shapes, tuple(lv))
         else:
-            key = ("e", torch.cuda.current_stream(dev).cuda_stream, shapes, tuple(lv))
+            key = ("e", dev.index, torch.cuda.current_stream(dev).cuda_stream, shapes, tuple(lv))
         st = self._states.get(key)
         if st is None:
             if len(self._states) >= 64:
@@ -442,10 +442,18 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         forced_tile = os.environ.get("WMD_SPARSE_TILE")
         big_from = int(os.environ.get("WMD_SPARSE_BIG_FROM", "700"))
 
+        # ... and no list at all below WMD_SPARSE_LIST_FROM items (one frame): the launch then runs the masked kernel the autotuner
+        # picked for the shape (a block per tile tests its own mask bytes; host-chosen split-K) -- with a few dozen tiles on 256 CUs
+        # nothing is gained by compacting them, and the tuned 16x16x4 / 32x32x2 kernels of round 3 are 10-20 % faster per launch
+        # than the list kernel's one tile shape (r04_sparse_timelines.txt: 99 + 25 us of convolutions + reduces against 107 + 37)
+        list_from = int(os.environ.get("WMD_SPARSE_LIST_FROM", "256"))
+
         def tile_for(hh, ww, cout):
             if forced_tile:
                 return tuple(int(v) for v in forced_tile.split("x"))
             items = B * (-(-hh // 8)) * (-(-ww // 16)) * (-(-cout // 32))
+            if items < list_from:
+                return None
             return (16, 16) if items > big_from else (8, 16)
         unpack = lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias)
         counters, static_ops = [], {}
