@@ -63,6 +63,102 @@ def test_fused_mask_level_equals_the_three_primitives_and_the_oracle(dev):
             assert torch.equal(fused[2].cpu().float(), R.dilate(ref, 5)[0, 0])
 
 
+@pytest.mark.parametrize("B,h,w", [(1, 12, 40), (3, 24, 80), (12, 48, 160), (2, 7, 9)])
+def test_mask_level_lists_masks_lists_counts_and_protocol(dev, B, h, w):
+    """wmd_mask_level_lists (round 4): the masks are those of wmd_mask_level_b (bit-exact), the per-frame work lists hold exactly
+    the tiles that contain a set pixel (as sets: the order inside a list is unspecified), the pixel counts arrive in the ring
+    slot of the forward, stamped; the range keys are consumed and re-armed; scratch is all zero again after every launch;
+    three forwards in a row land in three slots (the second and third with an injected mask and an AND mask)."""
+    from wavelet_monodepth_amd import sparse_ops as S
+    yl = t(synth.normal((B, 1, 2 * h, 2 * w), "lyl", 9)).to(dev)
+    yh = t(synth.normal((B, 1, 3, h, w), "lyh", 9)).to(dev)
+    st = S.LevelState(dev, B, 2, 16)
+    # the range the head epilogue would have left: order-preserving keys of (min, max) per frame
+    lo, hi = yl.reshape(B, -1).min(1)[0], yl.reshape(B, -1).max(1)[0]
+    key = lambda v: torch.where(v.view(torch.int32) < 0, ~v.view(torch.int32), v.view(torch.int32) | -2147483648)
+    st.keys.copy_(torch.stack([key(lo.contiguous()), key(hi.contiguous())], 1))
+    specs = [(1, 1, 0, None), (1, 2, 1, (8, 16)), (2, 2, 0, None), (2, 1, 2, (16, 16)), (2, 0, 3, None)]
+    ref = S.mask_level(yl, yh, 0.3, [(u, r) for u, r, _c, _t in specs]) if B > 1 else \
+        [m.unsqueeze(0) for m in S.mask_level(yl, yh, 0.3, [(u, r) for u, r, _c, _t in specs])]
+
+    def check(masks, lists, want, k, counts_off):
+        for m, r in zip(masks, want):
+            assert torch.equal(m.reshape(r.shape), r)
+        for j, (m, l) in enumerate(zip(masks, lists)):
+            if l is None:
+                continue
+            tl, tc, th, tw = l
+            H, W = m.shape[-2:]
+            ty, tx = -(-H // th), -(-W // tw)
+            pad = torch.zeros((B, ty * th, tx * tw), dtype=torch.uint8)
+            pad[:, :H, :W] = m.cpu()
+            act = pad.view(B, ty, th, tx, tw).amax((2, 4)).reshape(B, -1)
+            cnt = tc.cpu().tolist()
+            for f in range(B):
+                expect = {int(f * ty * tx + i) for i in torch.nonzero(act[f]).reshape(-1)}
+                got = tl.cpu()[f * ty * tx:f * ty * tx + cnt[f]].tolist()
+                assert cnt[f] == len(expect) and set(got) == expect and len(set(got)) == len(got), (j, f)
+        slot = st.ring.cpu()[(k % st.RING) * st.slot_ints:(k % st.RING + 1) * st.slot_ints].tolist()
+        assert slot[0] == k + 1, "stamp"
+        for f in range(B):
+            got = slot[1 + counts_off + 3 * f:1 + counts_off + 3 * f + 3]
+            assert got == [int(masks[1][f].sum()), int(masks[3][f].sum()), int(masks[4][f].sum())], (f, got)
+        assert int(st.scratch.abs().sum()) - int(st.scratch[1]) == 0 and int(st.scratch[1]) == k + 1     # all re-armed, seq advanced
+
+    masks, lists = S.mask_level_lists(st, B, h, w, specs, 0.3, yl=yl, yh=yh, use_keys=True, counts_off=0, advance=True)
+    check(masks, lists, ref, 0, 0)
+    assert st.keys.cpu().tolist() == [[-1, 0]] * B               # consumed and re-armed
+    # injected base mask + AND mask (the input support of upconv(i,0)); second counts column block of the slot
+    gen = torch.Generator().manual_seed(3)
+    m0 = (torch.rand((B, h, w), generator=gen) < 0.2).to(torch.uint8).to(dev)
+    andm = (torch.rand((B, h, w), generator=gen) < 0.5).to(torch.uint8).to(dev)
+    want = S.dilate_multi(m0, [(u, r) for u, r, _c, _t in specs])
+    for k in (1, 2):
+        masks, lists = S.mask_level_lists(st, B, h, w, specs + [(1, 1, 0, None, andm)], mask0=m0, counts_off=3 * B, advance=True)
+        check(masks[:5], lists[:5], want, k, 3 * B)
+        assert torch.equal(masks[5], want[0] & andm)
+
+
+@pytest.mark.parametrize("case", [(1, 24, 80, 128, 1, 0, 64, (8, 16)), (1, 48, 160, 64, 2, 64, 64, (8, 16)), (12, 24, 80, 32, 2, 32, 32, (16, 16)),
+                                  (2, 12, 40, 256, 1, 0, 128, (8, 16)), (1, 22, 50, 16, 1, 0, 40, (8, 16))],
+                         ids=lambda c: "x".join(str(v) for v in c[:7]))
+@pytest.mark.parametrize("density", [0.0, 0.03, 0.5, 1.0])
+def test_conv_work_list_form_equals_the_mask_form_and_the_oracle(dev, case, density):
+    """wmd_conv_fwd with out_tiles (round 4: LIST instantiations, device-chosen K split, list-driven second pass) against the
+    mask form of the same call (per-block mask tests, host-chosen split) -- identical support, values to 2e-6 -- and against the
+    oracle's masked convolution; empty lists, a few tiles (every slice of a deep K split), all tiles, a ragged map (the scalar
+    path of the second pass), several frames."""
+    from wavelet_monodepth_amd import ops, sparse_ops as S
+    B, H, W, C1, up, C2, Cout, tile = case
+    x1 = t(synth.normal((B, C1, H // up, W // up), "wlx", 4)).to(dev)
+    x2 = t(synth.normal((B, C2, H, W), "wls", 4)).to(dev) if C2 else None
+    wgt, bias = [t(a).to(dev) for a in synth.conv_params("wlw", Cout, C1 + C2, 3, 4)]
+    gen = torch.Generator().manual_seed(11)
+    base = (torch.rand((B, H // 2, W // 2), generator=gen) < density).to(torch.uint8).to(dev)
+    st = S.LevelState(dev, B, 1, 16)
+    (in_mask, out_mask), lists = S.mask_level_lists(st, B, H // 2, W // 2, [(2, 2, 0, None), (2, 1, 1, tile)], mask0=base, advance=True)
+    args = (x1, x2, ops.pack_weights(wgt), bias, Cout, 3, "reflect", "elu", 0.0, up, ops.pack_weights_wino(wgt))
+    y_list = torch.full((B, Cout, H, W), 7.0, device=dev)
+    ops._conv_fwd_raw(*args, in_mask=in_mask, out_mask=out_mask, out=y_list, in_mask_2x2=True, out_tiles=lists[1])
+    y_mask = torch.full((B, Cout, H, W), 7.0, device=dev)
+    ops._conv_fwd_raw(*args, in_mask=in_mask, out_mask=out_mask, out=y_mask, in_mask_2x2=True)
+    th, tw = tile
+    act = torch.zeros((B, -(-H // th) * th, -(-W // tw) * tw), dtype=torch.bool, device=dev)
+    act[:, :H, :W] = out_mask.bool()
+    act = act.view(B, -1, th, act.shape[2] // tw, tw).amax((2, 4), keepdim=True).expand(-1, -1, th, -1, tw).reshape(B, -1, act.shape[2])[:, :H, :W]
+    # unlisted tiles are not written (the never-refilled pool), listed tiles hold the masked convolution
+    assert bool((y_list[(~act).unsqueeze(1).expand_as(y_list)] == 7.0).all())
+    xin = torch.cat([R.up2(x1.cpu()) if up == 2 else x1.cpu()] + ([x2.cpu()] if C2 else []), 1) * in_mask.cpu().unsqueeze(1).float()
+    # (the mask test follows the coordinate padding: pad the masked input, KITTI/layers.py:439-453)
+    ref = torch.nn.functional.elu(R.conv3x3(xin, wgt.cpu(), bias.cpu(), "reflect")) * out_mask.cpu().unsqueeze(1).float()
+    sel = act.unsqueeze(1).expand_as(y_list).cpu()
+    if bool(sel.any()):
+        assert_close(y_list.cpu()[sel], ref[sel], 2e-5, "work-list form vs oracle")
+        # the mask form computes whole 8x32 / 6x40 ... tiles of its own: compare where both wrote
+        both = sel & (y_mask.cpu() != 7.0)
+        assert_close(y_list.cpu()[both], y_mask.cpu()[both], 2e-6, "work-list form vs mask form")
+
+
 @pytest.mark.parametrize("ksize,dual", [(3, False), (1, False), (3, True)])
 def test_sparse_conv_every_k_split_mode_vs_dense_reference(dev, ksize, dual):
     """The wavefronts of a block either split K for one tile or take whole K ranges of separate tiles, decided on the
