@@ -48,6 +48,7 @@ struct ConvKArgs {
     // result to y_final
     const int* tile_list;    // [B][tiles_y * tiles_x]: frame f's active tiles are the first tile_count[f] entries of its segment
     const int* tile_count;   // [B]
+    int no_x4;               // development switch (WMD_X4=0): dword pieces everywhere
     int ksmax;
     int list_slots;          // workgroup slots of the machine for this kernel (blocks per CU x CUs): the device's K-split target
     float* y_final;
@@ -89,14 +90,21 @@ template <int TH, int TW, int WN, int CK>
 struct W32Tile {
     static constexpr int NW = WN * 2, NT = NW * 64;
     static constexpr int TXB = TW / 2, TYB = TH / 2, NTILES = TXB * TYB;
-    static constexpr int PH = TH + 2, PWS = TW + 2;          // full-resolution patch: rows x row stride (even: 8-byte reads)
+    // Patch row strides are whole 16-byte groups (round 4): a tile whose patch columns all lie inside the image stages a chunk
+    // with 16-byte LDS-DMA pieces -- a quarter of the staging instructions (gfx950 accepts 4-byte-aligned global addresses for
+    // them: tools/probes/dma16_probe.hip) --, the columns beyond TW + 2 / TW/2 + 2 are padding nobody reads
+    // (32- / 64- / 16-wide tiles only: the 40-wide ones lose more to the longer rows -- 6x40 measured +12 % -- than their rare
+    //  interior tiles could gain)
+    static constexpr bool X4OK = TW % 16 == 0;
+    static constexpr int PH = TH + 2, PWS = X4OK ? ((TW + 2 + 3) / 4) * 4 : TW + 2;          // full-resolution patch: rows x row stride (even: 8-byte reads)
     static constexpr int PSF = PH * PWS;
-    static constexpr int PHL = TH / 2 + 2, PWL = TW / 2 + 2, PSL = PHL * PWL;   // low-resolution patch of the upsampled operand
+    static constexpr int PHL = TH / 2 + 2, PWL = X4OK ? ((TW / 2 + 2 + 3) / 4) * 4 : TW / 2 + 2, PSL = PHL * PWL;   // low-resolution patch of the upsampled operand
+    static constexpr int GF = PWS / 4, GL = PWL / 4;       // 16-byte groups per patch row (X4OK)
     static constexpr int NPOSF = (PSF + NT - 1) / NT, NPOSL = (PSL + NT - 1) / NT;
     static constexpr int RUN = CK * 256;       // one 16-out-channel run of a chunk: (CK/4) K-steps x 16 positions x 64 floats
     static constexpr int RUN_LDS = RUN + 16;   // the two runs a 32-lane read group touches fall on disjoint bank halves
     static constexpr int A_FLOATS = 2 * RUN_LDS;
-    static constexpr int B_FLOATS = ((CK * PSF + 63) / 64) * 64;   // whole 64-dword LDS-DMA runs (tail = padding)
+    static constexpr int B_FLOATS = X4OK ? ((CK * PSF + 255) / 256) * 256 : ((CK * PSF + 63) / 64) * 64;   // whole LDS-DMA runs (256 dwords of 16-byte pieces / 64 dwords; tail = padding)
     static constexpr int NAV = (2 * CK * 64 + NT - 1) / NT;   // 16-byte weight pieces per thread and chunk
     static constexpr int BUF_FLOATS = B_FLOATS + A_FLOATS;
     static constexpr int KW = CK / 2;          // 2-channel K-steps per chunk

@@ -1418,6 +1418,8 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.ksplit = plan.ksplit;
     a.chunks_per_split = plan.chunks_per_split;
     a.y = plan.ksplit > 1 ? g->workspace : g->y;
+    static const int no_x4 = env_int("WMD_X4", 1) == 0;
+    a.no_x4 = no_x4;
     const bool list = g->out_tiles != nullptr;
     if (list) {
         a.tile_list = g->out_tiles;

@@ -191,6 +191,10 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     };
     // pure layers: flattened [channel][position] runs of a chunk, element tid + i * NT
     constexpr int NPF = GENERIC ? 1 : (CK * PSF + NT - 1) / NT, NPL = GENERIC ? 1 : (CK * PSL + NT - 1) / NT;
+    // 16-byte pieces (dense flattened staging, tiles whose patch columns all lie inside the source rows): groups per thread
+    constexpr bool X4 = !GENERIC && !MASKED && T::X4OK;
+    constexpr int NPF4 = (CK * PSF / 4 + NT - 1) / NT, NPL4 = (CK * PSL / 4 + NT - 1) / NT;
+    bool x4 = false;
     // generic layers: positions tid + i * NT of one channel
     constexpr int NPOSF = GENERIC ? T::NPOSF : 1;
     unsigned obF[NPF], obL[NPL], ob1[NPOSF], ob2[NPOSF];
@@ -227,6 +231,35 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         }
         __syncthreads();
         const unsigned pbs = a.up1 == 2 ? pb2 : pb1;
+        if constexpr (X4) {
+            // every used patch column x0 - 1 .. x0 + TW (minus the shift of a data-gradient launch) inside the source row: no
+            // column is folded, a row of the patch is one contiguous run of the source row (the upsampled operand's low-resolution
+            // patch likewise: (x0 >> 1) - 1 .. (x0 + TW) >> 1).  Border tiles keep the dword pieces with their per-column folds.
+            const bool up = a.up1 == 2;
+            const int Ws = up ? W : a.W1, sh = up ? 0 : a.shift1;
+            x4 = x0 - 1 - sh >= 0 && x0 + TW - sh < Ws && !a.no_x4;
+        }
+        if (X4 && x4) {
+            const bool up = a.up1 == 2;
+            const int sh = up ? 0 : a.shift1;
+            constexpr int PH_ = T::PH, GF = T::GF, GL = T::GL, PHL_ = T::PHL;
+#pragma unroll
+            for (int i = 0; i < NPF4; ++i) {
+                const unsigned e = tid + i * NT, ch = e / (PH_ * GF), rem = e - __umul24(ch, PH_ * GF);
+                const unsigned py = rem / GF, j = rem - __umul24(py, GF);
+                const int r = tab[min(py, (unsigned)PH_ - 1)];
+                const bool ok = ch < CK && r >= 0;
+                obF[i] = ok ? ch * pbs + (unsigned)r + (unsigned)(x0 - 1 - sh + 4 * (int)j) * 4u : kOOB;
+            }
+#pragma unroll
+            for (int i = 0; i < NPL4; ++i) {
+                const unsigned e = tid + i * NT, ch = e / (PHL_ * GL), rem = e - __umul24(ch, PHL_ * GL);
+                const unsigned py = rem / GL, j = rem - __umul24(py, GL);
+                const int r = tab[PH + PWS + min(py, (unsigned)PHL_ - 1)];
+                const bool ok = ch < CK && r >= 0;
+                obL[i] = ok ? ch * pb1 + (unsigned)r + (unsigned)((x0 >> 1) - 1 + 4 * (int)j) * 4u : kOOB;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const unsigned e = tid + i * NT, ch = e / PSF, pos = e - __umul24(ch, PSF);
@@ -250,6 +283,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             }
             obL[i] = ok ? ch * pb1 + (unsigned)(r + c) : kOOB;
         }
+        }   // dword pieces
     } else {
 #pragma unroll
         for (int i = 0; i < NPOSF; ++i) full_pos(tid + i * NT, ob1[i], ob2[i]);
@@ -296,7 +330,10 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     auto stage_full_piece = [&](int chunk, float* bufp, int q, const ChunkSrc& cs) {
         if (q < NPB_F) {
             if constexpr (!GENERIC) {
-                if ((q + 1) * NT <= CK * PSF || wave * 64 + q * NT < CK * PSF)   // wave-uniform: skip wholly empty runs
+                if (X4 && x4) {      // block-uniform: 64 lanes x 16 bytes = 256 consecutive dwords of the chunk's run per instruction
+                    if (q < NPF4 && ((q + 1) * NT * 4 <= CK * PSF || (wave * 64 + q * NT) * 4 < CK * PSF))
+                        lds_dma16(cs.r, (lds_ptr_t)(bufp + (wave * 64 + q * NT) * 4), obF[q], cs.base);
+                } else if ((q + 1) * NT <= CK * PSF || wave * 64 + q * NT < CK * PSF)   // wave-uniform: skip wholly empty runs
                     lds_dma4(cs.r, (lds_ptr_t)(bufp + wave * 64 + q * NT), obF[q], cs.base);
             } else {
                 const int j = q / NPOSF, i = q % NPOSF;
@@ -317,7 +354,10 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     };
     auto stage_up_piece = [&](int chunk, float* bufp, int q) {
         if (q < NPB_L) {
-            if ((q + 1) * NT <= CK * PSL || wave * 64 + q * NT < CK * PSL)
+            if (X4 && x4) {
+                if (q < NPL4 && ((q + 1) * NT * 4 <= CK * PSL || (wave * 64 + q * NT) * 4 < CK * PSL))
+                    lds_dma16(r1, (lds_ptr_t)(bufp + (wave * 64 + q * NT) * 4), obL[q], (unsigned)(chunk * CK) * pb1);
+            } else if ((q + 1) * NT <= CK * PSL || wave * 64 + q * NT < CK * PSL)
                 lds_dma4(r1, (lds_ptr_t)(bufp + wave * 64 + q * NT), obL[q], (unsigned)(chunk * CK) * pb1);
         } else {
             stage_weight_piece(chunk, bufp, q - NPB_L);
