@@ -238,9 +238,15 @@ __global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a)
         int32_t* fs = a.scratch + kMlFrame0 + (size_t)f * kMlFrameInts;    // this frame's accumulators
         const int up_ = sp.up;
         const int tiles_xg = ls.tile_w ? (w * up_ + ls.tile_w - 1) / ls.tile_w : 0, tiles_yg = ls.tile_h ? (h * up_ + ls.tile_h - 1) / ls.tile_h : 0;
-        if (ls.tile_list && bits) {   // reserve a run of the frame's list with one atomic; bit k's entry sits at popcount(bits below k)
-            __shared__ int s_base;
-            if (threadIdx.x == 0) s_base = atomicAdd(&fs[kMlFTile0 + blockIdx.z], __popc(bits));
+        // thread 0's two accumulator updates travel together (one round trip instead of two): the pixel count and the reservation
+        // of a run of the frame's list; both returned values are awaited before the ticket is drawn (below)
+        int old = 0;
+        __shared__ int s_base;
+        if (threadIdx.x == 0) {
+            if (ls.count && s_cnt) old = atomicAdd(&fs[kMlFCnt0 + ls.count - 1], s_cnt);
+            if (ls.tile_list && bits) s_base = atomicAdd(&fs[kMlFTile0 + blockIdx.z], __popc(bits));
+        }
+        if (ls.tile_list && bits) {   // bit k's entry sits at popcount(bits below k) of the reserved run
             __syncthreads();
             const int k = threadIdx.x;
             if (k < 32 && ((bits >> k) & 1u)) {
@@ -255,8 +261,6 @@ __global__ __launch_bounds__(256) void mask_level_kernel(const MaskLevelKArgs a)
             // performed before it draws -- their returned values are awaited (the empty asm consumes them).  A __threadfence()
             // here is a release at agent scope = a write-back of this XCD's L2, dirty with the masks just written.  The list
             // entries and masks are plain stores for LATER launches and need no ordering inside this one.
-            int old = 0;
-            if (ls.count && s_cnt) old = atomicAdd(&fs[kMlFCnt0 + ls.count - 1], s_cnt);
             asm volatile("" ::"v"(old) : "memory");
             s_last = atomicAdd(&fs[kMlFTicket], 1) == (int)(gridDim.x * gridDim.z) - 1;
         }
