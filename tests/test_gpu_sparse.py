@@ -335,6 +335,22 @@ def test_sparse_decoder_graph_replay_with_injected_masks(dev):
         assert_close(out2[("disp", s_)], ref2[("disp", s_)], 2e-6, "disp%d after in-place mask update" % s_)
 
 
+def test_total_ops_of_an_old_forward_survives_the_count_ring(dev):
+    """The work-list form publishes a forward's pixel counts into slot k % 64 of a device-side ring and reads them only when
+    `total_ops` is asked for.  An output dictionary that is still unresolved when its slot comes round again is resolved by the
+    forward that is about to reuse the slot: 70 forwards with alternating thresholds, the first two outputs read last."""
+    sp = _decoder(dev, seed=3)
+    feats = [f.to(dev) for f in kitti_feats(1, 96, 160, seed=2)]
+    want = {thr: sp(feats, thr)["total_ops"] for thr in (0.15, 0.3)}
+    assert want[0.15] != want[0.3]
+    for graph in (False, True):
+        sp.enable_graph(graph)
+        outs = [sp(feats, (0.15, 0.3)[k & 1]) for k in range(70)]
+        assert outs[0]["total_ops"] == want[0.15] and outs[1]["total_ops"] == want[0.3]
+        assert outs[69]["total_ops"] == want[0.3] and outs[64]["total_ops"] == want[0.15]
+    sp.enable_graph(False)
+
+
 def test_sparse_equals_dense_at_negative_threshold(dev):
     """Reference invariant: thresh_ratio <= 0 reproduces the dense decoder with the same weights."""
     from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
