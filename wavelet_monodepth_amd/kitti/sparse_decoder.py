@@ -442,11 +442,14 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         forced_tile = os.environ.get("WMD_SPARSE_TILE")
         big_from = int(os.environ.get("WMD_SPARSE_BIG_FROM", "700"))
 
-        # ... and no list at all below WMD_SPARSE_LIST_FROM items (one frame): the launch then runs the masked kernel the autotuner
+        # ... and no list at all below WMD_SPARSE_LIST_FROM items (one frame; the coarse launches of a batch): the launch then runs the masked kernel the autotuner
         # picked for the shape (a block per tile tests its own mask bytes; host-chosen split-K) -- with a few dozen tiles on 256 CUs
         # nothing is gained by compacting them, and the tuned 16x16x4 / 32x32x2 kernels of round 3 are 10-20 % faster per launch
         # than the list kernel's one tile shape (r04_sparse_timelines.txt: 99 + 25 us of convolutions + reduces against 107 + 37)
-        list_from = int(os.environ.get("WMD_SPARSE_LIST_FROM", "256"))
+        # (threshold swept at 12 frames, contour masks 0.10 / 0.03 / 0.01: 256 -> 0.633 ms, 500 -> 0.605, 800 -> 0.585, 1500 -> 0.630,
+        #  no lists -> 0.689; dense 0.644-0.666: the lists pay on the two large launches of a batch -- upconv(2,1), upconv(1,1) --
+        #  where tail rounds of whole tiles are what skipping loses, and cost on the small ones)
+        list_from = int(os.environ.get("WMD_SPARSE_LIST_FROM", "800"))
 
         def tile_for(hh, ww, cout):
             if forced_tile:

@@ -237,11 +237,26 @@ def _conv_fwd_raw(x1, x2, wp, bias, cout, ksize, pad, act, slope, up1, wp_wino=N
         if wp_wino is None and ksize == 3:
             key += "|direct"   # a choice made with the Winograd configurations on offer must not be reused without them
         if out_mask is not None:
-            key += "|tiles"    # block-sparse: small tiles skip more (timed on the masks of the first call)
+            key += "|tiles"    # block-sparse execution: its own (masked) instantiations, timed at full density (below)
         choice = tuner.lookup(key)
         if choice is None:
             if torch.cuda.is_current_stream_capturing():
                 choice = (0, 0)  # cannot time inside a capture: the library's cost model decides
+            elif out_mask is not None or in_mask is not None:
+                # The candidates are timed on ALL-ONES masks into a scratch output, not on the caller's masks: a first call with
+                # empty masks (every block returns at once, every configuration "takes" the same few microseconds) used to
+                # fix an arbitrary choice for the life of the process -- seen as 41 + 62 us unsplit level-2 launches after a
+                # test had tuned the same shape on an empty mask.  Full density is the reproducible worst case.
+                saved = (a.in_mask, a.out_mask, a.y)
+                ones = torch.ones((B, H, W), device=x1.device, dtype=torch.uint8)
+                scratch = torch.empty_like(y)
+                a.in_mask = ptr(ones) if in_mask is not None else None
+                a.out_mask = ptr(ones) if out_mask is not None else None
+                a.y = ptr(scratch)
+                try:
+                    choice = tuner.tune(key, 9 if ksize == 3 else 1, launch)
+                finally:
+                    a.in_mask, a.out_mask, a.y = saved
             else:
                 choice = tuner.tune(key, 9 if ksize == 3 else 1, launch)
     check(launch(*choice), "wmd_conv_fwd")
