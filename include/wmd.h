@@ -325,6 +325,13 @@ typedef struct {
     const float* ll_wp1;
     const float* ll_bias1;
     const float* ll_wp2;
+    /* optional (round 5, training forward on the fused kernels: trainer.py:208-212 needs what autograd would have kept): the
+     * LeakyReLU outputs of the 1x1 stage are ALSO written to mid_out [B, mid_ct, H, W], channels mid_off_p.. (+ side),
+     * mid_off_n.. (- side) and, with the low-pass chain riding along, mid_off_ll.. (C/4 channels) -- the layout the heads'
+     * backward operators (wmd_head3x3_bwd / wmd_head1x1_bwd) read.  Chained kernel only (C = 64, 128, 256, chain = 0):
+     * WMD_ERR_UNSUPPORTED otherwise.                                                                                      */
+    float* mid_out;
+    int mid_ct, mid_off_p, mid_off_n, mid_off_ll;
 } wmd_head_fused_args;
 int wmd_head_fused_fwd(const wmd_head_fused_args* args, void* stream);
 
@@ -356,6 +363,11 @@ typedef struct {
      * (depth_decoder.py:308: yl.max() - yl.min()) without a reduction pass of its own.  key(f) = bits(f) ^ (f < 0 ?
      * 0xFFFFFFFF : 0x80000000); armed state (0xFFFFFFFF, 0); consumed by wmd_mask_level_lists.                             */
     uint32_t* range_keys;
+    /* optional (round 5, training forward): the sigmoid outputs themselves -- sig_p, sig_n [B,3,H,W], sig_ll [B,1,H,W] (with
+     * yl_out) -- whose s (1 - s) the backward of the heads multiplies by (what wmd_head3x3_fwd returns as sig_p / sig_n)      */
+    float* sig_p;
+    float* sig_n;
+    float* sig_ll;
 } wmd_head_shiftsum_args;
 int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* args, void* stream);
 
@@ -382,6 +394,12 @@ typedef struct {
     float disp_scale;
     int clamp01;
     const uint8_t* yh_mask; /* optional [B,H,W] bytes, see wmd_head_shiftsum_args.yh_mask                    */
+    /* optional (round 5, training forward): the LeakyReLU outputs of the 1x1 stage -> mid_out [B, mid_ct, H, W] at channels
+     * mid_off_p.. / mid_off_n.. (see wmd_head_fused_args.mid_out) and the sigmoid outputs sig_p, sig_n [B,3,H,W]             */
+    float* mid_out;
+    int mid_ct, mid_off_p, mid_off_n;
+    float* sig_p;
+    float* sig_n;
 } wmd_head_level_args;
 int wmd_head_level_supported(int C);
 int wmd_head_level_fwd(const wmd_head_level_args* args, void* stream);

@@ -373,6 +373,72 @@ def test_stacked_heads_equal_per_head_operators_and_the_oracle(dev):
     assert none is None and float((yh2 - yh).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("C,H,W,B,with_ll", [(32, 12, 40, 2, False), (32, 7, 9, 1, False), (64, 6, 10, 2, False), (128, 4, 6, 2, False),
+                                             (256, 6, 20, 2, True), (256, 2, 2, 1, True)])
+def test_fused_training_level_vs_oracle_and_stacked_path(dev, C, H, W, B, with_ll):
+    """ops.fused_level_train (round 5: a level's heads + Haar synthesis in training mode on the inference kernels, with the
+    1x1 outputs and the sigmoid outputs written for the hand-written backward) against autograd through the oracle -- values,
+    the `mid` tensor, and the gradient of every input and parameter under a loss that reaches all four outputs (yh, the
+    low-pass head's own output, the synthesis and the clamped disparity) -- and against the stacked-operator path it replaces."""
+    from wavelet_monodepth_amd import ops
+    assert ops.fused_train_supported(C, H, W, with_ll)
+    x = t(synth.normal((B, C, H, W), "ftx", 5))
+    mk = lambda tag, mid, out: [t(a) for a in synth.conv_params(tag + "1", mid, C, 1, 5)] + [t(a) for a in synth.conv_params(tag + "3", out, mid, 3, 5)]
+    hp, hn = mk("ftp", C, 3), mk("ftn", C, 3)
+    hl = mk("ftl", C // 4, 1) if with_ll else []
+    yl0 = t(synth.uniform((B, 1, H, W), "ftyl", 5, 2.0, 9.0))
+    s_hf, s_ll, dsc = 4.0, 16.0, 0.3
+    g = {k: t(synth.normal(shape, "ftg" + k, 5)) for k, shape in (("yh", (B, 3, H, W)), ("ll", (B, 1, H, W)), ("out", (B, 1, 2 * H, 2 * W)),
+                                                                   ("disp", (B, 1, 2 * H, 2 * W)))}
+    lk = lambda v: torch.nn.functional.leaky_relu(v, 0.1)
+
+    def oracle(xx, p, n, ll, yl):
+        sig = lambda h: torch.sigmoid(R.conv3x3(lk(R.conv1x1(xx, h[0], h[1])), h[2], h[3], "reflect"))
+        yh = s_hf * (sig(p) - sig(n))
+        lo = s_ll * sig(ll) if ll else yl
+        out = R.haar_idwt(lo, yh.unsqueeze(1))
+        return yh, lo, out, torch.clamp(out * dsc, 0, 1)
+
+    leaves = [x] + hp + hn + hl + ([] if with_ll else [yl0])
+    ref = [v.clone().requires_grad_(True) for v in leaves]
+    r_yh, r_lo, r_out, r_disp = oracle(ref[0], ref[1:5], ref[5:9], ref[9:13] if with_ll else None, None if with_ll else ref[9])
+    loss_r = (r_yh * g["yh"]).sum() + (r_out * g["out"]).sum() + (r_disp * g["disp"]).sum() + ((r_lo * g["ll"]).sum() if with_ll else 0.0)
+    loss_r.backward()
+    assert float(((r_out * dsc <= 0) | (r_out * dsc >= 1)).float().mean()) > 0.01, "the clamp must be active somewhere"
+
+    def run(fn):
+        d = [v.to(dev).requires_grad_(True) for v in leaves]
+        yh, lo, out, disp = fn(d)
+        loss = (yh * g["yh"].to(dev)).sum() + (out * g["out"].to(dev)).sum() + (disp * g["disp"].to(dev)).sum()
+        if with_ll:
+            loss = loss + (lo * g["ll"].to(dev)).sum()
+        loss.backward()
+        return d, (yh, lo, out, disp)
+
+    def fused(d):
+        yh, lo, out, disp, mid = ops.fused_level_train(d[0], d[1:5], d[5:9], s_hf, yl=None if with_ll else d[9], disp_scale=dsc, clamp01=True,
+                                                       head_ll=d[9:13] if with_ll else None, scale_ll=s_ll)
+        heads = ([ref[9:13]] if with_ll else []) + [ref[1:5], ref[5:9]]
+        want = torch.cat([lk(R.conv1x1(ref[0], h[0], h[1])) for h in heads], 1).detach()
+        assert_close(mid, want, 2e-5, "mid (LeakyReLU outputs, order [LL, +, -])")
+        return yh, lo, out, disp
+
+    def stacked(d):
+        yh, lo = ops.stacked_heads(d[0], d[1:5], d[5:9], s_hf, head_ll=d[9:13] if with_ll else None, scale_ll=s_ll)
+        out, disp = ops.idwt_haar(lo if with_ll else d[9], yh.unsqueeze(1), disp_scale=dsc, clamp01=True)
+        return yh, lo, out, disp
+
+    d_f, o_f = run(fused)
+    for got, want, name in zip(o_f, (r_yh, r_lo, r_out, r_disp), ("yh", "yl", "out", "disp")):
+        if got is not None:
+            assert_close(got, want.detach(), 2e-5, "fused level: " + name)
+    for k, (a_, b_) in enumerate(zip(d_f, ref)):
+        assert_close(a_.grad, b_.grad, GRAD_TOL, "fused level: gradient of leaf %d" % k)
+    d_s, o_s = run(stacked)
+    for k, (a_, b_) in enumerate(zip(d_f, d_s)):
+        assert_close(a_.grad, b_.grad, GRAD_TOL, "fused vs stacked path: gradient of leaf %d" % k)
+
+
 @pytest.mark.parametrize("C,H,W,B,with_ll", [(32, 9, 21, 2, False), (64, 2, 5, 1, True), (16, 3, 2, 3, False), (80, 7, 66, 1, False), (128, 5, 9, 1, True),
                                              (256, 6, 20, 2, True)])
 def test_head3x3_backward_kernels_vs_oracle_and_generic_path(dev, C, H, W, B, with_ll, monkeypatch):

@@ -287,6 +287,60 @@ def test_config4_operating_point_vs_oracle(dev, kind, B, tiles, monkeypatch):
     sp.enable_graph(False)
 
 
+@pytest.mark.parametrize("B", [1, 12])
+@pytest.mark.parametrize("poison", [float("nan"), float("inf")], ids=["nan", "inf"])
+def test_config4_worklist_form_survives_a_poisoned_pool(dev, B, poison):
+    """The work-list form never refills its activation pool: a tile the block-sparse kernels skip keeps whatever an earlier
+    forward left there, and exactness rests on every consumer SELECTING on its mask instead of multiplying by it (one 0 * Inf and
+    a skipped region leaks NaN).  So: run the operating point once (this creates the decoder's LevelState), overwrite the whole
+    pool with NaN / Inf -- the worst an earlier forward could have left in a region that is skipped now --, run again, eager and
+    replayed, one frame (masked kernels, no lists) and a batch (LIST kernels): every output must be finite, bit-identical to the
+    forward on the clean pool and equal to the oracle.  Also with a first forward whose FEATURES carry the poison in a region the
+    second forward's masks skip (the way a real caller would produce stale non-finite values)."""
+    masks = _operating_point_masks("contour", B)
+    sd = R.make_state_dict(R.kitti_wave_param_shapes(R18), seed=1)
+    feats = kitti_feats(B, 192, 640, seed=4)
+    sp = _sparse(dev)
+    gfeats = [f.to(dev) for f in feats]
+    force = {i: t(m).to(dev) for i, m in masks.items()}
+    with torch.no_grad():
+        ref = R.kitti_sparse_decoder([x[0:1] for x in feats], sd, 0.05, force_masks={i: m[0] for i, m in masks.items()})
+    for graph in (False, True):
+        sp.enable_graph(graph)
+        for _ in range(2 if graph else 1):
+            clean = sp(gfeats, 0.05, _force_masks=force)
+        clean = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in clean.items()}
+        assert sp._states, "the work-list form keeps a LevelState per input signature"
+        # (a) the pool itself
+        for st in sp._states.values():
+            st.pool.fill_(poison)
+        again = sp(gfeats, 0.05, _force_masks=force)
+        for k, v in clean.items():
+            if torch.is_tensor(v):
+                assert torch.isfinite(again[k].float()).all(), "%s not finite after a poisoned pool (graph=%s)" % (key_str(k), graph)
+                assert torch.equal(again[k], v), "%s differs after a poisoned pool (graph=%s)" % (key_str(k), graph)
+        # (b) a forward that computes non-finite activations everywhere (all-ones masks, poisoned skip features), then the clean
+        # one.  In place: the same tensors = the same LevelState / capture, so the stale values land in THIS pool.
+        keep_f, keep_m = [f.clone() for f in gfeats], {i: m.clone() for i, m in force.items()}
+        for f in gfeats[:3]:
+            f.fill_(poison)
+        for m in force.values():
+            m.fill_(1)
+        sp(gfeats, 0.05, _force_masks=force)
+        for f, k in zip(gfeats, keep_f):
+            f.copy_(k)
+        for i, m in force.items():
+            m.copy_(keep_m[i])
+        again = sp(gfeats, 0.05, _force_masks=force)
+        for k, v in clean.items():
+            if torch.is_tensor(v):
+                assert torch.equal(again[k], v), "%s differs after a non-finite forward (graph=%s)" % (key_str(k), graph)
+        for k, v in ref.items():
+            if torch.is_tensor(v) and v.dtype != torch.bool:
+                assert_close(again[k][0:1], v, NET_TOL, "frame 0 %s vs oracle after poisoning" % key_str(k))
+    sp.enable_graph(False)
+
+
 @pytest.mark.parametrize("thr", [0.01, 0.05, 0.1])
 def test_config4_sparse_640x192_free_running_vs_oracle(dev, thr):
     """No injected masks: the GPU's own thresholding.  A coefficient within rounding distance of the threshold may flip, so

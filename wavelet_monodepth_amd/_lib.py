@@ -56,7 +56,8 @@ class HeadFusedArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("slope", C.c_float),
                 ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p), ("t", C.c_void_p),
                 ("chain", C.c_int), ("t_planes", C.c_int), ("run_mask", C.c_void_p), ("ll_wp1", C.c_void_p),
-                ("ll_bias1", C.c_void_p), ("ll_wp2", C.c_void_p)]
+                ("ll_bias1", C.c_void_p), ("ll_wp2", C.c_void_p), ("mid_out", C.c_void_p), ("mid_ct", C.c_int),
+                ("mid_off_p", C.c_int), ("mid_off_n", C.c_int), ("mid_off_ll", C.c_int)]
 
 
 class HeadLevelArgs(C.Structure):
@@ -65,7 +66,8 @@ class HeadLevelArgs(C.Structure):
                 ("x", C.c_void_p), ("wp1", C.c_void_p), ("bias1", C.c_void_p), ("wp2", C.c_void_p),
                 ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
                 ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
-                ("clamp01", C.c_int), ("yh_mask", C.c_void_p)]
+                ("clamp01", C.c_int), ("yh_mask", C.c_void_p), ("mid_out", C.c_void_p), ("mid_ct", C.c_int),
+                ("mid_off_p", C.c_int), ("mid_off_n", C.c_int), ("sig_p", C.c_void_p), ("sig_n", C.c_void_p)]
 
 
 class HeadBwdHead(C.Structure):
@@ -108,7 +110,8 @@ class HeadShiftsumArgs(C.Structure):
                 ("t", C.c_void_p), ("bias_p", C.c_void_p), ("bias_n", C.c_void_p), ("yh", C.c_void_p),
                 ("yl", C.c_void_p), ("out", C.c_void_p), ("disp", C.c_void_p), ("disp_scale", C.c_float),
                 ("clamp01", C.c_int), ("bias_ll", C.c_void_p), ("scale_ll", C.c_float), ("yl_out", C.c_void_p),
-                ("yh_mask", C.c_void_p), ("range_keys", C.c_void_p)]
+                ("yh_mask", C.c_void_p), ("range_keys", C.c_void_p), ("sig_p", C.c_void_p), ("sig_n", C.c_void_p),
+                ("sig_ll", C.c_void_p)]
 
 
 class LevelSpec(C.Structure):

@@ -52,7 +52,23 @@ struct ConvKArgs {
     int ksmax;
     int list_slots;          // workgroup slots of the machine for this kernel (blocks per CU x CUs): the device's K-split target
     float* y_final;
+    // conv_wino32_kernel (round 5): output rows transposed through LDS into whole 128-byte lines (WMD_W32_COALESCE=0: 16-byte
+    // pieces of 64 different lines per store instruction)
+    int st_coalesce;
+    // development builds only (-DWMD_STAMPS, tools/probes/stamps_probe.py): per-block cycle stamps [blocks][12]; dbg_mode bit 0:
+    // no output stores, bit 1: no activation
+    unsigned long long* dbg;
+    int dbg_mode;
 };
+
+#ifdef WMD_STAMPS
+#define WMD_STAMP(k) do { asm volatile("" ::: "memory"); stamp_[k] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+// ... after the scalar loads / LDS traffic issued so far have returned and the scalar `dep` has been computed
+#define WMD_STAMP_AFTER(k, dep) do { asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(dep) : "memory"); stamp_[k] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define WMD_STAMP(k) do { } while (0)
+#define WMD_STAMP_AFTER(k, dep) do { } while (0)
+#endif
 
 // Device-chosen split of the input-channel reduction of a work-list launch: the same function in the convolution and in its
 // second pass.  Fills the machine (`slots` workgroup slots) when few tiles are active, at least two chunks per slice.

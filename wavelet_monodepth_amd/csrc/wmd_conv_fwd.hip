@@ -1094,10 +1094,15 @@ extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     const bool want_ll = g->chain == 0 && g->ll_wp1 && g->ll_wp2;
     if (want_ll && (g->C != 256 || t_planes != 81))
         return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: the low-pass chain needs C = 256 and an 81-plane t (C=%d, t_planes=%d)", g->C, t_planes);
+    if (g->mid_out && (g->chain != 0 || g->mid_ct <= 0 || g->mid_off_p < 0 || g->mid_off_n < 0 || g->mid_off_p + g->C > g->mid_ct ||
+                       g->mid_off_n + g->C > g->mid_ct || (want_ll && (g->mid_off_ll < 0 || g->mid_off_ll + g->C / 4 > g->mid_ct))))
+        return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: mid_out needs chain = 0 and channel offsets inside mid_ct = %d", g->mid_ct);
     if (g->chain == 0) {
         const int took = head_chain_launch(g, t_planes, (hipStream_t)stream);
         int st = took ? check_launch("head_chain_kernel") : WMD_OK;
         if (st) return st;
+        if (g->mid_out && (!took || (want_ll && took != 2)))
+            return fail(WMD_ERR_UNSUPPORTED, "wmd_head_fused_fwd: mid_out is written by the chained kernel only (C = 64, 128, 256, H*W %% 4 == 0)");
         if (want_ll && took != 2) {   // the chained kernel did not take the low-pass chain along: a launch of its own
             wmd_head_fused_args l = *g;
             l.wp1 = g->ll_wp1;
@@ -1420,6 +1425,12 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.y = plan.ksplit > 1 ? g->workspace : g->y;
     static const int no_x4 = env_int("WMD_X4", 1) == 0;
     a.no_x4 = no_x4;
+    static const int st_coalesce = env_int("WMD_W32_COALESCE", 1);
+    a.st_coalesce = st_coalesce;
+#ifdef WMD_STAMPS
+    if (const char* e = getenv("WMD_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
+    a.dbg_mode = env_int("WMD_DBG_MODE", 0);
+#endif
     const bool list = g->out_tiles != nullptr;
     if (list) {
         a.tile_list = g->out_tiles;

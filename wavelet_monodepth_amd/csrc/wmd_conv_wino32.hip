@@ -109,6 +109,10 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WMD_STAMPS
+    unsigned long long stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    WMD_STAMP(0);
     // waves w and w + WN are the two halves of tile group w % WN; a workgroup's waves are dealt to the four SIMDs cyclically,
     // so for WN = 4 the halves of a group share a SIMD (their MFMA counts on an upsampled chunk, 5 + 4, add up evenly)
     const int wn = wave % WN;
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     const int y0 = ty * TH, x0 = tx * TW;
     const int ks = blockIdx.z;
     const int H = a.H, W = a.W;
+    WMD_STAMP_AFTER(1, y0 + x0 + H);   // kernel arguments have arrived, the item is decoded
     // Block-sparse: a tile without active output pixels keeps its zeros.  It does not `return` here: an early exit ahead of
     // the pipelined body costs the DENSE launches of this same instantiation 45 % (L14: 110 -> 160 us, A/B builds on one box;
     // the epilogue's mask code costs nothing) -- the skipped block walks an empty chunk range and stores nothing instead
@@ -209,27 +214,37 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         // the border source pixel, zero padding stays zero; rows beyond the ring (tile overhang) are never used by a stored output.
         int* tab = reinterpret_cast<int*>(lds + T::LDS_FLOATS);
         constexpr int PH = T::PH, PHL = T::PHL;
+        const bool up_g = a.up1 == 2;
+        const int Hs_g = up_g ? H : a.H1, Ws_g = up_g ? W : a.W1, sh_g = up_g ? 0 : a.shift1;
+        // folded byte offset of full-resolution patch row / column t (-1: reads zero), and of the low-resolution patch's
+        auto full_rc = [&](bool row, int t) {
+            const int g0 = row ? y0 + t - 1 : x0 + t - 1, n = row ? H : W, ns = row ? Hs_g : Ws_g;
+            int ok = (int)(g0 <= n);
+            const int g = fold(g0, n, ok) - sh_g;
+            ok &= (int)(g >= 0) & (int)(g < ns);
+            return ok ? (row ? g * Ws_g * 4 : g * 4) : -1;
+        };
+        auto low_rc = [&](bool row, int t) {
+            const int s0 = row ? (y0 >> 1) - 1 + t : (x0 >> 1) - 1 + t, n = row ? a.H1 : a.W1;
+            const int sc = min(max(s0, 0), n - 1);
+            const int ok = (int)(s0 <= n) & ((int)(a.pad_mode != WMD_PAD_ZERO) | (int)(sc == s0));
+            return ok ? (row ? sc * a.W1 * 4 : sc * 4) : -1;
+        };
+        // (Round 5 measured the alternative -- every element folding its own row and column, no LDS table, no barrier: 40 VALU
+        //  instructions per element instead of two table reads.  Slower: offsets phase 3.4 k -> 4.4 k cycles on L14, 2.8 k -> 6.5 k on
+        //  the 40-wide tiles; a young wave's VALU instructions get the issue slots its SIMD partner's main loop leaves over, so the
+        //  prologue's price is its VALU count.  s_setprio 1 through the prologue and / or the epilogue: no change either.
+        //  profiles/r05_stamps.txt, profiles/r05_notes.md.)
         {
-            const bool up = a.up1 == 2;
-            const int Hs = up ? H : a.H1, Ws = up ? W : a.W1, sh = up ? 0 : a.shift1;
             int t = tid;
-            if (t < PH + PWS) {
-                const bool row = t < PH;
-                const int g0 = row ? y0 + t - 1 : x0 + (t - PH) - 1, n = row ? H : W, ns = row ? Hs : Ws;
-                int ok = (int)(g0 <= n);
-                const int g = fold(g0, n, ok) - sh;
-                ok &= (int)(g >= 0) & (int)(g < ns);
-                tab[t] = ok ? (row ? g * Ws * 4 : g * 4) : -1;
-            } else if (t < PH + PWS + PHL + PWL) {
+            if (t < PH + PWS) tab[t] = full_rc(t < PH, t < PH ? t : t - PH);
+            else if (t < PH + PWS + PHL + PWL) {
                 t -= PH + PWS;
-                const bool row = t < PHL;
-                const int s0 = row ? (y0 >> 1) - 1 + t : (x0 >> 1) - 1 + (t - PHL), n = row ? a.H1 : a.W1;
-                const int sc = min(max(s0, 0), n - 1);
-                const int ok = (int)(s0 <= n) & ((int)(a.pad_mode != WMD_PAD_ZERO) | (int)(sc == s0));
-                tab[PH + PWS + t] = ok ? (row ? sc * a.W1 * 4 : sc * 4) : -1;
+                tab[PH + PWS + t] = low_rc(t < PHL, t < PHL ? t : t - PHL);
             }
         }
         __syncthreads();
+        WMD_STAMP_AFTER(2, 0);   // row / column tables in LDS
         const unsigned pbs = a.up1 == 2 ? pb2 : pb1;
         if constexpr (X4) {
             // every used patch column x0 - 1 .. x0 + TW (minus the shift of a data-gradient launch) inside the source row: no
@@ -288,6 +303,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 #pragma unroll
         for (int i = 0; i < NPOSF; ++i) full_pos(tid + i * NT, ob1[i], ob2[i]);
     }
+    WMD_STAMP_AFTER(3, 0);   // per-lane gather offsets
     const float* x1b = a.x1 + (size_t)b * a.C1 * plane1;
     const float* x2b = a.x2 ? a.x2 + (size_t)b * a.C2 * plane2 : a.x1;
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x1b), 0, (int)(a.C1 * plane1 * 4), 0x00020000);
@@ -366,6 +382,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 
     const int c_begin = ks * cps;
     const int c_end = skip ? c_begin : min(c_begin + cps, a.nchunks);
+    WMD_STAMP(4);   // descriptors, weight offsets
     if (c_begin < c_end) {
         if (is_up(c_begin)) {
             static_for<NPB_L + T::NAV>([&](auto qc) { stage_up_piece(c_begin, lds, decltype(qc)::value); });
@@ -383,7 +400,9 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     const int pbF = tyy * 2 * PWS + txx * 2 + (lane >> 5) * PSF;
     const int pbL = tyy * PWL + txx + (lane >> 5) * PSL;
     const int wbase = T::B_FLOATS + ((lane & 31) >> 4) * T::RUN_LDS + (lane & 15) + 16 * (lane >> 5);
+    WMD_STAMP(5);   // first chunk issued
     __syncthreads();
+    WMD_STAMP(6);   // first chunk landed
 
     // Everything from here on is compiled once per half (the set of owned positions is a compile-time property).
     auto run = [&](auto hf_tag) {
@@ -405,6 +424,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             constexpr int NEXT = decltype(next_tag)::value;
             constexpr int NP = w32_count(HF, UP);
             constexpr int S = KW * NP, D = 3, RS = D + 1;
+                        // (round 5, A/B builds: dealing the pieces over the first third or half instead moved nothing -- bench 0.601 / 0.601 / 0.599 ms)
             constexpr int SP = (S * 2) / 3 > 0 ? (S * 2) / 3 : 1;
             constexpr int NPIECES = NEXT == 0 ? 0 : (NEXT == 2 ? NPB_L : NPB_F) + T::NAV;
             const int buf = (c - c_begin) & 1;
@@ -518,6 +538,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         for (; c + 1 < c_end; ++c) chunk_body(c, std::false_type{}, I1{});
         if (c < c_end) chunk_body(c, std::false_type{}, I0{});
 
+        WMD_STAMP(7);   // main loop done
         // ---- epilogue -------------------------------------------------------------------------------------------------
         // Accumulator register g = 4q + r of lane l belongs to tile slot wn*32 + 8q + 4(l >> 5) + r and out channel l & 31.
         // Partial outputs of this half: Y[a][b] += A^T[a][r] A^T[b][c] M[r][c] over the owned (r, c).  Half hf keeps output
@@ -544,6 +565,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             give[g][0] = y[1 - HF][0];
             give[g][1] = y[1 - HF][1];
         }
+        WMD_STAMP(8);   // output transform
         float* xch = lds + (size_t)wn * (2 * 32 * 64) + lane;   // [wn][sender half][value][lane]
 #pragma unroll
         for (int e = 0; e < 32; ++e) xch[(HF * 32 + e) * 64] = give[e >> 1][e & 1];
@@ -551,6 +573,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 #pragma unroll
         for (int e = 0; e < 32; ++e) keep[e >> 1][e & 1] += xch[((1 - HF) * 32 + e) * 64];
 
+        WMD_STAMP(9);   // halves exchanged
         const bool final_out = (ks_n == 1);
         float* ybase = (LIST && final_out) ? a.y_final + (size_t)b * a.Cout * plane2 : a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
         const bool vec_ok = (W & 3) == 0;
@@ -576,6 +599,9 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = mv[e] ? o[e] : 0.f;
                 }
+#ifdef WMD_STAMPS
+                if ((a.dbg_mode & 1) && o[0] == o[0]) continue;
+#endif
                 if (vec_ok && ox + 7 < W) {
                     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
@@ -586,11 +612,71 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
                 }
             }
         };
-        if (!final_out) store_rows(std::integral_constant<int, -1>{});
-        else if (a.act == WMD_ACT_ELU) store_rows(std::integral_constant<int, WMD_ACT_ELU>{});
-        else if (a.act == WMD_ACT_LEAKY) store_rows(std::integral_constant<int, WMD_ACT_LEAKY>{});
-        else if (a.act == WMD_ACT_SIGMOID) store_rows(std::integral_constant<int, WMD_ACT_SIGMOID>{});
+        // Round 5: the kept output row leaves through whole 128-byte lines.  A lane holds 8-pixel runs of ONE out channel, so a
+        // store instruction of store_rows touches 64 different lines with 16 bytes each (cycle stamps: 4.2 k cycles from the
+        // exchange to the last store issued).  Here the wave first transposes its 32 channels x 32 tile slots x 2 pixels through the
+        // 8 KB of the exchange area only it has read ([co][16 pieces of two tiles], pieces XOR-swizzled by the channel so that the
+        // 8-lane write groups and the 16-lane read groups each cover distinct banks) and then stores [4 channels][256 bytes] per
+        // instruction.  LDS operations of one wave execute in order: no barrier.
+        auto store_lines = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            float* tb = lds + (size_t)wn * (2 * 32 * 64) + (size_t)(1 - HF) * (32 * 64);
+            const int col = lane & 31, hh = lane >> 5;
+            const int swz_w = ((col & 3) << 2) | ((col >> 2) & 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = keep[4 * q + 2 * pr + (e >> 1)][e & 1];
+                        o[e] = ACT < 0 ? yv : act_const<(ACT < 0 ? 0 : ACT)>(yv + bias_v, a.slope);
+                    }
+                    const int pc = 4 * q + 2 * hh + pr;
+                    *reinterpret_cast<float4*>(tb + col * 64 + ((pc ^ swz_w) * 4)) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 4 * i + (lane >> 4), pc = lane & 15;
+                const int swz_r = ((c & 3) << 2) | ((c >> 2) & 3);
+                const float4 v = *reinterpret_cast<const float4*>(tb + c * 64 + ((pc ^ swz_r) * 4));
+                const int ts = wn * 32 + 2 * pc;
+                const int oy = y0 + (ts / TXB) * 2 + HF, ox = x0 + (ts % TXB) * 2;
+                const int cg = by * 32 + c;
+#ifdef WMD_STAMPS
+                if ((a.dbg_mode & 1) && v.x == v.x) continue;
+#endif
+                if (cg < a.Cout && ts < T::NTILES && oy < H && ox < W)
+                    *reinterpret_cast<float4*>(ybase + (size_t)cg * plane2 + (size_t)oy * W + ox) = v;
+            }
+        };
+        const bool lines = !MASKED && a.st_coalesce != 0 && vec_ok;
+        int act_sel = final_out ? a.act : -1;
+#ifdef WMD_STAMPS
+        if ((a.dbg_mode & 2) && final_out) act_sel = WMD_ACT_NONE;
+#endif
+        if (lines) {
+            if (act_sel < 0) store_lines(std::integral_constant<int, -1>{});
+            else if (act_sel == WMD_ACT_ELU) store_lines(std::integral_constant<int, WMD_ACT_ELU>{});
+            else if (act_sel == WMD_ACT_LEAKY) store_lines(std::integral_constant<int, WMD_ACT_LEAKY>{});
+            else if (act_sel == WMD_ACT_SIGMOID) store_lines(std::integral_constant<int, WMD_ACT_SIGMOID>{});
+            else store_lines(std::integral_constant<int, WMD_ACT_NONE>{});
+        } else if (act_sel < 0) store_rows(std::integral_constant<int, -1>{});
+        else if (act_sel == WMD_ACT_ELU) store_rows(std::integral_constant<int, WMD_ACT_ELU>{});
+        else if (act_sel == WMD_ACT_LEAKY) store_rows(std::integral_constant<int, WMD_ACT_LEAKY>{});
+        else if (act_sel == WMD_ACT_SIGMOID) store_rows(std::integral_constant<int, WMD_ACT_SIGMOID>{});
         else store_rows(std::integral_constant<int, WMD_ACT_NONE>{});
+        WMD_STAMP(10);   // stores issued
+#ifdef WMD_STAMPS
+        if (a.dbg && tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            stamp_[11] = xcc;
+            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            for (int k = 0; k < 12; ++k) a.dbg[blk * 12 + k] = stamp_[k];
+        }
+#endif
     };
     if (hf == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
@@ -612,7 +698,11 @@ void launch_wino32(const ConvKArgs& a, dim3 grid, hipStream_t s) {
 }
 
 #define WMD_W32_INST(TH, TW, WN, CK) template void launch_wino32<TH, TW, WN, CK>(const ConvKArgs&, dim3, hipStream_t);
+#ifdef WMD_W32_DEV_TABLE   // development: compile-check one shape in seconds instead of the table in minutes
+WMD_W32_INST(8, 32, 2, 8)
+#else
 #include "wmd_conv_wino32_table.inc"
+#endif
 #undef WMD_W32_INST
 
 }  // namespace wmd

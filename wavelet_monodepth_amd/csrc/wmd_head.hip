@@ -347,6 +347,10 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
                 }
                 const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
                 yh[co] = in_mask ? a.scale * a1 - a.scale * a2 : 0.f;
+                if (a.sig_p && live) {   // training forward: what the heads' backward multiplies by
+                    a.sig_p[(b * 3 + co) * plane + (size_t)y * W + x] = a1;
+                    a.sig_n[(b * 3 + co) * plane + (size_t)y * W + x] = a2;
+                }
             }
         }
         if (live) {
@@ -360,6 +364,7 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
             for (int t = 0; t < 9; ++t) sl += okf[t] * tb[(size_t)(54 + t) * plane + off[t]];
             l = a.scale_ll / (1.f + expf(-sl));
             if (live) a.yl_out[i] = l;
+            if (live && a.sig_ll) a.sig_ll[i] = 1.f / (1.f + expf(-sl));
         } else if (a.yl) {
             l = a.yl[i];
         }
@@ -481,6 +486,8 @@ extern "C" int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* g, void* stre
     if (g->yl_out && g->yl) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: yl_out (low-pass head completed here) excludes yl");
     if ((g->out != nullptr) != (g->yl != nullptr || g->yl_out != nullptr))
         return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: yl (or yl_out) and out go together");
+    if ((g->sig_p != nullptr) != (g->sig_n != nullptr) || (g->sig_ll && !g->yl_out) || (g->sig_p && g->yh_mask))
+        return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_fwd: sig_p and sig_n go together, sig_ll needs yl_out, neither takes a yh_mask");
     const size_t n = (size_t)g->B * g->H * g->W;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("head_shiftsum_kernel", 60.0 * n, 4.0 * n * ((g->yl_out ? 64 : 54) + 3 + (g->out ? (g->disp ? 9 : 5) : 0)), s);

@@ -45,6 +45,10 @@ struct HeadChainArgs {
     const float* ll_wp1;
     const float* ll_bias1;
     const float* ll_wp2;
+    // training forward (wmd_head_fused_args.mid_out): the LeakyReLU outputs also go to mid_out [B, mid_ct, plane], this side's
+    // channels from mid_off[side] (the low-pass chain's from mid_off[2])
+    float* mid_out;
+    int mid_ct, mid_off[3];
 };
 
 template <int C, int RS, int PG, int NT, int KC>
@@ -205,6 +209,10 @@ __device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* l
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const float mid = act_apply(acc[m][n][i] + bv[i], WMD_ACT_LEAKY, a.slope);
+                if (a.mid_out) {   // lane = (channel 16 mg + 4 g + i, pixel lc of group n): 64-byte runs of four channel rows
+                    const int px = pix0 + (pg * NT + n) * 16 + lc;
+                    if (px < plane) a.mid_out[((size_t)b * a.mid_ct + a.mid_off[side] + mg * 16 + g * 4 + i) * plane + px] = mid;
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc2[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][i], mid, acc2[j][n], 0, 0, 0);
             }
@@ -230,6 +238,10 @@ __device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* l
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const float mid = act_apply(acc[MT][n][i] + bv[i], WMD_ACT_LEAKY, a.slope);
+                if (a.mid_out) {
+                    const int px = pix0 + (pg * NT + n) * 16 + lc;
+                    if (px < plane) a.mid_out[((size_t)b * a.mid_ct + a.mid_off[2] + r * 16 + g * 4 + i) * plane + px] = mid;
+                }
                 acc2l[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2l[i], mid, acc2l[n], 0, 0, 0);
             }
     }
@@ -337,6 +349,11 @@ int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s)
     a.ll_wp1 = with_ll ? g->ll_wp1 : nullptr;
     a.ll_bias1 = with_ll ? g->ll_bias1 : nullptr;
     a.ll_wp2 = with_ll ? g->ll_wp2 : nullptr;
+    a.mid_out = g->mid_out;
+    a.mid_ct = g->mid_ct;
+    a.mid_off[0] = g->mid_off_p;
+    a.mid_off[1] = g->mid_off_n;
+    a.mid_off[2] = g->mid_off_ll;
     const double pix = (double)g->B * plane;
     ProfScope prof("head_chain_kernel", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C), 4.0 * pix * (g->C + 54), s);
     // (pixel-tile / wave-count / chunk variants -- 64 to 256 pixels, 2 to 16 waves, channel split 1 / 2 / 4 / 8 -- all measured

@@ -211,6 +211,29 @@ __global__ __launch_bounds__(NW * 64, 2) void head_level_kernel(const wmd_head_l
         }
     }
     __syncthreads();
+    // training forward (wmd_head_level_args.mid_out): the tile's own pixels of mid, both sides, out of LDS -- consecutive
+    // threads take consecutive pixels of a channel (40-pixel runs); the halo positions belong to the neighbouring tiles
+    if (a.mid_out) {
+        const bool v4 = (W & 3) == 0;      // (x0 and rx are multiples of 4: 16-byte stores wherever the image width allows)
+        for (int idx = tid; idx < 2 * C * HL_TH * (HL_TW / 4); idx += NW * 64) {
+            const int x4 = idx % (HL_TW / 4), r2 = idx / (HL_TW / 4);
+            const int ry = r2 % HL_TH, chs = r2 / HL_TH;
+            const int sd = chs / C, ch = chs - sd * C;
+            const int rx = x4 * 4, q0 = (ry + 1) * PW + rx + 1;
+            const float* pl = (sd == 0 ? ms : xs) + ch * PS;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pl[(q0 + e) ^ hl_swz(ch)];
+            if (y0 + ry >= H || x0 + rx >= W) continue;
+            float* dst = a.mid_out + ((size_t)b * a.mid_ct + (sd == 0 ? a.mid_off_p : a.mid_off_n) + ch) * plane + (size_t)(y0 + ry) * W + x0 + rx;
+            if (v4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x0 + rx + e < W) dst[e] = v[e];
+            }
+        }
+    }
 
     // ---- 3. GEMM 2, both sides: t = W3' mid -----------------------------------------------------------------------
     f32x4 acc2[2][2][NR];
@@ -284,6 +307,10 @@ __global__ __launch_bounds__(NW * 64, 2) void head_level_kernel(const wmd_head_l
     for (int co = 0; co < 3; ++co) {
         const float a1 = 1.f / (1.f + expf(-hs[0][co])), a2 = 1.f / (1.f + expf(-hs[1][co]));
         yh[co] = a.scale * a1 - a.scale * a2;
+        if (a.sig_p) {   // training forward: what the heads' backward multiplies by
+            a.sig_p[((size_t)b * 3 + co) * plane + (size_t)y * W + x] = a1;
+            a.sig_n[((size_t)b * 3 + co) * plane + (size_t)y * W + x] = a2;
+        }
         if (a.yh_mask && a.yh_mask[(size_t)b * plane + (size_t)y * W + x] == 0) yh[co] = 0.f;
         a.yh[((size_t)b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
     }
@@ -329,6 +356,10 @@ extern "C" int wmd_head_level_fwd(const wmd_head_level_args* g, void* stream) {
     if (g->disp && !g->out) return fail(WMD_ERR_BAD_ARG, "wmd_head_level_fwd: disp needs out");
     if ((double)g->C * g->H * g->W * 4 > 2147483647.0)
         return fail(WMD_ERR_UNSUPPORTED, "wmd_head_level_fwd: a per-image tensor slice exceeds 2 GiB");
+    if ((g->sig_p != nullptr) != (g->sig_n != nullptr) || ((g->sig_p || g->mid_out) && g->yh_mask))
+        return fail(WMD_ERR_BAD_ARG, "wmd_head_level_fwd: sig_p and sig_n go together; the training outputs take no yh_mask");
+    if (g->mid_out && (g->mid_ct <= 0 || g->mid_off_p < 0 || g->mid_off_n < 0 || g->mid_off_p + g->C > g->mid_ct || g->mid_off_n + g->C > g->mid_ct))
+        return fail(WMD_ERR_BAD_ARG, "wmd_head_level_fwd: mid_out channel offsets outside mid_ct = %d", g->mid_ct);
     const int tiles_x = (g->W + HL_TW - 1) / HL_TW, tiles_y = (g->H + HL_TH - 1) / HL_TH;
     const double pix = (double)g->B * g->H * g->W;
     hipStream_t s = (hipStream_t)stream;

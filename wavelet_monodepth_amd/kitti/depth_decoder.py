@@ -64,7 +64,9 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self.stack_heads = os.environ.get("WMD_STACKED_HEADS", "1") == "1"   # training: one launch per stage over all heads of a level
         self.branch_trace = None   # set to a dict to record the LeakyReLU pieces of a training-mode forward
         self.fuse_heads = True   # inference: fused 1x1 -> 3x3 -> IDWT head kernels where the width allows (32/64/128)
-        self.overlap_heads = os.environ.get("WMD_OVERLAP_HEADS", "0") == "1"   # opt-in (graph mode): heads on a second stream; measured no gain
+        # opt-in: heads on a second stream -- 1: under graph capture only (a replayed graph serialises the fork: no gain), 2: eager
+        # launches too (side stream of priority WMD_OVERLAP_PRIO; tools/probes/overlap_probe.py)
+        self.overlap_heads = int(os.environ.get("WMD_OVERLAP_HEADS", "0"))
         self._side_stream = None
         # graph mode: one graph (default), or trunk / heads as graph segments on two streams (WMD_TWO_STREAM_GRAPHS=1).  The
         # two-stream replay won 2-3 % while the trunk ran on the 16x16x4 Winograd kernels; beside conv_wino32_kernel (two
@@ -266,10 +268,11 @@ class DepthWaveProgressiveDecoder(nn.Module):
         # (46 - 720 workgroups) and so are the coarse trunk convolutions: side by side they fill each other's idle CUs.
         # (Capture only: there every buffer is static; the eager path stays on one stream.)  Measured on MI355X: 0.748 vs
         # 0.743 ms per step -- the replayed graph gains nothing from the fork, so this stays opt-in (WMD_OVERLAP_HEADS=1).
-        overlap = self.overlap_heads and torch.cuda.is_current_stream_capturing() and not torch.is_grad_enabled()
+        overlap = bool(self.overlap_heads) and not torch.is_grad_enabled() and \
+            (torch.cuda.is_current_stream_capturing() or self.overlap_heads >= 2)
         main = torch.cuda.current_stream() if overlap else None
         if overlap and self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
+            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("WMD_OVERLAP_PRIO", "0")))
         side = self._side_stream if overlap else None
         keep = []   # tensors that cross streams stay referenced until the streams have joined
         # training: every consumer of a trunk activation (the next trunk convolution, the heads' 1x1 convolutions) returns its
@@ -297,6 +300,15 @@ class DepthWaveProgressiveDecoder(nn.Module):
             main.wait_stream(side)
         return self.outputs
 
+    def _fused_train_ok(self, i, x):
+        """Training mode: may level i's heads + synthesis run as ops.fused_level_train?  (Same conditions as the stacked form
+        of get_coefficients -- whole 16-channel tiles, WMD_STACKED_HEADS -- plus what the fused kernels can write.)"""
+        if not torch.is_grad_enabled() or not self.stack_heads or not self.fuse_heads:
+            return False
+        if any(self.convs[("waveconv", i, j)][0].conv.weight.shape[0] % 16 for j in ([0] if i == 4 else []) + [1]):
+            return False
+        return int(self.num_ch_dec[i]) in ops.FUSED_HEAD_WIDTHS and ops.fused_train_supported(int(self.num_ch_dec[i]), x.shape[2], x.shape[3], i == 4)
+
     def _level_heads(self, i, x, yl):
         """Coefficients, IDWT and disparity of level i from the trunk activation x (and the previous low-pass yl)."""
         fused = (not torch.is_grad_enabled()) and int(self.num_ch_dec[i]) in ops.FUSED_HEAD_WIDTHS and self.fuse_heads
@@ -317,6 +329,26 @@ class DepthWaveProgressiveDecoder(nn.Module):
             if head_ll is not None:
                 yl_in = res[3]
             self.outputs[("wavelets", i - 1, "LL")] = yl_in
+        elif self._fused_train_ok(i, x):
+            # training forward on the same fused kernels (round 5, ops._FusedLevelFn): heads + synthesis of the level as ONE
+            # autograd node that keeps the 1x1 outputs and the sigmoid outputs for the hand-written backward
+            gate = ("elu", 0.0) if getattr(self, "_gated", False) else None
+            hd = lambda j: (lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias))(self.convs[("waveconv", i, j)])
+            yl_in = yl
+            yh, yl_ll, yl, disp, mid = ops.fused_level_train(x, hd(1), hd(-1), 2.0 ** (i - 1), yl=None if i == 4 else yl,
+                                                             disp_scale=1.0 / 2 ** (i - 1), clamp01=True,
+                                                             head_ll=hd(0) if i == 4 else None, scale_ll=2.0 ** i, x_gate=gate)
+            if i == 4:
+                yl_in = yl_ll
+            if self.branch_trace is not None:   # which LeakyReLU piece each element took (gradient-parity diagnostics)
+                o = 0
+                for j in ([0] if i == 4 else []) + [1, -1]:
+                    c = self.convs[("waveconv", i, j)][0].conv.weight.shape[0]
+                    self.branch_trace[("waveconv", i, j)] = (mid[:, o:o + c] > 0).cpu()
+                    o += c
+            self.outputs[("wavelets", i - 1, "LL")] = yl_in
+            yh = yh.unsqueeze(1)
+            fused = True
         else:
             gate = ("elu", 0.0) if (torch.is_grad_enabled() and getattr(self, "_gated", False)) else None   # x is this decoder's own ELU output, its producer expects dz (see _forward_impl)
             if i == 4:

@@ -613,10 +613,17 @@ class _StackedHeadsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_yh, d_yl, _d_mid):
-        l = _lib.lib()
         x, mid, sp, sn, sl = ctx.saved_tensors[:5]
-        params = ctx.saved_tensors[5:]
-        x_gate, s_hf, s_ll, has_ll, order, offs = ctx.meta
+        dx, grads = _stacked_heads_backward(x, mid, sp, sn, sl, ctx.saved_tensors[5:], ctx.meta, d_yh, d_yl, ctx.needs_input_grad[0])
+        return (dx, None, None, None) + tuple(grads)
+
+
+def _stacked_heads_backward(x, mid, sp, sn, sl, params, meta, d_yh, d_yl, want_dx):
+    """Backward of a level's stacked heads from the saved 1x1 outputs `mid` and sigmoid outputs sp / sn / sl (see
+    _StackedHeadsFn): -> (dx, [dw1, db1, dw3, db3 of the + head, the - head(, the LL head)])."""
+    if True:
+        l = _lib.lib()
+        x_gate, s_hf, s_ll, has_ll, order, offs = meta
         heads = [params[i:i + 4] for i in range(0, len(params), 4)]
         B, Ct, H, W = mid.shape
         C_in = x.shape[1]
@@ -635,7 +642,6 @@ class _StackedHeadsFn(torch.autograd.Function):
             rows[k] = r
             r += heads[k][2].shape[0]
         w1s = torch.cat([heads[k][0].detach() for k in order], 0)
-        want_dx = ctx.needs_input_grad[0]
         dzmid = torch.empty_like(mid)
         a3_pending = None
         nsl = sum((heads[k][2].shape[1] + 63) // 64 for k in order)
@@ -736,7 +742,7 @@ class _StackedHeadsFn(torch.autograd.Function):
             c1, c3 = w1.shape[0], w3.shape[0]
             dw3k, db3k = head_grads3(k)
             grads += [dw1f[offs[k]:offs[k] + c1].reshape(w1.shape), db1f[offs[k]:offs[k] + c1], dw3k, db3k]
-        return (dx, None, None, None) + tuple(grads)
+        return dx, grads
 
 
 def stacked_heads(x, head_p, head_n, scale_hf, head_ll=None, scale_ll=1.0, x_gate=None, return_mid=False):
@@ -856,7 +862,7 @@ def head_level_folds_range_keys(C_):
 
 
 def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, clamp01=False, head_ll=None, scale_ll=1.0,
-                            yh_mask=None, run_mask=None, range_keys=None):
+                            yh_mask=None, run_mask=None, range_keys=None, train=None):
     """Inference form of one level's high-frequency heads + (optionally) the Haar IDWT in one launch (C = 32:
     wmd_head_level_fwd, every intermediate in LDS) or two: wmd_head_fused_fwd (1x1 -> LeakyReLU -> 27 tap-partials per
     side, intermediate stays on chip) and wmd_head_shiftsum_fwd (9-tap gather, bias, sigmoid, combine, IDWT).
@@ -867,10 +873,16 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
     run_mask (uint8 [B,H,W], two-launch form): pixel runs without a set byte skip the GEMMs (wmd_head_fused_args.run_mask);
     range_keys (int32 [B,2], two-launch form): the (min, max) of the new low-pass plane are folded into it by the second
     launch's epilogue (wmd_head_shiftsum_args.range_keys) -- returns None for them when the one-launch kernel ran.
+    train (round 5: the training forward on these kernels, _FusedLevelFn): dict(mid=[B,Ct,H,W], off_p=, off_n=, off_ll=,
+    sig_p=, sig_n= [B,3,H,W], sig_ll= [B,1,H,W] or None) -- the LeakyReLU outputs of the 1x1 stage and the sigmoid outputs are
+    written there as well (what autograd would have kept for the backward).
     Returns (yh [B,1,3,H,W], out or None, disp or None[, yl_ll [B,1,H,W] when head_ll is given])."""
     l = _lib.lib()
     x = _c(x)
     B, Cc, H, W = x.shape
+    tr = train or {}
+    if train is not None and not fused_train_supported(Cc, H, W, head_ll is not None):
+        raise _lib.WmdError("head_fused_level_nograd: no fused training forward for C=%d, %dx%d%s" % (Cc, H, W, " + LL" if head_ll is not None else ""))
     if yh_mask is not None and (yh_mask.dtype != torch.uint8 or yh_mask.numel() != B * H * W or not yh_mask.is_contiguous()):
         raise _lib.WmdError("head_fused_level_nograd: yh_mask must be a contiguous uint8 [B,H,W] tensor")
     (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
@@ -899,6 +911,9 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
                                wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), bias_p=ptr(b3p), bias_n=ptr(b3n), yh=ptr(yh),
                                yl=ptr(yl), out=ptr(out), disp=ptr(disp), disp_scale=float(disp_scale or 1.0),
                                clamp01=int(clamp01), yh_mask=ptr(yh_mask))
+        if train is not None:
+            a.mid_out, a.mid_ct, a.mid_off_p, a.mid_off_n = ptr(tr["mid"]), tr["mid"].shape[1], tr["off_p"], tr["off_n"]
+            a.sig_p, a.sig_n = ptr(tr["sig_p"]), ptr(tr["sig_n"])
         check(l.wmd_head_level_fwd(C.byref(a), s), "wmd_head_level_fwd")
     else:
         planes = 81 if head_ll is not None else 54
@@ -911,6 +926,9 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
             b1l_c = _c(b1l.detach())
             if _LL_MERGE:
                 a.ll_wp1, a.ll_bias1, a.ll_wp2 = ptr(wpl1), ptr(b1l_c), ptr(wpl2)
+        if train is not None:
+            a.mid_out, a.mid_ct, a.mid_off_p, a.mid_off_n = ptr(tr["mid"]), tr["mid"].shape[1], tr["off_p"], tr["off_n"]
+            a.mid_off_ll = tr.get("off_ll", 0)
         check(l.wmd_head_fused_fwd(C.byref(a), s), "wmd_head_fused_fwd")
         if head_ll is not None and not _LL_MERGE:
             a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wpl1), bias1=ptr(b1l_c), wp2=ptr(wpl2),
@@ -922,10 +940,110 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
                                   bias_ll=ptr(b3l) if head_ll is not None else None, scale_ll=float(scale_ll),
                                   yl_out=ptr(yl_ll) if head_ll is not None else None, yh_mask=ptr(yh_mask),
                                   range_keys=ptr(range_keys) if out is not None else None)
+        if train is not None:
+            g.sig_p, g.sig_n = ptr(tr["sig_p"]), ptr(tr["sig_n"])
+            g.sig_ll = ptr(tr.get("sig_ll")) if head_ll is not None else None
         check(l.wmd_head_shiftsum_fwd(C.byref(g), s), "wmd_head_shiftsum_fwd")
     if yl_ll is not None:
         return yh.unsqueeze(1), out, disp, yl_ll
     return yh.unsqueeze(1), out, disp
+
+
+_TRAIN_FUSED = os.environ.get("WMD_TRAIN_FUSED_HEADS", "1") != "0"   # 0: training forward of the heads on _StackedHeadsFn + idwt_haar
+_HEAD_CHAIN_ON = os.environ.get("WMD_HEAD_CHAIN", "1") != "0"
+
+
+def fused_train_supported(C_, H, W, has_ll):
+    """Can the training forward of a level's heads run on the fused inference kernels (_FusedLevelFn)?  They must be able to
+    write the 1x1 outputs: the one-launch kernel (C = 32, no low-pass head) or the chained kernel (C = 64 / 128 / 256, planes of
+    a multiple of 4 pixels; the low-pass head only folded into the C = 256 launch)."""
+    if not _TRAIN_FUSED or _TWO_LAUNCH_HEAD:
+        return False
+    if bool(_lib.lib().wmd_head_level_supported(int(C_))):
+        return not has_ll
+    if not _HEAD_CHAIN_ON or int(C_) not in (64, 128, 256) or (H * W) % 4:
+        return False
+    return (not has_ll) or (int(C_) == 256 and _LL_FOLD and _LL_MERGE)
+
+
+class _FusedLevelFn(torch.autograd.Function):
+    """One decoder level's wavelet heads AND its Haar synthesis in training mode on the inference kernels (round 5; VERDICT r4:
+    the training forward ran the 3x3 stage on a VALU kernel, 0.19 ms per step at 0 % MFMA): wmd_head_fused_fwd +
+    wmd_head_shiftsum_fwd (or wmd_head_level_fwd at C = 32) with the extra outputs the backward needs -- the LeakyReLU outputs
+    of the stacked 1x1 (`mid`, same layout as _StackedHeadsFn's) and the sigmoid outputs.  Backward = adjoint of the synthesis
+    (wmd_idwt_haar_bwd, incl. the clamp of the disparity) followed by _stacked_heads_backward, unchanged.
+
+    inputs: x, yl (previous low-pass or None), x_gate, scale_hf, scale_ll, disp_scale, clamp01, then (w1, b1, w3, b3) of the
+    + head, the - head and optionally the LL head.  outputs: yh [B,3,H,W], yl_ll [B,1,H,W] (or empty), out, disp, mid."""
+
+    @staticmethod
+    def forward(ctx, x, yl, x_gate, scale_hf, scale_ll, disp_scale, clamp01, *params):
+        x = _c(x)
+        heads = [params[i:i + 4] for i in range(0, len(params), 4)]       # [+, -, (LL)]
+        has_ll = len(heads) == 3
+        order = ([2] if has_ll else []) + [0, 1]                            # channel order of mid: [LL, +, -]
+        offs, o = {}, 0
+        for k in order:
+            offs[k] = o
+            o += heads[k][0].shape[0]
+        B, _, H, W = x.shape
+        dev = x.device
+        mid = torch.empty((B, o, H, W), device=dev, dtype=torch.float32)
+        sp = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+        sn = torch.empty_like(sp)
+        sl = torch.empty((B, 1, H, W), device=dev, dtype=torch.float32) if has_ll else None
+        train = dict(mid=mid, off_p=offs[0], off_n=offs[1], off_ll=offs.get(2, 0), sig_p=sp, sig_n=sn, sig_ll=sl)
+        # (the parameters themselves, not detached views: the packed weight images are memoised on the parameter objects)
+        res = head_fused_level_nograd(x, tuple(heads[0]), tuple(heads[1]), scale_hf, yl=None if has_ll else _c(yl.detach()),
+                                      disp_scale=disp_scale, clamp01=clamp01, head_ll=tuple(heads[2]) if has_ll else None,
+                                      scale_ll=scale_ll, train=train)
+        yh, out, disp = res[0].squeeze(1), res[1], res[2]
+        yl_ll = res[3] if has_ll else yh.new_empty(0)
+        ctx.save_for_backward(x, mid, sp, sn, sl, out, *params)
+        ctx.meta = (x_gate, float(scale_hf), float(scale_ll), has_ll, order, offs)
+        ctx.cfg = (float(disp_scale), bool(clamp01))
+        ctx.mark_non_differentiable(mid)
+        return yh, yl_ll, out, disp, mid
+
+    @staticmethod
+    def backward(ctx, d_yh, d_yl_ll, d_out, d_disp, _d_mid):
+        l = _lib.lib()
+        x, mid, sp, sn, sl, out = ctx.saved_tensors[:6]
+        params = ctx.saved_tensors[6:]
+        has_ll = ctx.meta[3]
+        disp_scale, clamp01 = ctx.cfg
+        B, _, H, W = x.shape
+        # adjoint of the synthesis: d(out) + d(disp) through the clamp -> d(low-pass input), d(yh)
+        d_lo = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+        d_hi = torch.empty((B, 1, 3, H, W), device=x.device, dtype=torch.float32)
+        d_out = _c(d_out) if d_out is not None else None
+        d_disp = _c(d_disp) if d_disp is not None else None
+        if d_out is None and d_disp is None:
+            d_lo.zero_()
+            d_hi.zero_()
+        else:
+            check(l.wmd_idwt_haar_bwd(ptr(d_out), ptr(d_disp), ptr(out), ptr(d_lo), ptr(d_hi), B, H, W, float(disp_scale),
+                                      int(clamp01), current_stream()), "wmd_idwt_haar_bwd")
+        d_hi = d_hi.view(B, 3, H, W)
+        if d_yh is not None:
+            d_hi = d_hi + d_yh
+        d_ll = None
+        if has_ll:      # the low-pass head's output is the synthesis' low-pass input (and an output of its own)
+            d_ll = d_lo if (d_yl_ll is None or d_yl_ll.numel() == 0) else d_lo + d_yl_ll
+        dx, grads = _stacked_heads_backward(x, mid, sp, sn, sl, params, ctx.meta, d_hi, d_ll, ctx.needs_input_grad[0])
+        return (dx, None if has_ll else d_lo, None, None, None, None, None) + tuple(grads)
+
+
+def fused_level_train(x, head_p, head_n, scale_hf, yl=None, disp_scale=1.0, clamp01=True, head_ll=None, scale_ll=1.0, x_gate=None):
+    """Training-mode heads + Haar synthesis of one level on the fused kernels (see _FusedLevelFn; fused_train_supported says
+    when).  head_* = (w1, b1, w3, b3); exactly one of yl / head_ll supplies the low-pass input.
+    Returns (yh [B,3,H,W], yl_ll [B,1,H,W] or None, out [B,1,2H,2W], disp, mid)."""
+    if (yl is None) == (head_ll is None):
+        raise _lib.WmdError("fused_level_train: exactly one of yl / head_ll")
+    params = tuple(head_p) + tuple(head_n) + (tuple(head_ll) if head_ll is not None else ())
+    _require_gpu(x, *params)
+    yh, yl_ll, out, disp, mid = _FusedLevelFn.apply(x, yl, x_gate, scale_hf, scale_ll, disp_scale, clamp01, *params)
+    return yh, (yl_ll if head_ll is not None else None), out, disp, mid
 
 
 # ---------------------------------------------------------------------------------------------
