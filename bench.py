@@ -35,7 +35,7 @@ HEIGHT, WIDTH, BATCH = 192, 640, 12
 FLOP_PER_FRAME = 6.947e9     # conv MACs x2, SURVEY.md §8(d) / BASELINE.md §2
 PEAK_F32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 PEAK_HBM = 8000.0            # GB/s, MI355X_MICROARCH.md (HBM3E)
-TUNE_CACHE = "r04_tune_cache.json"   # committed tile / split-K choices (profiles/)
+TUNE_CACHE = "r05_tune_cache.json"   # committed tile / split-K choices (profiles/)
 
 
 def build_model(dev):
@@ -88,7 +88,7 @@ def cpu_baseline(dec, feats, gpu_out=None, budget_s=20.0):
     # distinct cores of one socket, next to their memory).  Round 3 let the scheduler place them: the same 32 threads gave 60
     # frames/s in the probe and 32 in the timed passes of one run (threads migrating between the sockets of a 256-thread host,
     # and the sleeping workers of the larger probes' pools still runnable).  Best (min) and median pass are both reported;
-    # `value` is the best pass: the baseline gets its best case.
+    # `value` is the median pass (the definition of rounds 1-3), `best_frames_per_s` the best one.
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -129,8 +129,11 @@ def cpu_baseline(dec, feats, gpu_out=None, budget_s=20.0):
             pass
     torch.set_num_threads(min(avail, 32))
     med, fastest = float(np.median(times)), float(min(times))
-    return {"value": round(BATCH / fastest, 2), "unit": "frames/s", "cores": best, "kind": "port", "parity_of_timed_mode": parity,
-            "median_frames_per_s": round(BATCH / med, 2), "pinned": allowed is not None,
+    # `value` = the MEDIAN pass, as in rounds 1-3 (round 4 reported the best pass under the same key: ADVICE r4, profiles/HISTORY.md);
+    # the best pass stays beside it
+    return {"value": round(BATCH / med, 2), "unit": "frames/s", "cores": best, "kind": "port", "parity_of_timed_mode": parity,
+            "value_is": "median pass", "best_frames_per_s": round(BATCH / fastest, 2), "median_frames_per_s": round(BATCH / med, 2),
+            "pinned": allowed is not None,
             "probe_frames_per_s_by_threads": probe_fps,   # best of two full batches each; 8 threads is SURVEY.md's probe setting
             "sample": "%d timed passes of the same 12x640x192 batch (best %.3f s, median %.3f s per pass) after 1 warm-up; torch %s CPU; "
                       "%d threads pinned to the first %d allowed logical CPUs = best of %s on two full-batch passes each; host exposes "
@@ -282,7 +285,27 @@ def _per_step_ms(step, steps):
 def train_stats(kind, args, rank, world, dev, red_dev, steps, warmup, strong=False):
     """Time the data-parallel training step with the gradient exchange on, then (world > 1) with the all-reduces switched
     off: the difference is the all-reduce time the overlap did NOT hide.  -> dict (same on every rank)."""
-    step, gx, cfg, (loss_fn, opt, nets, part_ms) = _train_setup(kind, args, rank, world, dev, strong)
+    # Set-up (model, RCCL communicator, parameter broadcast) is where a multi-GPU launch fails if it fails -- and it may fail on
+    # SOME ranks only, which would leave the others waiting in the first collective of the timed steps.  So every rank reports
+    # its set-up status through the process group that is already up, and all of them raise together, with every rank's error
+    # string and the state of HSA_ENABLE_IPC_MODE_LEGACY in the message (-> the line's `train.error`).
+    setup, err = None, None
+    try:
+        setup = _train_setup(kind, args, rank, world, dev, strong)
+    except Exception as e:      # noqa: BLE001 -- reported, then re-raised on every rank
+        err = "%s: %s" % (type(e).__name__, str(e)[:600])
+    if world > 1:
+        import torch.distributed as dist
+        rec = {"rank": rank, "error": err, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+               "device": str(dev), "exchange_backend": args.exchange_backend}
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+        bad = [r for r in recs if r["error"]]
+        if bad:
+            raise RuntimeError("training set-up failed on %d of %d ranks: %s" % (len(bad), world, json.dumps(bad)))
+    elif err:
+        raise RuntimeError("training set-up failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=%s)" % (err, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+    step, gx, cfg, (loss_fn, opt, nets, part_ms) = setup
     elapsed, loss = _timed(step, steps, warmup, world, red_dev)
     assert torch.isfinite(loss)
     del loss      # nothing may keep the eager autograd graph (and its default-stream AccumulateGrad nodes) alive into the capture
@@ -374,7 +397,9 @@ def main():
     ap.add_argument("--no-train-nyu", action="store_true", help="skip the NYUv2 DenseNet161 training step of the fwd line")
     ap.add_argument("--train-graph", choices=["auto", "on", "off"], default="auto",
                     help="also time the training step as hipGraph replays (auto: single-GPU --workload train / train-nyu runs)")
-    ap.add_argument("--workload", choices=["fwd", "train", "train-nyu"], default="fwd")
+    ap.add_argument("--workload", choices=["fwd", "train", "train-nyu", "fwd-1024"], default="fwd",
+                    help="fwd-1024: only the line's secondary forward workload (KITTI ResNet50 1024x320, batch 8) -- what the counter "
+                         "passes of tools/profile_session.sh run")
     ap.add_argument("--strong", action="store_true", help="--workload train: --batch is the global batch, split over the ranks "
                     "(strong scaling); default: --batch per GPU (weak scaling)")
     ap.add_argument("--num-layers", type=int, default=50)
@@ -416,6 +441,14 @@ def main():
     if os.environ.get("WMD_BENCH_RETUNE", "0") != "1":
         tuner.preload(os.path.join(ROOT, "profiles", TUNE_CACHE))
 
+    if args.workload == "fwd-1024":
+        if rank == 0:
+            print(json.dumps({"fwd_1024x320": forward_extra(
+                dev, [64, 256, 512, 1024, 2048], 8, 320, 1024, args.steps,
+                "KITTI ResNet50 1024x320 dense wavelet decoder + IDWT, forward, batch 8", graph=os.environ.get("WMD_BENCH_GRAPH", "1") != "0")}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.workload != "fwd":
         train_main("kitti" if args.workload == "train" else "nyu", args, rank, world, dev, red_dev)
         if world > 1:
@@ -504,7 +537,7 @@ def main():
         try:      # an extra of the line: a failure here (e.g. the RCCL exchange cannot be set up) must not cost the headline figure
             train = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 5)
         except Exception as e:
-            train = {"error": repr(e)[:400]}
+            train = {"error": repr(e)[:2000]}
         if world > 1 and args.batch % world == 0:      # "also report strong scaling of a fixed global batch"
             try:
                 train_strong = train_stats("kitti", args, rank, world, dev, red_dev, args.train_steps, 5, strong=True)
@@ -566,9 +599,35 @@ def trunk_signatures(feats):
     return sigs
 
 
-def forward_extra(dev, chans, B, H, W, steps, label):
-    """Secondary forward workload for the line (north_star: "frames/sec on synthetic 640x192 and 1024x320 batches"): the dense
-    decoder on other channels / sizes, hipGraph replay timed like the headline, + the executed-MFMA fraction of its trunk."""
+def _is_trunk_conv(r):
+    return (r["kernel"].startswith("conv_fwd_kernel<") and "fused" not in r["kernel"]) or r["kernel"].startswith("conv_wino")
+
+
+def _layer_traffic(kernel, feats):
+    """HBM bytes per launch of `kernel` on the trunk layers of this workload, from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, keyed by the autotuner's problem signature) -> (launch average, source, {signature: bytes})."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pm = json.load(f)
+    except OSError:
+        return None, None, None
+    sigs = trunk_signatures(feats)
+    layers = {sig: v for sig, v in pm.get("layers", {}).items() if v.get("kernel") == kernel and sig in sigs}
+    src = "imported: profiles/pmc_traffic.json (%s)" % pm.get("source", "rocprofv3 --pmc passes of bench.py")
+    if not layers:
+        t = pm["kernels"].get(kernel, {}).get("traffic_bytes_per_launch") if sigs & set(pm.get("layers", {})) else None
+        return t, (src if t is not None else None), None
+    by_layer = {sig: {"hbm_bytes": v["hbm_bytes_per_launch"], "algorithmic_bytes": v.get("algorithmic_bytes"),
+                      "mfma_busy_frac": v.get("mfma_busy_frac")} for sig, v in layers.items()}
+    return int(sum(v["hbm_bytes_per_launch"] for v in layers.values()) / len(layers)), src, by_layer
+
+
+def forward_extra(dev, chans, B, H, W, steps, label, graph=True):
+    """Secondary forward workload for the line (north_star: "frames/sec on synthetic 640x192 and 1024x320 batches ... as fraction
+    of the roofline"): the dense decoder on other channels / sizes, hipGraph replay timed like the headline, the executed-MFMA
+    fraction of its trunk and -- round 5 -- its dominant kernel the way the headline's `roofline` object reports it: launches,
+    average launch time (hipEvents), executed / algorithmic rate against the fp32 MFMA peak, algorithmic and measured HBM bytes
+    per launch (the counter passes of `--workload fwd-1024`, tools/profile_session.sh)."""
     from wavelet_monodepth_amd import _lib, synth
     from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
     dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
@@ -579,7 +638,7 @@ def forward_extra(dev, chans, B, H, W, steps, label):
         for _ in range(3):
             dec(feats)
         recs = _lib.profile_end()
-        dec.enable_graph(True)
+        dec.enable_graph(graph)
         for _ in range(5):
             dec(feats)
         torch.cuda.synchronize()
@@ -588,13 +647,24 @@ def forward_extra(dev, chans, B, H, W, steps, label):
             dec(feats)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-    convs = [r for r in recs if (r["kernel"].startswith("conv_fwd_kernel<") and "fused" not in r["kernel"]) or r["kernel"].startswith("conv_wino")]
-    ex = sum(r.get("mfma_flops", r["flops"]) for r in convs)
+    convs = [r for r in recs if _is_trunk_conv(r)]
+    executed = lambda r: r.get("mfma_flops", r["flops"])
+    ex = sum(executed(r) for r in convs)
     cms = sum(r["ms"] for r in convs)
+    dom = max(convs, key=lambda r: r["ms"])
+    traffic, traffic_src, by_layer = _layer_traffic(dom["kernel"], feats)
     return {"workload": label, "frames_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "steps": steps,
             "trunk_executed_mfma_frac": round(ex / (cms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
             "trunk_algorithmic_tflops": round(sum(r["flops"] for r in convs) / (cms * 1e-3) / 1e12, 1),
-            "trunk_ms_per_step": round(cms / 3, 4), "gpu_ms_per_step_eager": round(sum(r["ms"] for r in recs) / 3, 4)}
+            "trunk_ms_per_step": round(cms / 3, 4), "gpu_ms_per_step_eager": round(sum(r["ms"] for r in recs) / 3, 4),
+            "roofline": {"bound": "mfma", "kernel": dom["kernel"], "launches_per_step": dom["calls"] // 3,
+                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2),
+                         "achieved": round(executed(dom) / (dom["ms"] * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                         "frac": round(executed(dom) / (dom["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
+                         "achieved_algorithmic": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"], "traffic": traffic,
+                         "traffic_source": traffic_src, "traffic_by_layer": by_layer},
+            "kernels_ms_per_step": {r["kernel"]: round(r["ms"] / 3, 4) for r in recs}}
 
 
 def roofline(dec, feats, steps):
@@ -614,7 +684,7 @@ def roofline(dec, feats, steps):
         recs = _lib.profile_end()
     # trunk convolutions: the direct kernels and the Winograd ones (the fused-head GEMM chains are listed apart)
     is_wino = lambda r: r["kernel"].startswith("conv_wino")
-    convs = [r for r in recs if (r["kernel"].startswith("conv_fwd_kernel<") and "fused" not in r["kernel"]) or is_wino(r)]
+    convs = [r for r in recs if _is_trunk_conv(r)]
     dom = max(convs, key=lambda r: r["ms"])
     tot_ms = sum(r["ms"] for r in recs)
     conv_ms = sum(r["ms"] for r in convs)
@@ -625,19 +695,7 @@ def roofline(dec, feats, steps):
     # HBM bytes per launch: rocprofv3 --pmc passes of this same command (tools/profile_session.sh), keyed by the PROBLEM SIGNATURE
     # of every trunk layer (the autotuner's key: batch, size, channels) -- round 3 keyed them by kernel name + grid size and
     # mistook one layer for another.  `traffic` = launch average over the layers the dominant kernel runs, as `achieved` is.
-    traffic, traffic_src, by_layer = None, None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pm = json.load(f)
-        layers = {sig: v for sig, v in pm.get("layers", {}).items() if v.get("kernel") == dom["kernel"] and sig in trunk_signatures(feats)}
-        if layers:
-            by_layer = {sig: {"hbm_bytes": v["hbm_bytes_per_launch"], "algorithmic_bytes": v.get("algorithmic_bytes")} for sig, v in layers.items()}
-            traffic = int(sum(v["hbm_bytes_per_launch"] for v in layers.values()) / len(layers))
-        else:
-            traffic = pm["kernels"].get(dom["kernel"], {}).get("traffic_bytes_per_launch")
-        traffic_src = "imported: profiles/pmc_traffic.json (%s)" % pm.get("source", "rocprofv3 --pmc passes of bench.py")
-    except OSError:
-        pass
+    traffic, traffic_src, by_layer = _layer_traffic(dom["kernel"], feats)
     # the HBM-bound kernel of the path: the Haar synthesis is fused into the head kernels, whose epilogues write
     # the planes it defines -- 8 B read + 4 B written per output pixel (+ 4 B for the disparity plane), 163 200 output pixels
     # per frame; reported against the time of the launches that contain it

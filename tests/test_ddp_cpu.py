@@ -146,6 +146,56 @@ def test_ranks_that_reach_different_parameters_are_caught_before_any_arm_is_lowe
         assert got == ["raised", True, "ok", True], (r, got)
 
 
+def _strong_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wavelet_monodepth_amd.ddp import GradientExchange, bucket_groups
+    net = TinyNet()
+    gx = GradientExchange(bucket_groups(net.encoder, net.decoder, bucket_bytes=1200), backend="torch", modules=[net])
+    torch.manual_seed(7)
+    full, target = torch.randn(4, 3, 8, 8), torch.randn(4, 1, 8, 8)
+    per = full.shape[0] // world                          # `bench.py --workload train --strong`: the GLOBAL batch split over the ranks
+    x, y = full[rank * per:(rank + 1) * per], target[rank * per:(rank + 1) * per]
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    losses = []
+    for _ in range(3):
+        gx.zero_grad()
+        loss = (net(x) - y).abs().mean()
+        loss.backward()
+        gx.finish()                                       # sum over the ranks / world = the full batch's mean gradient
+        opt.step()
+        t = loss.detach().clone()
+        dist.all_reduce(t)
+        losses.append(float(t) / world)                   # equal shards: the global loss is the mean of the shard losses
+    torch.save({"losses": losses, "params": [p.detach().clone() for p in net.parameters()]}, os.path.join(out_dir, "s%d.pt" % rank))
+    gx.close()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_split_reproduces_the_single_rank_trajectory(tmp_path):
+    """a fixed global batch split over 2 ranks (what `bench.py --strong` does) must walk the SAME loss trajectory
+    and reach the same parameters as one rank stepping the whole batch -- three optimizer steps with momentum, so that an
+    exchange that averaged wrongly (or a bucket that stopped being sent after the first step) shows up in steps 2 and 3."""
+    world, port = 2, _free_port()
+    mp.spawn(_strong_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    net = TinyNet()
+    torch.manual_seed(7)
+    full, target = torch.randn(4, 3, 8, 8), torch.randn(4, 1, 8, 8)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    want = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = (net(full) - target).abs().mean()
+        loss.backward()
+        opt.step()
+        want.append(float(loss))
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, "s%d.pt" % r))
+        assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(got["losses"], want)), (r, got["losses"], want)
+        for a, b in zip(got["params"], net.parameters()):
+            assert torch.allclose(a, b.detach(), atol=1e-6, rtol=1e-5)
+
+
 def test_message_sizes_match_survey():
     """R18 encoder + wavelet decoder: 11.2 M + 3.36 M parameters -> ~58 MB of gradients."""
     import numpy as np

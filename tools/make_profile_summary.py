@@ -76,10 +76,10 @@ def merged(per_grid):
             "by_grid_size": per_grid}
 
 
-def conv_plan():
+def conv_plan(name="conv_plan.txt"):
     """conv_plan.txt = stderr of one eager bench step under WMD_CONV_VERBOSE=1: the problem signature of every trunk layer with
     the kernel and grid it ran on -> {signature: (kernel, rocprof Grid_Size)} (Grid_Size = total work-items of the launch)."""
-    f = os.path.join(src, "conv_plan.txt")
+    f = os.path.join(src, name)
     plan = {}
     if os.path.exists(f):
         for ln in open(f):
@@ -116,17 +116,21 @@ copy("tune_cache.json", tag + "_tune_cache.json")
 copy("gpu_tests.txt", tag + "_gpu_tests.txt")
 method = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc <SQ counters> GRBM_GUI_ACTIVE in separate passes (tools/profile_session.sh); "
           "per-launch averages; HBM-side bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE reports half of the fetched bytes on gfx950)")
+layers, fwd_kernels = {}, {}
 for kind, what in (("fwd", "WMD_BENCH_GRAPH=0 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train"),
+                   ("fwd1024", "WMD_BENCH_GRAPH=0 python bench.py --workload fwd-1024 --steps 3 (KITTI ResNet50 1024x320, batch 8, forward)"),
                    ("bwd", "python tools/train_profile.py (decoder forward + backward, config 2 shapes)"),
                    ("sparse", "python tools/sparse_profile.py 0.15 (sparse KITTI decoder, batch 1)")):
     summ = summarise(kind)
     if not summ:
         continue
     json.dump({"_method": method, "command": what, "session": tag, "kernels": summ}, open(os.path.join(P, "%s_pmc_%s.json" % (tag, kind)), "w"), indent=1)
-    if kind == "fwd":
+    if kind in ("fwd", "fwd1024"):
         # trunk layers by PROBLEM SIGNATURE (what bench.py's roofline.traffic reads): joined on (kernel, grid) with the plan dump;
         # two layers that share a kernel AND a grid cannot be told apart by the counters and are flagged instead of guessed
-        layers, plan = {}, conv_plan()
+        # (both forward workloads land in ONE `layers` object: their signatures differ in batch and size)
+        plan = conv_plan("conv_plan.txt" if kind == "fwd" else "conv_plan_1024.txt")
+        fwd_kernels = {k: merged(v) for k, v in summ.items()} if kind == "fwd" else fwd_kernels
         for sig, (kern, grid) in sorted(plan.items()):
             twins = [s2 for s2, kg in plan.items() if kg == (kern, grid)]
             row = summ.get(kern, {}).get(grid)
@@ -136,8 +140,10 @@ for kind, what in (("fwd", "WMD_BENCH_GRAPH=0 python bench.py --steps 3 --warmup
                            "fetch_kib_raw": row["fetch_kib_raw"], "write_kib": row["write_kib"], "algorithmic_bytes": algorithmic_bytes(sig),
                            "mfma_busy_frac": row.get("mfma_busy_frac"), "ambiguous_with": [t for t in twins if t != sig] or None}
         json.dump({"_method": method, "session": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, session " + tag,
-                   "layers": layers, "kernels": {k: merged(v) for k, v in summ.items()}}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+                   "layers": layers, "kernels": fwd_kernels}, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
         for sig, v in layers.items():
+            if sig not in plan:
+                continue
             print("  layer %-38s %-34s %7.1f MB HBM vs %6.1f MB algorithmic (%.2fx)" % (sig, v["kernel"], v["hbm_bytes_per_launch"] / 1e6,
                                                                                       v["algorithmic_bytes"] / 1e6, v["hbm_bytes_per_launch"] / v["algorithmic_bytes"]))
     print("==", kind)

@@ -32,7 +32,10 @@ fwd)
     tail -c 400 $OUT/bench.json; echo
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $REPO/bench.py --no-cpu-baseline --no-train > $OUT/stats.log 2>&1)
     cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv; rm -rf $OUT/stats
-    WMD_BENCH_GRAPH=0 pmc_passes fwd python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train ;;
+    WMD_BENCH_GRAPH=0 pmc_passes fwd python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train
+    # north_star's second resolution (KITTI ResNet50 1024x320, batch 8): plan dump + the same three counter passes
+    WMD_CONV_VERBOSE=1 WMD_BENCH_GRAPH=0 python bench.py --workload fwd-1024 --steps 1 2>&1 >/dev/null | grep "sig conv" | sort -u > $OUT/conv_plan_1024.txt
+    WMD_BENCH_GRAPH=0 pmc_passes fwd1024 python $REPO/bench.py --workload fwd-1024 --steps 3 ;;
 bwd)   # WMD_TUNE_CACHE: the first run tunes and stores its choices, the counter passes replay them (no tuning launches in the counters)
     export WMD_TUNE_CACHE=$OUT/train_tune_cache.json
     python tools/train_profile.py > $OUT/train_profile_r18_640x192_bs12.txt 2>&1

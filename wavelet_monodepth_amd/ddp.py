@@ -68,7 +68,16 @@ class _RcclBackend:
             store.set("wmd_comm_uid", uid.raw)
         raw = store.get("wmd_comm_uid")
         self.comm = C.c_void_p()
-        _lib.check(l.wmd_comm_init(C.byref(self.comm), raw, world, rank), "wmd_comm_init")
+        try:
+            _lib.check(l.wmd_comm_init(C.byref(self.comm), raw, world, rank), "wmd_comm_init")
+        except _lib.WmdError as e:
+            #  name the known cause instead of leaving the caller with RCCL's `hipIpcGetMemHandle: invalid argument`
+            if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+                raise _lib.WmdError("%s -- rank %d of %d: HSA_ENABLE_IPC_MODE_LEGACY=0 is not in this process' environment; the host "
+                                    "driver only supports dmabuf IPC and RCCL's communicator set-up between processes fails without "
+                                    "it.  Export it in the LAUNCHER (before the first HIP call; INTEGRATION.md, 'Multi-GPU launch')"
+                                    % (e, rank, world)) from e
+            raise _lib.WmdError("%s -- rank %d of %d (HSA_ENABLE_IPC_MODE_LEGACY=%s)" % (e, rank, world, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))) from e
         self.world = world
         self.side = torch.cuda.Stream()
 

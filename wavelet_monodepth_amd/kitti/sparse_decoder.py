@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops, sparse_ops as S
+from .. import _lib, ops, sparse_ops as S
 from ..wavelets import IDWT
 from ..graphs import GraphCache
 from .depth_decoder import _build_wave_convs
@@ -181,6 +181,10 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         if os.environ.get("WMD_SPARSE_LISTS", "1") == "0" or not self._block_sparse(0) or not self.use_skips:
             return False
         if _force_masks is not None and 4 in _force_masks:
+            return False
+        if any(i > 3 for i in set(sparse_scales)):
+            # level 4 has no low-pass plane to threshold: the reference and the tile form fail an assertion there -- so must this
+            # form (it used to drop the level silently and run it densely); 0 is ignored by every form
             return False
         lv = sorted(i for i in set(sparse_scales) if 1 <= i <= 3)
         if not lv or lv != list(range(1, lv[-1] + 1)):
@@ -451,9 +455,14 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
         #  where tail rounds of whole tiles are what skipping loses, and cost on the small ones)
         list_from = int(os.environ.get("WMD_SPARSE_LIST_FROM", "800"))
 
-        def tile_for(hh, ww, cout):
+        def tile_for(hh, ww, cout, cin=8, c_up=8):
+            # a LIST launch needs the flattened staging (wino32_pure: every 8-channel chunk inside one source tensor) and a tile
+            # shape the library has a work-list kernel for; anything else takes the mask form of the same level
+            if cin % 8 or c_up % 8:
+                return None
             if forced_tile:
-                return tuple(int(v) for v in forced_tile.split("x"))
+                th, tw = (int(v) for v in forced_tile.split("x"))
+                return (th, tw) if _lib.lib().wmd_conv_list_tile_supported(th, tw) else None
             items = B * (-(-hh // 8)) * (-(-ww // 16)) * (-(-cout // 32))
             if items < list_from:
                 return None
@@ -474,7 +483,9 @@ class SparseDepthWaveProgressiveDecoder(nn.Module):
             if i in lv:
                 k = lv.index(i)
                 C0, C1_ = c0.weight.shape[0], c1.weight.shape[0]
-                specs = [(1, 1, 0, None), (1, 2, 1, tile_for(h, w, C0)), (2, 2, 0, None), (2, 1, 2, tile_for(H2, W2, C1_)), (2, 0, 3, None)]
+                skip_c = input_features[i - 1].shape[1]
+                specs = [(1, 1, 0, None), (1, 2, 1, tile_for(h, w, C0, c0.weight.shape[1])), (2, 2, 0, None),
+                         (2, 1, 2, tile_for(H2, W2, C1_, c1.weight.shape[1], C0 if skip_c else 8)), (2, 0, 3, None)]
                 if prev_upconv1 is not None:     # input support of upconv(i,0): lowres AND the previous sparse level's support
                     specs.append((1, 1, 0, None, prev_upconv1))
                 if forced:
