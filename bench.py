@@ -724,6 +724,13 @@ def roofline(dec, feats, steps):
                                  "achieved_algorithmic": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                  "ms_per_step": round(conv_ms / steps, 4),
                                  "share_of_gpu_time": round(conv_ms / tot_ms, 3)},
+            # the 32x32x2 Winograd kernels as ONE family (conv_wino32_kernel's tile shapes + the quarter-position conv_wino32q_kernel):
+            # which instantiation the tuner gives a layer changes from box to box, this aggregate does not
+            "wino32_family": (lambda fam: {"kernels": sorted(r["kernel"] for r in fam), "launches_per_step": sum(r["calls"] for r in fam) // steps,
+                                           "ms_per_step": round(sum(r["ms"] for r in fam) / steps, 4),
+                                           "achieved": round(sum(executed(r) for r in fam) / (sum(r["ms"] for r in fam) * 1e-3) / 1e12, 2),
+                                           "frac": round(sum(executed(r) for r in fam) / (sum(r["ms"] for r in fam) * 1e-3) / 1e12 / PEAK_F32_MFMA, 4)}
+                              if fam else None)([r for r in convs if r["kernel"].startswith("conv_wino32")]),
             "heads_and_idwt": {"ms_per_step": round(sum(r["ms"] for r in heads) / steps, 4)},
             "whole_step": {"achieved_algorithmic": round(FLOP_PER_FRAME * BATCH * steps / (tot_ms * 1e-3) / 1e12, 2),
                            "gpu_ms_per_step": round(tot_ms / steps, 4)},

@@ -138,3 +138,9 @@ def check_packed(out, gold, tol, exact=True, limit=4096):
 def unpack_mask(gold, key):
     shape = tuple(int(n) for n in gold["mshape|" + key])
     return np.unpackbits(gold["m|" + key])[:int(np.prod(shape))].reshape(shape)
+
+
+def quarter_family_declines(name, C1, C2, masked=False):
+    """conv_wino32q_kernel (round 5) takes pure, unmasked layers only -- every 8-channel chunk inside one source tensor; a forced
+    launch on anything else must return WMD_ERR_UNSUPPORTED (-3) instead of computing something."""
+    return name.startswith("conv_wino32q") and (masked or (C1 + C2) % 8 != 0 or (C2 > 0 and C1 % 8 != 0))

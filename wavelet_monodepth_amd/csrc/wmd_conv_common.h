@@ -133,6 +133,35 @@ struct W32Tile {
     static_assert((LDS_FLOATS + TAB_FLOATS) * 4 <= 160 * 1024, "LDS");
 };
 
+// conv_wino32q_kernel (wmd_conv_wino32q.hip, round 5): one tile group (32 Winograd tiles = 128 pixels) x four quarter-position
+// waves, one 32-out-channel slab; same patch / weight staging geometry as W32Tile<TH, TW, 1, CK> with 256 threads.
+template <int TH, int TW, int CK>
+struct W32QTile {
+    static constexpr int NW = 4, NT = 256;
+    static constexpr int TXB = TW / 2, TYB = TH / 2, NTILES = TXB * TYB;
+    static constexpr bool X4OK = TW % 16 == 0;
+    static constexpr int PH = TH + 2, PWS = X4OK ? ((TW + 2 + 3) / 4) * 4 : TW + 2;
+    static constexpr int PSF = PH * PWS;
+    static constexpr int PHL = TH / 2 + 2, PWL = X4OK ? ((TW / 2 + 2 + 3) / 4) * 4 : TW / 2 + 2, PSL = PHL * PWL;
+    static constexpr int GF = PWS / 4, GL = PWL / 4;
+    static constexpr int RUN = CK * 256;
+    static constexpr int RUN_LDS = RUN + 16;
+    static constexpr int A_FLOATS = 2 * RUN_LDS;
+    static constexpr int B_FLOATS = ((CK * PSF + 255) / 256) * 256;   // whole LDS-DMA runs of either piece size (tail = padding)
+    static constexpr int NAV = (2 * CK * 64 + NT - 1) / NT;
+    static constexpr int BUF_FLOATS = B_FLOATS + A_FLOATS;
+    static constexpr int KW = CK / 2;
+    static constexpr int XCH_FLOATS = 4 * 32 * 64;   // the four quarters trade 32 partial outputs per lane
+    static constexpr int LDS_FLOATS = 2 * BUF_FLOATS > XCH_FLOATS ? 2 * BUF_FLOATS : XCH_FLOATS;
+    static constexpr int TAB_FLOATS = ((PH + PWS + PHL + PWL + 3) / 4) * 4;
+    static_assert(TH % 2 == 0 && TW % 8 == 0, "whole 2x2 tiles; a lane's four consecutive tiles stay in one tile row");
+    static_assert(NTILES <= 32 && NTILES % 2 == 0, "one tile group");
+    static_assert(CK % 4 == 0 && PWS % 2 == 0 && PSF % 2 == 0, "8-byte patch reads");
+    static_assert((LDS_FLOATS + TAB_FLOATS) * 4 <= 53 * 1024, "three blocks per CU");
+};
+template <int TH, int TW, int CK>
+void launch_wino32q(const ConvKArgs& a, dim3 grid, hipStream_t s);   // explicit instantiations: wmd_conv_wino32q_table.inc
+
 // conv_wino32_kernel's flattened-staging instantiation needs every chunk inside one source tensor, one full-resolution
 // geometry; an input mask must live on that geometry too (same-size x1, or an upsampled x1 under a 2x2-constant mask, whose
 // low-resolution patch reads the mask at (2y, 2x)); everything else runs the GENERIC instantiation

@@ -904,6 +904,13 @@ static void launch_wino(const ConvKArgs& a, dim3 grid, hipStream_t s) {
             (int)sizeof(float) * (W32Tile<TH, TW, WN, CK>::LDS_FLOATS + W32Tile<TH, TW, WN, CK>::TAB_FLOATS),          \
             &launch_wino32<TH, TW, WN, CK>, "conv_wino32_kernel<" #TH "," #TW "," #WN "," #CK ">"},
 
+// conv_wino32q_kernel (wmd_conv_wino32q.hip, round 5) entries: TAPS = 18 marks the family (quarter-position waves: pure unmasked
+// layers only); MR = 2 (a block's slab = 32 out channels), WN = its four waves
+#define WMD_W32Q_INST(TH, TW, CK)                                                                                      \
+    ConvCfg{TH, TW, 2, 1, 1, 4, CK, 18,                                                                                \
+            (int)sizeof(float) * (W32QTile<TH, TW, CK>::LDS_FLOATS + W32QTile<TH, TW, CK>::TAB_FLOATS),                \
+            &launch_wino32q<TH, TW, CK>, "conv_wino32q_kernel<" #TH "," #TW "," #CK ">"},
+
 static const ConvCfg kCfgs[] = {
     // 3x3, 32-wide rows (W % 32 == 0: 160/320, 1024-wide pyramids)
     WMD_CFG(16, 32, 2, 8, 1, 4, 8, 9),  // co32  x 512px
@@ -970,6 +977,8 @@ static const ConvCfg kCfgs[] = {
     WMD_WINO(16, 32, 1, 2, 8, 8),   // co32 x 512px, 16 waves
     // Winograd on 32x32x2 MFMAs, two position halves per tile group
 #include "wmd_conv_wino32_table.inc"
+    // Winograd on 32x32x2 MFMAs, four quarter-position waves per tile group (three blocks per CU)
+#include "wmd_conv_wino32q_table.inc"
     // 1x1 on the flattened image (TH = 1)
     WMD_CFG(1, 256, 4, 4, 1, 4, 32, 1),  // co64  x 256px
     WMD_CFG(1, 256, 2, 4, 1, 4, 32, 1),  // co32  x 256px
@@ -1006,6 +1015,8 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         if (wino ? (taps != 9 || !g->wp_wino) : c.TAPS != taps) continue;
         if ((g->in_mask || g->out_mask) && !wino) continue;   // block-sparse execution lives in the Winograd kernels
         if (g->gate && wino) continue;                        // the output gate lives in the direct kernels (and the split-K reduce)
+        if (c.TAPS == 18 && (g->in_mask || g->out_mask || g->out_tiles || Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK)))
+            continue;                                         // quarter-position kernel: flattened staging of pure, unmasked layers only
         if (g->out_tiles) {   // work-list form: the LIST instantiations of conv_wino32_kernel on the list's own tile shape
             if (c.TAPS != 17 || c.TH != g->out_tile_h || c.TW != g->out_tile_w || !wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK)) continue;
             if (Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK) || (g->in_mask && g->up1 == 2 && !g->in_mask_2x2)) continue;   // wino32_pure
@@ -1018,7 +1029,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         const int nchunks = (Cin + c.CK - 1) / c.CK;
         const int waves = c.WM * c.WN;
         // blocks resident per CU: LDS (160 KiB) and ~2 waves/SIMD of these register-heavy kernels
-        int bpc = std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, 8 / waves));
+        int bpc = std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, (c.TAPS == 18 ? 12 : 8) / waves));
         bpc = std::max(bpc, 1);
         const double block_macs_per_chunk = (double)(c.WM * c.MR * 16) * (c.WN * c.NR * 16) * c.CK * c.TAPS;   // MFMA work (Winograd: 16 positions x 16 tiles)
         if (g->out_tiles) {
@@ -1056,7 +1067,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             double cycles = per_cu_blocks * block_macs_per_chunk * cps / std::max(rate, 1.0);
             cycles += 3000.0 * rounds;            // prologue/epilogue per block round
             if (c.TAPS == 16) cycles *= 1.3;      // transforms + 1.5 LDS reads per MFMA: measured, not modelled
-            if (c.TAPS == 17) cycles *= 0.8;      // 32x32x2 form: fewer MFMAs on upsampled operands, lighter issue stream
+            if (c.TAPS >= 17) cycles *= 0.8;      // 32x32x2 forms: fewer MFMAs on upsampled operands, lighter issue stream
             if (ks_eff > 1) cycles += 6000.0;     // reduce pass launch
             if (cycles < best) {
                 best = cycles;
@@ -1468,9 +1479,10 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
                        4.0 * (pix * g->C1 / (a.up1 * a.up1) + pix * g->C2 + (double)a.Cin * taps * g->Cout + pix * g->Cout),
                        (hipStream_t)stream);
         if (c.TAPS == 16) prof.mfma(2.0 * a.Cin * 9 * g->Cout * pix / 2.25);
-        if (c.TAPS == 17) {   // 32x32x2 MFMAs of 4096 FLOP: per block (waves / 2) tile groups x chunks x K-steps x positions
+        if (c.TAPS >= 17) {   // 32x32x2 MFMAs of 4096 FLOP: per block its tile groups x chunks x K-steps x positions
             const int n_up = (wino32_pure(a, c.CK) && a.up1 == 2) ? a.C1 / c.CK : 0;
-            prof.mfma(4096.0 * grid.x * grid.y * (c.WN / 2) * (c.CK / 2) * (9.0 * n_up + 16.0 * (plan.nchunks - n_up)));
+            const int groups = c.TAPS == 17 ? c.WN / 2 : 1;
+            prof.mfma(4096.0 * grid.x * grid.y * groups * (c.CK / 2) * (9.0 * n_up + 16.0 * (plan.nchunks - n_up)));
         }
         c.launch(a, grid, (hipStream_t)stream);
     }

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         aoff[v] = e < 2 * CK * 64 ? (unsigned)(((size_t)cot * a.nci4 * 16 * 64 + (size_t)rem * 4) * 4) : kOOB;
     }
 
+    const int c_begin_dbg = LIST ? 0 : (int)blockIdx.z * a.chunks_per_split;
     // Chunk kinds: UP = CK channels of the upsampled x1, staged at low resolution (pure layers only); FULL = anything else.
     auto is_up = [&](int chunk) { return upl && (chunk + 1) * CK <= a.C1; };
     // wave-instructions per chunk and wave: pure layers move whole 64-dword runs (the tail lanes of the last one carry the
@@ -338,12 +339,18 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         return cs;
     };
     auto stage_weight_piece = [&](int chunk, float* bufp, int v) {
+#ifdef WMD_STAMPS
+        if ((a.dbg_mode & 4) && chunk > c_begin_dbg + 1) return;   // timing experiment: no weight traffic after the first two chunks (results wrong)
+#endif
         const unsigned soffA = (unsigned)chunk * (unsigned)(T::RUN * 4);
         const int e0 = wave * 64 + v * NT;   // first piece of this wave-instruction (a multiple of 64: inside one run)
         if (T::NAV * NT == 2 * CK * 64 || e0 < 2 * CK * 64)   // wave-uniform: whole wave-instructions only
             lds_dma16(rw, (lds_ptr_t)(bufp + T::B_FLOATS + (e0 / (CK * 64)) * T::RUN_LDS + (e0 % (CK * 64)) * 4), aoff[v], soffA);
     };
     auto stage_full_piece = [&](int chunk, float* bufp, int q, const ChunkSrc& cs) {
+#ifdef WMD_STAMPS
+        if ((a.dbg_mode & 8) && q < NPB_F && chunk > c_begin_dbg + 1) return;   // timing experiment: no patch traffic either
+#endif
         if (q < NPB_F) {
             if constexpr (!GENERIC) {
                 if (X4 && x4) {      // block-uniform: 64 lanes x 16 bytes = 256 consecutive dwords of the chunk's run per instruction
@@ -369,6 +376,9 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         }
     };
     auto stage_up_piece = [&](int chunk, float* bufp, int q) {
+#ifdef WMD_STAMPS
+        if ((a.dbg_mode & 8) && q < NPB_L && chunk > c_begin_dbg + 1) return;
+#endif
         if (q < NPB_L) {
             if (X4 && x4) {
                 if (q < NPL4 && ((q + 1) * NT * 4 <= CK * PSL || (wave * 64 + q * NT) * 4 < CK * PSL))
