@@ -1,9 +1,10 @@
 """Cycle stamps inside conv_wino32_kernel blocks (development aid; needs the -DWMD_STAMPS build of the library:
-tools/probes/build_stamps.sh -> tools/probes/_build/libwmd_hip_stamps.so, loaded through WMD_LIB_PATH).
+tools/probes/build_variant.sh stamps "-DWMD_STAMPS" wmd_conv_wino32 wmd_conv_fwd wmd_conv_wino32q
+-> tools/probes/_build/libwmd_stamps.so, loaded through WMD_LIB_PATH).
 
 For each (layer, configuration, ksplit): one launch with a debug buffer, then per phase the median / p10 / p90 cycles over
 the blocks, separately for the first wave of blocks (those that start within half a block time of the earliest) and the rest.
-usage: WMD_LIB_PATH=tools/probes/_build/libwmd_hip_stamps.so python tools/probes/stamps_probe.py [layer:cfg:ks ...]"""
+usage: WMD_LIB_PATH=tools/probes/_build/libwmd_stamps.so python tools/probes/stamps_probe.py [layer:cfg:ks ...]"""
 import ctypes as C
 import os
 import sys

@@ -76,8 +76,10 @@ struct Wg32Tile {
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 };
 
+// (the 4-wave blocks -- one slab pair -- carry 56 staging pieces per wave and tile next to their 128 accumulators: 299 registers, one
+//  wave per SIMD; asking for two made hipcc warn "desired occupancy 2, final 1" for code that is the same either way)
 template <int TH, int TW, int WCO, int WCI>
-__global__ __launch_bounds__(WCO* WCI * 128, 2) void conv_wgrad_wino32_kernel(const WgradKArgs a) {
+__global__ __launch_bounds__(WCO* WCI * 128, (WCO * WCI >= 4 ? 2 : 1)) void conv_wgrad_wino32_kernel(const WgradKArgs a) {
     using T = Wg32Tile<TH, TW, WCO, WCI>;
     constexpr int PW = T::PW, SA = T::SA, SB = T::SB, NPIX = T::NPIX, NW = T::NW;
     constexpr unsigned kOOB = 0x80000000u;
