@@ -276,7 +276,7 @@ def test_conv_block_sparse_every_winograd_configuration(dev, up, C1, C2, pad):
                 st = l.wmd_conv_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream)
                 if st == -3 and ks > 1:
                     continue
-                if quarter_family_declines(name, C1, C2, masked=True):
+                if quarter_family_declines(name, C1, C2, masked=True, up=up, promise=promise):
                     assert st == -3, name
                     continue
                 _lib.check(st, name)

@@ -140,7 +140,10 @@ def unpack_mask(gold, key):
     return np.unpackbits(gold["m|" + key])[:int(np.prod(shape))].reshape(shape)
 
 
-def quarter_family_declines(name, C1, C2, masked=False):
-    """conv_wino32q_kernel (round 5) takes pure, unmasked layers only -- every 8-channel chunk inside one source tensor; a forced
-    launch on anything else must return WMD_ERR_UNSUPPORTED (-3) instead of computing something."""
-    return name.startswith("conv_wino32q") and (masked or (C1 + C2) % 8 != 0 or (C2 > 0 and C1 % 8 != 0))
+def quarter_family_declines(name, C1, C2, masked=False, up=1, promise=1):
+    """conv_wino32q_kernel (round 5) takes pure layers only -- every 8-channel chunk inside one source tensor, and an input mask
+    over an upsampled operand only under the 2x2-constant promise (it has no generic gather); a forced launch on anything else
+    must return WMD_ERR_UNSUPPORTED (-3) instead of computing something."""
+    if not name.startswith("conv_wino32q"):
+        return False
+    return (C1 + C2) % 8 != 0 or (C2 > 0 and C1 % 8 != 0) or (masked and up == 2 and not promise)

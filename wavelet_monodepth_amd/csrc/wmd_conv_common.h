@@ -161,6 +161,8 @@ struct W32QTile {
 };
 template <int TH, int TW, int CK>
 void launch_wino32q(const ConvKArgs& a, dim3 grid, hipStream_t s);   // explicit instantiations: wmd_conv_wino32q_table.inc
+// quarter-position tile shapes with a LIST instantiation: the 8 x 16 list tile of wmd_mask_level_lists
+constexpr bool wino32q_has_list(int TH, int TW, int CK) { return CK == 8 && TH == 8 && TW == 16; }
 
 // conv_wino32_kernel's flattened-staging instantiation needs every chunk inside one source tensor, one full-resolution
 // geometry; an input mask must live on that geometry too (same-size x1, or an upsampled x1 under a 2x2-constant mask, whose

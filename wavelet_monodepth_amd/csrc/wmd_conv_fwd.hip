@@ -1015,10 +1015,16 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
         if (wino ? (taps != 9 || !g->wp_wino) : c.TAPS != taps) continue;
         if ((g->in_mask || g->out_mask) && !wino) continue;   // block-sparse execution lives in the Winograd kernels
         if (g->gate && wino) continue;                        // the output gate lives in the direct kernels (and the split-K reduce)
-        if (c.TAPS == 18 && (g->in_mask || g->out_mask || g->out_tiles || Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK)))
-            continue;                                         // quarter-position kernel: flattened staging of pure, unmasked layers only
-        if (g->out_tiles) {   // work-list form: the LIST instantiations of conv_wino32_kernel on the list's own tile shape
-            if (c.TAPS != 17 || c.TH != g->out_tile_h || c.TW != g->out_tile_w || !wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK)) continue;
+        if (c.TAPS == 18 && (Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK) || (g->in_mask && g->up1 == 2 && !g->in_mask_2x2)))
+            continue;                                         // quarter-position kernel: flattened staging of pure layers only (wino32_pure)
+        if (g->out_tiles) {   // work-list form: the LIST instantiations of the 32x32x2 kernels on the list's own tile shape
+            // (both families have one for 8 x 16 tiles: the quarter-position kernel unless WMD_LIST_FAMILY=17)
+            static const int list_family = env_int("WMD_LIST_FAMILY", 18);
+            const bool has17 = c.TAPS == 17 && wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK);
+            const bool has18 = c.TAPS == 18 && wino32q_has_list(c.TH, c.TW, c.CK);
+            if ((!has17 && !has18) || c.TH != g->out_tile_h || c.TW != g->out_tile_w) continue;
+            if (has17 && list_family == 18 && wino32q_has_list(c.TH, c.TW, c.CK) && force < 0) continue;   // its quarter twin follows in the table
+            if (has18 && list_family == 17 && force < 0) continue;
             if (Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK) || (g->in_mask && g->up1 == 2 && !g->in_mask_2x2)) continue;   // wino32_pure
         }
         if (force >= 0 && force != i) continue;
@@ -1447,7 +1453,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
         a.tile_list = g->out_tiles;
         a.tile_count = g->out_tile_count;
         a.ksmax = plan.ksplit;
-        a.list_slots = kNumCU * std::max(1, std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, 8 / (c.WM * c.WN))));
+        a.list_slots = kNumCU * std::max(1, std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, (c.TAPS == 18 ? 12 : 8) / (c.WM * c.WN))));
         a.y_final = g->y;
     }
     a.gate = g->gate;

@@ -50,18 +50,33 @@ __device__ __forceinline__ float q_act(float v, float slope) {
     else return v;
 }
 
-template <int TH, int TW, int CK>
+// MASKED: block-sparse execution (wmd_conv_args.in_mask / out_mask: the sparse decoders' levels) -- input positions outside in_mask
+//   gather the out-of-range offset (read 0), a tile without an out_mask pixel walks an empty chunk range and stores nothing, stored
+//   pixels outside out_mask are 0; dword staging only (the mask is per position).  LIST (with MASKED): the block's tile comes out of
+//   the per-frame work lists and the K split is chosen on the device (wmd_conv_args.out_tiles), as in conv_wino32_kernel.
+template <int TH, int TW, int CK, bool MASKED = false, bool LIST = false>
 __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a) {
     using T = W32QTile<TH, TW, CK>;
     constexpr int NT = T::NT, PWS = T::PWS, PSF = T::PSF, PWL = T::PWL, PSL = T::PSL, KW = T::KW, TXB = T::TXB;
-    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS + T::TAB_FLOATS];
+    static_assert(!LIST || MASKED, "the work-list form is a masked instantiation");
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS + T::TAB_FLOATS + 8];   // + one tile-activity flag per wave
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int qr = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's transformed row
 
     int t, by;
-    if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD
+    int ks_n = a.ksplit, cps = a.chunks_per_split;   // LIST: chosen below from the list's length
+    if constexpr (LIST) {
+        const int n_items = list_total(a.tile_count, a.B) * a.cob;
+        if ((int)blockIdx.x >= n_items) return;
+        list_ksplit(n_items, a.nchunks, a.ksmax, a.list_slots, ks_n, cps);
+        if ((int)blockIdx.z >= ks_n) return;
+        const int item = xcd_contiguous(blockIdx.x, n_items);
+        const int ti = item / a.cob;
+        by = item - ti * a.cob;
+        t = list_entry(a.tile_list, a.tile_count, a.B, a.tiles_x * a.tiles_y, ti);
+    } else if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD
         const int item = xcd_contiguous(blockIdx.x, gridDim.x);
         t = item / a.cob;
         by = item - t * a.cob;
@@ -77,6 +92,21 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
     const int ks = blockIdx.z;
     const int H = a.H, W = a.W;
     const bool upl = a.up1 == 2;   // structured low-resolution path of the upsampled operand
+    // block-sparse: a tile without active output pixels keeps its zeros (empty chunk range + no stores; see conv_wino32_kernel for
+    // why not an early return)
+    bool skip = false;
+    if (MASKED && !LIST && a.out_mask) {
+        int any = 0;
+        for (int i = tid; i < TH * TW; i += NT) {
+            const int yy = y0 + i / TW, xx = x0 + i % TW;
+            if (yy < H && xx < W) any |= a.out_mask[(size_t)b * H * W + (size_t)yy * W + xx];
+        }
+        int* flags = reinterpret_cast<int*>(lds + T::LDS_FLOATS + T::TAB_FLOATS);
+        const bool wave_any = __builtin_amdgcn_ballot_w64(any != 0) != 0;
+        if (lane == 0) flags[qr] = wave_any ? 1 : 0;
+        __syncthreads();
+        skip = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) == 0;
+    }
 
     // ---- staging geometry (as conv_wino32_kernel's flattened staging) ------------------------------------------------
     constexpr unsigned kOOB = 0x80000000u;
@@ -90,7 +120,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
         return min(max(r, 0), n - 1);
     };
     constexpr int NPF = (CK * PSF + NT - 1) / NT, NPL = (CK * PSL + NT - 1) / NT;
-    constexpr bool X4 = T::X4OK;
+    constexpr bool X4 = T::X4OK && !MASKED;
     constexpr int NPF4 = (CK * PSF / 4 + NT - 1) / NT, NPL4 = (CK * PSL / 4 + NT - 1) / NT;
     bool x4 = false;
     unsigned obF[NPF], obL[NPL];
@@ -142,7 +172,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
             const unsigned e = tid + i * NT, ch = e / PSF, pos = e - __umul24(ch, PSF);
             const unsigned py = pos / PWS, px = pos - __umul24(py, PWS);
             const int r = tab[py], c = tab[PH + px];
-            const bool ok = ch < CK && (r | c) >= 0;
+            bool ok = ch < CK && (r | c) >= 0;
+            // the full-resolution geometry is the mask's own (pure layers): the folded pixel offset indexes it directly
+            if (MASKED && a.in_mask && ok) ok = a.in_mask[(size_t)b * plane2 + ((unsigned)(r + c) >> 2)] != 0;
             obF[i] = ok ? ch * pbs + (unsigned)(r + c) : kOOB;
         }
 #pragma unroll
@@ -150,7 +182,11 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
             const unsigned e = tid + i * NT, ch = e / PSL, pos = e - __umul24(ch, PSL);
             const unsigned py = pos / PWL, px = pos - __umul24(py, PWL);
             const int r = tab[PH + PWS + py], c = tab[PH + PWS + PHL + px];
-            const bool ok = ch < CK && (r | c) >= 0;
+            bool ok = ch < CK && (r | c) >= 0;
+            if (MASKED && a.in_mask && upl && ok) {   // 2x2-constant mask: source pixel (sy, sx) is masked like (2 sy, 2 sx)
+                const unsigned sidx = (unsigned)(r + c) >> 2, sy = sidx / (unsigned)a.W1, sx = sidx - sy * (unsigned)a.W1;
+                ok = a.in_mask[(size_t)b * plane2 + (size_t)(2 * sy) * W + 2 * sx] != 0;
+            }
             obL[i] = ok ? ch * pb1 + (unsigned)(r + c) : kOOB;
         }
     }
@@ -220,9 +256,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
         }
     };
 
-    const int cps = a.chunks_per_split;
     const int c_begin = ks * cps;
-    const int c_end = min(c_begin + cps, a.nchunks);
+    const int c_end = skip ? c_begin : min(c_begin + cps, a.nchunks);
     if (c_begin < c_end) {
         if (is_up(c_begin)) {
             q_static_for<NPL + T::NAV>([&](auto qc) { stage_up_piece(c_begin, lds, decltype(qc)::value); });
@@ -393,8 +428,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
             }
         __syncthreads();   // every quarter has read what it needs: the exchange area is free for the output transposes
 
-        const bool final_out = (a.ksplit == 1);
-        float* ybase = a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
+        const bool final_out = (ks_n == 1);
+        float* ybase = (LIST && final_out) ? a.y_final + (size_t)b * a.Cout * plane2 : a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
         const bool vec_ok = (W & 3) == 0;
         // lane (co = l & 31, h = l >> 5) holds, for q2 = 0, 1 and r = 0..3: tile slot 8 (2 (R & 1) + q2) + 4 h + r, output row A,
         // 2 pixels.  16 slots x 2 pixels x 32 channels = 4 KB per wave: [co][8 pieces of two tiles] through the wave's own
@@ -423,11 +458,16 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
                 const int ts = 16 * (R & 1) + 2 * pc;
                 const int oy = y0 + (ts / TXB) * 2 + A, ox = x0 + (ts % TXB) * 2;
                 const int cg = by * 32 + cc;
-                if (cg < a.Cout && ts < T::NTILES && oy < H && ox < W) {
+                if (cg < a.Cout && ts < T::NTILES && oy < H && ox < W && !skip) {
                     float* dst = ybase + (size_t)cg * plane2 + (size_t)oy * W + ox;
-                    if (vec_ok) *reinterpret_cast<float4*>(dst) = v;
+                    float o[4] = {v.x, v.y, v.z, v.w};
+                    if (MASKED && a.out_mask) {   // branch-free: clamped byte loads + selects (elements past W are never stored)
+                        const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = mp[min(ox + e, W - 1)] ? o[e] : 0.f;
+                    }
+                    if (vec_ok) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     else {
-                        const float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (ox + e < W) dst[e] = o[e];
@@ -450,7 +490,14 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
 
 template <int TH, int TW, int CK>
 void launch_wino32q(const ConvKArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((conv_wino32q_kernel<TH, TW, CK>), grid, dim3(256), 0, s, a);
+    if constexpr (wino32q_has_list(TH, TW, CK)) {
+        if (a.tile_list) {
+            hipLaunchKernelGGL((conv_wino32q_kernel<TH, TW, CK, true, true>), grid, dim3(256), 0, s, a);
+            return;
+        }
+    }
+    if (a.in_mask || a.out_mask) hipLaunchKernelGGL((conv_wino32q_kernel<TH, TW, CK, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wino32q_kernel<TH, TW, CK>), grid, dim3(256), 0, s, a);
 }
 
 #define WMD_W32Q_INST(TH, TW, CK) template void launch_wino32q<TH, TW, CK>(const ConvKArgs&, dim3, hipStream_t);
