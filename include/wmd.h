@@ -370,6 +370,11 @@ typedef struct {
     float* sig_ll;
 } wmd_head_shiftsum_args;
 int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* args, void* stream);
+/* Round 5: the completions of up to three CONSECUTIVE levels (coarse to fine, each twice the size of the one before) in one launch --
+ * level k's synthesis output is level k+1's low-pass input (depth_decoder.py:164: yl = IDWT((yl, [yh])) feeds the next iteration), so
+ * levels[k > 0] carry yl = yl_out = NULL and take it from the chain; every level needs `out`.  Dense inference only (no yh_mask,
+ * range_keys or sigmoid outputs).  Same values as n_levels calls of wmd_head_shiftsum_fwd.                                      */
+int wmd_head_shiftsum_chain_fwd(const wmd_head_shiftsum_args* levels, int n_levels, void* stream);
 
 /* Single-launch inference form of a level's two high-frequency heads AND the Haar synthesis that consumes them
  * (depth_decoder.py:108-136,164-166): 1x1 -> LeakyReLU -> 3x3 (as tap-partials) -> sigmoid -> 2^(s-1)(sig+ - sig-)

@@ -456,6 +456,39 @@ def test_kitti_dense_decoder_graph_replay_and_grad_mode_paths_agree(dev):
             assert_close(a[k], b[k], 2e-6, "graph vs eager " + key_str(k))
 
 
+@pytest.mark.parametrize("hw", [(96, 160), (64, 64), (192, 640)])
+def test_chained_completion_of_levels_4_to_2_equals_the_per_level_launches(dev, hw, monkeypatch):
+    """Round 5: the dense decoder's inference forward completes levels 4, 3 and 2 in ONE launch (wmd_head_shiftsum_chain_fwd: a block
+    walks a 4 x 4 coarse tile down two levels through LDS) instead of three wmd_head_shiftsum_fwd launches.  Same arithmetic per
+    pixel: every output must be bit-identical, on maps whose coarsest level is not a multiple of the 4 x 4 tile, eager and replayed,
+    and equal to the oracle."""
+    import numpy as np
+    from wavelet_monodepth_amd import ops
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    H, W = hw
+    B = 2
+    dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=3).to(dev)
+    feats = kitti_feats(B, H, W, seed=5)
+    gf = [f.to(dev) for f in feats]
+    monkeypatch.setattr(ops, "_SHIFTSUM_CHAIN_MAX_PIXELS", 1 << 30)      # (the default switches it off for large batches)
+    assert ops.shiftsum_chain_supported([256, 128, 64], B * (H // 4) * (W // 4))
+    with torch.no_grad():
+        got = {k: v.clone() for k, v in dec(gf).items()}
+        dec.enable_graph(True)
+        for _ in range(2):
+            rep = dec(gf)
+        rep = {k: v.clone() for k, v in rep.items()}
+        dec.enable_graph(False)
+        monkeypatch.setattr(ops, "_SHIFTSUM_CHAIN", False)
+        want = dec(gf)
+        ref = R.kitti_wave_decoder(feats, {k: v.cpu() for k, v in dec.state_dict().items()})
+    assert set(got) == set(want) == set(ref)
+    for k in want:
+        assert torch.equal(got[k], want[k]), "%s: chained completion differs from the per-level launches" % key_str(k)
+        assert torch.equal(rep[k], want[k]), "%s: replayed chained completion differs" % key_str(k)
+        assert_close(got[k], ref[k], 1e-4, key_str(k))
+
+
 def test_config2_in_the_benchmarked_execution_mode_vs_oracle(dev):
     """Round-2 VERDICT: what bench.py times -- BASELINE config 2 at batch 12, hipGraph replay (the decoder's default graph
     mode), the COMMITTED tile choices preloaded -- held against the oracle: three sampled frames, every disparity map and

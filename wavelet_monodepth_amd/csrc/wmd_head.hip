@@ -408,6 +408,117 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
     }
 }
 
+// ---- the shift-sums of up to three consecutive levels in ONE launch (round 5, dense inference) ---------------------------------
+// Level k's synthesis output IS level k+1's low-pass input, pixel for pixel (out_k [2h,2w] = yl_{k+1}), so once the chained GEMM
+// kernels of all levels have written their tap-partial planes the three completions have no reason to be three graph nodes of
+// 7-10 us each (every one a launch of a few hundred small workgroups on its latency floor): a block takes a 4 x 4 tile of the
+// coarsest level, 16 threads finish it (nine-tap gathers, bias, sigmoid, combine, Haar butterfly) and leave the 8 x 8 low-pass
+// tile of the next level in LDS, 64 threads finish that one, 256 the third.  Same per-pixel arithmetic as head_shiftsum_kernel
+// (shared body below), same outputs per level.
+struct ShiftsumChainArgs {
+    wmd_head_shiftsum_args lv[3];
+    int n;
+};
+
+// one coefficient pixel of one level: gathers, bias, sigmoid, combine; -> yh[3] (stored), the low-pass value l (from yl_out's head,
+// a.yl or l_in) and the four synthesised values v (stored to out / disp when the level has them)
+__device__ __forceinline__ void shiftsum_pixel(const wmd_head_shiftsum_args& a, size_t b, int y, int x, bool have_l_in, float l_in, float (&v)[4]) {
+    const int H = a.H, W = a.W;
+    const size_t plane = (size_t)H * W, i = b * plane + (size_t)y * W + x;
+    int off[9];
+    float okf[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        int gy = y + t / 3 - 1, gx = x + t % 3 - 1;
+        const bool ok = pad_coord(gy, H, a.pad_mode) & pad_coord(gx, W, a.pad_mode);
+        gy = min(max(gy, 0), H - 1);
+        gx = min(max(gx, 0), W - 1);
+        off[t] = gy * W + gx;
+        okf[t] = ok ? 1.f : 0.f;
+    }
+    const float* tb = a.t + b * (a.yl_out ? 81 : 54) * plane;
+    float vp[27], vn[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        vp[k] = tb[(size_t)k * plane + off[k % 9]];
+        vn[k] = tb[(size_t)(27 + k) * plane + off[k % 9]];
+    }
+    float yh[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        float sp = a.bias_p ? a.bias_p[co] : 0.f, sn = a.bias_n ? a.bias_n[co] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            sp += okf[t] * vp[co * 9 + t];
+            sn += okf[t] * vn[co * 9 + t];
+        }
+        const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
+        yh[co] = a.scale * a1 - a.scale * a2;
+        a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
+    }
+    float l = have_l_in ? l_in : 0.f;
+    if (a.yl_out) {
+        float sl = a.bias_ll ? a.bias_ll[0] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) sl += okf[t] * tb[(size_t)(54 + t) * plane + off[t]];
+        l = a.scale_ll / (1.f + expf(-sl));
+        a.yl_out[i] = l;
+    } else if (!have_l_in && a.yl) {
+        l = a.yl[i];
+    }
+    v[0] = (l + yh[0] + yh[1] + yh[2]) * 0.5f;
+    v[1] = (l + yh[0] - yh[1] - yh[2]) * 0.5f;
+    v[2] = (l - yh[0] + yh[1] - yh[2]) * 0.5f;
+    v[3] = (l - yh[0] - yh[1] + yh[2]) * 0.5f;
+    if (a.out) {
+        const size_t dst = b * 4 * plane + (size_t)(2 * y) * (2 * W) + 2 * x;
+        *reinterpret_cast<float2*>(a.out + dst) = make_float2(v[0], v[1]);
+        *reinterpret_cast<float2*>(a.out + dst + 2 * W) = make_float2(v[2], v[3]);
+        if (a.disp) {
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = v[k] * a.disp_scale;
+                if (a.clamp01) d[k] = fminf(fmaxf(d[k], 0.f), 1.f);
+            }
+            *reinterpret_cast<float2*>(a.disp + dst) = make_float2(d[0], d[1]);
+            *reinterpret_cast<float2*>(a.disp + dst + 2 * W) = make_float2(d[2], d[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_shiftsum_chain_kernel(const ShiftsumChainArgs c) {
+    __shared__ float low[2][16 * 16];     // low-pass tiles handed from level k to level k + 1: 8 x 8, then 16 x 16
+    const int H0 = c.lv[0].H, W0 = c.lv[0].W;
+    const int tiles_x = (W0 + 3) / 4, tiles_y = (H0 + 3) / 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const size_t b = t / tiles_y;
+    const int tid = threadIdx.x;
+    for (int k = 0; k < c.n; ++k) {
+        const int side = 4 << k;                       // the tile's edge at level k
+        if (tid < side * side) {
+            const int py = tid / side, px = tid % side;
+            const int y = ty * side + py, x = tx * side + px;
+            if (y < c.lv[k].H && x < c.lv[k].W) {
+                float v[4];
+                shiftsum_pixel(c.lv[k], b, y, x, k > 0, k > 0 ? low[(k - 1) & 1][py * side + px] : 0.f, v);
+                if (k + 1 < c.n) {
+                    float* nl = low[k & 1];
+                    const int ns = side * 2;
+                    nl[(2 * py) * ns + 2 * px] = v[0];
+                    nl[(2 * py) * ns + 2 * px + 1] = v[1];
+                    nl[(2 * py + 1) * ns + 2 * px] = v[2];
+                    nl[(2 * py + 1) * ns + 2 * px + 1] = v[3];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static void head_plan(const wmd_head_args* g, int* tiles_x, int* tiles_y, int* csplit, int* cper) {
     *tiles_x = (g->W + HT_W - 1) / HT_W;
     *tiles_y = (g->H + HT_H - 1) / HT_H;
@@ -474,6 +585,34 @@ extern "C" int wmd_head3x3_fwd(const wmd_head_args* g, void* stream) {
     hipLaunchKernelGGL(head_finalize_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, *g,
                        g->workspace, csplit);
     return check_launch("head_finalize_kernel");
+}
+
+extern "C" int wmd_head_shiftsum_chain_fwd(const wmd_head_shiftsum_args* levels, int n_levels, void* stream) {
+    if (!levels || n_levels < 1 || n_levels > 3) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_chain_fwd: 1..3 levels (got %d)", n_levels);
+    ShiftsumChainArgs c;
+    c.n = n_levels;
+    for (int k = 0; k < n_levels; ++k) {
+        const wmd_head_shiftsum_args& g = levels[k];
+        if (!g.t || !g.yh || !g.out) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_chain_fwd: level %d: t, yh and out are required", k);
+        if (g.B != levels[0].B || g.H != (levels[0].H << k) || g.W != (levels[0].W << k))
+            return fail(WMD_ERR_BAD_SHAPE, "wmd_head_shiftsum_chain_fwd: level %d is %dx%dx%d, expected %dx%dx%d (each level doubles the one before)",
+                        k, g.B, g.H, g.W, levels[0].B, levels[0].H << k, levels[0].W << k);
+        if (g.pad_mode < 0 || g.pad_mode > 2) return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_chain_fwd: pad_mode=%d", g.pad_mode);
+        if (g.pad_mode == WMD_PAD_REFLECT && (g.H < 2 || g.W < 2)) return fail(WMD_ERR_BAD_SHAPE, "wmd_head_shiftsum_chain_fwd: reflect padding needs H,W >= 2");
+        if (g.yh_mask || g.range_keys || g.sig_p || g.sig_n || g.sig_ll)
+            return fail(WMD_ERR_UNSUPPORTED, "wmd_head_shiftsum_chain_fwd: dense inference only (no yh_mask / range_keys / sigmoid outputs)");
+        if (k == 0 ? ((g.yl != nullptr) == (g.yl_out != nullptr)) : (g.yl != nullptr || g.yl_out != nullptr))
+            return fail(WMD_ERR_BAD_ARG, "wmd_head_shiftsum_chain_fwd: the first level takes exactly one of yl / yl_out, the others take the chain's low-pass");
+        c.lv[k] = g;
+    }
+    for (int k = n_levels; k < 3; ++k) c.lv[k] = levels[0];
+    const int tiles = ((levels[0].W + 3) / 4) * ((levels[0].H + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    double n = 0;
+    for (int k = 0; k < n_levels; ++k) n += (double)levels[k].B * levels[k].H * levels[k].W;
+    ProfScope prof("head_shiftsum_chain_kernel", 60.0 * n, 4.0 * n * 66, s);
+    hipLaunchKernelGGL(head_shiftsum_chain_kernel, dim3((unsigned)(levels[0].B * tiles)), dim3(256), 0, s, c);
+    return check_launch("head_shiftsum_chain_kernel");
 }
 
 extern "C" int wmd_head_shiftsum_fwd(const wmd_head_shiftsum_args* g, void* stream) {

@@ -281,6 +281,13 @@ class DepthWaveProgressiveDecoder(nn.Module):
         elu = ("elu", 0.0) if (torch.is_grad_enabled() and gated_backward_allowed(self)) else None
         self._gated = elu is not None
         edge = getattr(self, "_edge", None)
+        # dense inference: levels 4..2 launch only their chained GEMMs here, ONE launch after level 2's completes all three (round 5:
+        # level k's synthesis output is level k+1's low-pass input, pixel for pixel -- ops.head_shiftsum_chain_nograd)
+        chain = (not overlap) and (not torch.is_grad_enabled()) and self.fuse_heads and \
+            ops.shiftsum_chain_supported([int(self.num_ch_dec[k]) for k in (4, 3, 2)],
+                                         input_features[1].shape[0] * input_features[1].shape[2] * input_features[1].shape[3]) and \
+            bool(ops._lib.lib().wmd_head_level_supported(int(self.num_ch_dec[1])))
+        pending = []
         for i in range(4, 0, -1):
             if i == 4 and edge is not None:
                 x = self.convs[("upconv", 4, 0)](x, x1_pre=edge.pre())      # ReLU (+ affine) of the encoder's last block on load
@@ -288,6 +295,20 @@ class DepthWaveProgressiveDecoder(nn.Module):
                 x = self.convs[("upconv", i, 0)](x, x1_gate=elu if i < 4 else None, grad_is_dz=elu is not None)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip=skip, up=2, x1_gate=elu, grad_is_dz=elu is not None)  # fused upsample + concat
+            if chain and i >= 2:
+                hd = lambda j: (lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias))(self.convs[("waveconv", i, j)])
+                pending.append(ops.head_fused_gemm_nograd(x, hd(1), hd(-1), hd(0) if i == 4 else None))
+                if i == 2:
+                    done = ops.head_shiftsum_chain_nograd(pending, [2.0 ** (k - 1) for k in (4, 3, 2)], [1.0 / 2 ** (k - 1) for k in (4, 3, 2)],
+                                                          scale_ll=2.0 ** 4)
+                    for k, (yh, out, disp, yl_ll) in zip((4, 3, 2), done):
+                        self.outputs[("wavelets", k - 1, "LL")] = yl_ll if k == 4 else yl
+                        self.outputs[("wavelets", k - 1, "LH")] = yh[:, :, 0]
+                        self.outputs[("wavelets", k - 1, "HL")] = yh[:, :, 1]
+                        self.outputs[("wavelets", k - 1, "HH")] = yh[:, :, 2]
+                        self.outputs[("disp", k - 1)] = disp
+                        yl = out
+                continue
             if overlap:
                 keep.append(x)
                 x.record_stream(side)

@@ -949,6 +949,74 @@ def head_fused_level_nograd(x, head_p, head_n, scale, yl=None, disp_scale=None, 
     return yh.unsqueeze(1), out, disp
 
 
+_SHIFTSUM_CHAIN = os.environ.get("WMD_SHIFTSUM_CHAIN", "1") != "0"   # 0: one wmd_head_shiftsum_fwd launch per level
+# ... up to this many pixels at the finest chained level: the single launch removes two graph nodes from a latency-bound forward (one
+# frame 640x192: 0.221 -> 0.211 ms) but completes levels 4 and 3 from planes that have left the caches by then -- at batch 12
+# (92 160 pixels) the step measured 0.5 - 1 % slower with it (0.588 / 0.592 vs 0.585 / 0.584 ms medians, same box)
+_SHIFTSUM_CHAIN_MAX_PIXELS = int(os.environ.get("WMD_SHIFTSUM_CHAIN_MAX_PIXELS", "32768"))
+
+
+def shiftsum_chain_supported(widths, finest_pixels=0):
+    """Dense inference: can the levels of these head widths (coarse to fine) run as chained GEMM launches + ONE completion launch
+    (head_fused_gemm_nograd + head_shiftsum_chain_nograd)?  Every one must be a two-launch width (the one-launch kernel of C = 32
+    completes itself) and the coarsest low-pass head must ride in the C = 256 launch; finest_pixels = B*H*W of the last level
+    (the launch pays for latency-bound forwards only: _SHIFTSUM_CHAIN_MAX_PIXELS)."""
+    l = _lib.lib()
+    return (_SHIFTSUM_CHAIN and finest_pixels <= _SHIFTSUM_CHAIN_MAX_PIXELS and not _TWO_LAUNCH_HEAD and 1 <= len(widths) <= 3 and _LL_FOLD and _LL_MERGE and _HEAD_CHAIN_ON and
+            all(int(c) in (64, 128, 256) and not l.wmd_head_level_supported(int(c)) for c in widths) and int(widths[0]) == 256)
+
+
+def head_fused_gemm_nograd(x, head_p, head_n, head_ll=None):
+    """First launch of the two-launch head form alone (wmd_head_fused_fwd: 1x1 -> LeakyReLU -> tap-partial planes, the coarsest
+    level's low-pass chain riding along): -> what head_shiftsum_chain_nograd needs to complete the level later."""
+    l = _lib.lib()
+    x = _c(x)
+    B, Cc, H, W = x.shape
+    (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
+    wp1, bias1 = stacked_pack([w1p, w1n], [b1p, b1n])
+    wp2 = _tap_partial_pack(w3p, w3n)
+    planes = 81 if head_ll is not None else 54
+    t = torch.empty((B, planes, H, W), device=x.device, dtype=torch.float32)
+    a = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t),
+                           chain=0, t_planes=planes)
+    keep = [x, wp1, bias1, wp2]
+    b3l = None
+    if head_ll is not None:
+        w1l, b1l, w3l, b3l = head_ll
+        wpl1, wpl2 = _ll_chain_pack(w1l, w3l)
+        b1l_c = _c(b1l.detach())
+        a.ll_wp1, a.ll_bias1, a.ll_wp2 = ptr(wpl1), ptr(b1l_c), ptr(wpl2)
+        keep += [wpl1, wpl2, b1l_c]
+    check(l.wmd_head_fused_fwd(C.byref(a), current_stream()), "wmd_head_fused_fwd")
+    return dict(t=t, B=B, H=H, W=W, b3p=b3p, b3n=b3n, b3l=b3l, has_ll=head_ll is not None, keep=keep)
+
+
+def head_shiftsum_chain_nograd(items, scales, disp_scales, scale_ll=1.0, yl=None, clamp01=True):
+    """Completes up to three consecutive levels (coarse to fine; items from head_fused_gemm_nograd) in ONE launch
+    (wmd_head_shiftsum_chain_fwd): per level -> (yh [B,1,3,H,W], out [B,1,2H,2W], disp, yl_ll or None)."""
+    l = _lib.lib()
+    n = len(items)
+    arr = (_lib.HeadShiftsumArgs * n)()
+    res = []
+    for k, it in enumerate(items):
+        B, H, W = it["B"], it["H"], it["W"]
+        dev = it["t"].device
+        yh = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+        out = torch.empty((B, 1, 2 * H, 2 * W), device=dev, dtype=torch.float32)
+        disp = torch.empty_like(out)
+        yl_ll = torch.empty((B, 1, H, W), device=dev, dtype=torch.float32) if (k == 0 and it["has_ll"]) else None
+        if k == 0 and not it["has_ll"] and yl is None:
+            raise _lib.WmdError("head_shiftsum_chain_nograd: the first level needs its low-pass input (yl) or the low-pass head")
+        arr[k] = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scales[k]), t=ptr(it["t"]), bias_p=ptr(it["b3p"]),
+                                       bias_n=ptr(it["b3n"]), yh=ptr(yh), yl=ptr(_c(yl)) if (k == 0 and yl_ll is None) else None, out=ptr(out),
+                                       disp=ptr(disp), disp_scale=float(disp_scales[k]), clamp01=int(clamp01),
+                                       bias_ll=ptr(it["b3l"]) if yl_ll is not None else None, scale_ll=float(scale_ll),
+                                       yl_out=ptr(yl_ll))
+        res.append((yh.unsqueeze(1), out, disp, yl_ll))
+    check(l.wmd_head_shiftsum_chain_fwd(arr, n, current_stream()), "wmd_head_shiftsum_chain_fwd")
+    return res
+
+
 _TRAIN_FUSED = os.environ.get("WMD_TRAIN_FUSED_HEADS", "1") != "0"   # 0: training forward of the heads on _StackedHeadsFn + idwt_haar
 _HEAD_CHAIN_ON = os.environ.get("WMD_HEAD_CHAIN", "1") != "0"
 
