@@ -6,6 +6,53 @@
 namespace wmd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Column mix of the Winograd F(2x2,3x3) input transform, V = tr B, on register pairs: one v_pk_add_f32 with half selects per
+// output pair (the compiler does not fold a shuffle into op_sel for packed fp32 and would spend a v_mov per half).
+// a = (t0, t1), b = (t2, t3) of one transformed row:
+//   w32_pk_lo -> (t0 - t2, t1 + t2)      w32_pk_hi -> (t2 - t1, t1 - t3)
+// and for the rows of an upsampled operand (three source columns, a = (t0, t1)):  w32_pk_up -> (t0 - t1, t1 + t1).
+// Every result is the same IEEE operation the scalar form performs (a negated operand, a sum in the other order).
+// w32_pk_add / w32_pk_sub: plain pair sums, also as inline asm -- the compiler's post-RA peephole UNPACKS a v_pk_add_f32 that follows
+// an MFMA into two v_add_f32 (it assumes they hide in the MFMA's shadow; here they are what the matrix pipe waits for).
+// An MFMA must not read a VGPR in the two wait states after a VALU wrote it.  The compiler's hazard recognizer pads its own VALU
+// instructions (s_nop) but does not look into inline asm, and it is free to place an asm statement right in front of the MFMA that
+// consumes its result (seen: the last chunk of an all-upsampled layer, conv_wino32q_kernel, wrong sums).  The column-mix helpers --
+// the ones whose results are MFMA operands -- therefore carry their own s_nop 1 (two cycles against 64 per MFMA).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ f32x2 w32_pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_lo(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_hi(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_up(f32x2 a) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,0]\n\ts_nop 1" : "=v"(r) : "v"(a));
+    return r;
+}
+#else
+__device__ __forceinline__ f32x2 w32_pk_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 w32_pk_sub(f32x2 a, f32x2 b) { return a - b; }
+__device__ __forceinline__ f32x2 w32_pk_lo(f32x2 a, f32x2 b) { return f32x2{a[0] - b[0], a[1] + b[0]}; }
+__device__ __forceinline__ f32x2 w32_pk_hi(f32x2 a, f32x2 b) { return f32x2{b[0] - a[1], a[1] - b[1]}; }
+__device__ __forceinline__ f32x2 w32_pk_up(f32x2 a) { return f32x2{a[0] - a[1], a[1] + a[1]}; }
+#endif
 
 struct ConvKArgs {
     const float* x1;

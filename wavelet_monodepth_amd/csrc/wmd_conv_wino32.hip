@@ -28,7 +28,6 @@
 namespace wmd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // compile-time loop: f(integral_constant<int, I>) for I = 0 .. N-1, expanded by the front end (a `#pragma unroll` loop over
 // the MFMA groups with the piece test inside exceeds the optimizer's full-unroll budget, and a rolled loop would index the
@@ -320,7 +319,9 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         aoff[v] = e < 2 * CK * 64 ? (unsigned)(((size_t)cot * a.nci4 * 16 * 64 + (size_t)rem * 4) * 4) : kOOB;
     }
 
+#ifdef WMD_STAMPS
     const int c_begin_dbg = LIST ? 0 : (int)blockIdx.z * a.chunks_per_split;
+#endif
     // Chunk kinds: UP = CK channels of the upsampled x1, staged at low resolution (pure layers only); FULL = anything else.
     auto is_up = [&](int chunk) { return upl && (chunk + 1) * CK <= a.C1; };
     // wave-instructions per chunk and wave: pure layers move whole 64-dword runs (the tail lanes of the last one carry the
@@ -444,52 +445,66 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             const float* wsrc = bufp + wbase;
             ChunkSrc csn;
             if constexpr (NEXT == 1) csn = chunk_src(c + 1);
-            float d[16], tr[16], v[2][16], wf[RS];
+            // The input transform in packed fp32 (v_pk_add_f32, two adds per lane per instruction): fp32 MFMA and the vector ALU are
+            // the same hardware, every VALU instruction between two MFMAs comes out of the matrix rate
+            // (tools/probes/mfma32_issue_probe.hip: one packed add costs what one plain add costs).  Pairs run along patch columns.
+            //   FULL: dp[2 r + h] = (d[r][2h], d[r][2h+1]) straight from the 8-byte LDS reads; rows mix as whole pairs, the
+            //         column mix of a row is two instructions with half selects (w32_pk_*), owned pairs only
+            //   UP:   the 3x3 source pixels; pairs (d[r][0], d[r][1]) + the third column as scalars
+            f32x2 dp[8], tp[8], vp[2][8];
+            float d2[3], wf[RS];
             auto fetch_patch = [&](int kk) {   // elements no owned position depends on are dropped by the compiler
                 if constexpr (UP) {
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) d[e] = psrc[kk * 2 * PSL + (e / 3) * PWL + (e % 3)];
+                    for (int r = 0; r < 3; ++r) {
+                        const float* pr = psrc + kk * 2 * PSL + r * PWL;
+                        dp[r] = f32x2{pr[0], pr[1]};
+                        d2[r] = pr[2];
+                    }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const f32x2 pr = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + (e >> 1) * PWS + (e & 1) * 2);
-                        d[2 * e] = pr[0];
-                        d[2 * e + 1] = pr[1];
-                    }
+                    for (int e = 0; e < 8; ++e)
+                        dp[e] = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + (e >> 1) * PWS + (e & 1) * 2);
                 }
             };
-            auto transform_rows = [&]() {   // tr = B^T d  (UP: the three non-zero rows from the 3x3 source pixels)
+            auto transform_rows = [&]() {   // tr = B^T d  (UP: rows 0, 1, 3 from the 3x3 source pixels, whichever the half uses)
                 if constexpr (UP) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        tr[0 * 4 + j] = d[0 * 3 + j] - d[1 * 3 + j];
-                        tr[1 * 4 + j] = d[1 * 3 + j] + d[1 * 3 + j];
-                        tr[3 * 4 + j] = d[1 * 3 + j] - d[2 * 3 + j];
+                    if constexpr (HF == 0) {
+                        tp[0] = w32_pk_sub(dp[0], dp[1]);  // tr[0][0..1]
+                        tp[1] = w32_pk_add(dp[1], dp[1]);  // tr[1][0..1]
+                        tp[2][0] = d2[0] - d2[1];         // tr[0][2]
+                    } else {
+                        tp[0] = w32_pk_sub(dp[1], dp[2]);  // tr[3][0..1]
+                        tp[1][0] = dp[1][1] - d2[1];      // (tr[1][1] - tr[1][2]) / 2
+                        tp[2][0] = d2[1] - d2[2];         // tr[3][2]
                     }
                 } else {
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        tr[0 * 4 + cc] = d[0 * 4 + cc] - d[2 * 4 + cc];
-                        tr[1 * 4 + cc] = d[1 * 4 + cc] + d[2 * 4 + cc];
-                        tr[2 * 4 + cc] = d[2 * 4 + cc] - d[1 * 4 + cc];
-                        tr[3 * 4 + cc] = d[1 * 4 + cc] - d[3 * 4 + cc];
+                    for (int h = 0; h < 2; ++h) {
+                        tp[0 + h] = w32_pk_sub(dp[0 + h], dp[4 + h]);
+                        tp[2 + h] = w32_pk_add(dp[2 + h], dp[4 + h]);
+                        tp[4 + h] = w32_pk_sub(dp[4 + h], dp[2 + h]);
+                        tp[6 + h] = w32_pk_sub(dp[2 + h], dp[6 + h]);
                     }
                 }
             };
-            auto transform_cols = [&](int kk) {   // V = tr B, owned positions only
-                float* vv = v[kk & 1];
+            auto transform_cols = [&](int kk) {   // V = tr B, owned positions only; position 4 r + c is vp[..][2 r + c / 2][c % 2]
+                f32x2* vv = vp[kk & 1];
+                if constexpr (UP) {
+                    if constexpr (HF == 0) {   // (0,0) (0,1) (0,3) (1,0) (1,1)
+                        vv[0] = w32_pk_up(tp[0]);
+                        vv[1][1] = tp[0][1] - tp[2][0];
+                        vv[2] = w32_pk_up(tp[1]);
+                    } else {                   // (1,3) (3,0) (3,1) (3,3)
+                        vv[3][1] = tp[1][0] + tp[1][0];
+                        vv[6] = w32_pk_up(tp[0]);
+                        vv[7][1] = tp[0][1] - tp[2][0];
+                    }
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (UP && r == 2) continue;
-                    if constexpr (UP) {   // tr columns 0,1,2 hold source columns 0,1,2 (patch columns 0, 1 = 2, 3)
-                        if (w32_owns(HF, r * 4 + 0)) vv[r * 4 + 0] = tr[r * 4 + 0] - tr[r * 4 + 1];
-                        if (w32_owns(HF, r * 4 + 1)) vv[r * 4 + 1] = tr[r * 4 + 1] + tr[r * 4 + 1];
-                        if (w32_owns(HF, r * 4 + 3)) vv[r * 4 + 3] = tr[r * 4 + 1] - tr[r * 4 + 2];
-                    } else {
-                        if (w32_owns(HF, r * 4 + 0)) vv[r * 4 + 0] = tr[r * 4 + 0] - tr[r * 4 + 2];
-                        if (w32_owns(HF, r * 4 + 1)) vv[r * 4 + 1] = tr[r * 4 + 1] + tr[r * 4 + 2];
-                        if (w32_owns(HF, r * 4 + 2)) vv[r * 4 + 2] = tr[r * 4 + 2] - tr[r * 4 + 1];
-                        if (w32_owns(HF, r * 4 + 3)) vv[r * 4 + 3] = tr[r * 4 + 1] - tr[r * 4 + 3];
+                    for (int r = 0; r < 4; ++r) {
+                        if (w32_owns(HF, r * 4 + 0)) vv[2 * r] = w32_pk_lo(tp[2 * r], tp[2 * r + 1]);
+                        if (w32_owns(HF, r * 4 + 2)) vv[2 * r + 1] = w32_pk_hi(tp[2 * r], tp[2 * r + 1]);
                     }
                 }
             };
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
                     });
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[w32_slot(HF, xi)] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[kk & 1][xi], wf[s2 % RS], acc[w32_slot(HF, xi)], 0, 0, 0);
+                acc[w32_slot(HF, xi)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[kk & 1][xi >> 1][xi & 1], wf[s2 % RS], acc[w32_slot(HF, xi)], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
             __syncthreads();   // next buffer landed (vmcnt(0) precedes the barrier), this one is released

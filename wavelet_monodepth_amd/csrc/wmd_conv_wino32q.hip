@@ -27,7 +27,6 @@
 namespace wmd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <class F, int... I>
 __device__ __forceinline__ void q_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -311,48 +310,50 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
                     else if constexpr (NEXT == 1) stage_full_piece(c + 1, nbufp, q, csn);
                 });
             } else {
-                float da[4], db[4], tr[4], v[2][4], wf[RS];
+                // packed fp32 like conv_wino32_kernel (wmd_conv_common.h, w32_pk_*): pairs along patch columns
+                f32x2 pa[2], pb[2], vp[2][2];
+                float ca = 0.f, cb = 0.f, wf[RS];   // UP: the third source column
                 auto fetch_patch = [&](int kk) {
 #ifdef WMD_STAMPS
                     if ((a.dbg_mode & 64) && kk > 0) return;   // timing experiment: no patch reads after the first K-step
 #endif
                     if constexpr (UP) {
-#pragma unroll
-                        for (int e = 0; e < 3; ++e) {
-                            da[e] = psrc[kk * 2 * PSL + LA * PWL + e];
-                            db[e] = psrc[kk * 2 * PSL + LB * PWL + e];
+                        const float* ra = psrc + kk * 2 * PSL + LA * PWL;
+                        const float* rb = psrc + kk * 2 * PSL + LB * PWL;
+                        pa[0] = f32x2{ra[0], ra[1]};
+                        ca = ra[2];
+                        if constexpr (R != 1) {
+                            pb[0] = f32x2{rb[0], rb[1]};
+                            cb = rb[2];
                         }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const f32x2 pa = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + RA * PWS + e * 2);
-                            const f32x2 pb = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + RB * PWS + e * 2);
-                            da[2 * e] = pa[0], da[2 * e + 1] = pa[1];
-                            db[2 * e] = pb[0], db[2 * e + 1] = pb[1];
+                            pa[e] = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + RA * PWS + e * 2);
+                            pb[e] = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + RB * PWS + e * 2);
                         }
                     }
                 };
                 auto transform = [&](int kk) {   // tr = row R of B^T d, then V = tr B on the columns the operand reaches
-                    float* vv = v[kk & 1];
+                    f32x2* vv = vp[kk & 1];      // column c is vv[c / 2][c % 2]
 #ifdef WMD_STAMPS
                     if (a.dbg_mode & 16) {   // timing experiment: no transform arithmetic (results wrong)
-                        vv[0] = da[0], vv[1] = da[1], vv[2] = db[0], vv[3] = db[1];
+                        vv[0] = pa[0], vv[1] = pb[0];
                         return;
                     }
 #endif
                     if constexpr (UP) {
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) tr[j] = R == 1 ? da[j] + da[j] : da[j] - db[j];
-                        vv[0] = tr[0] - tr[1];
-                        vv[1] = tr[1] + tr[1];
-                        vv[3] = tr[1] - tr[2];
+                        const f32x2 t01 = R == 1 ? w32_pk_add(pa[0], pa[0]) : w32_pk_sub(pa[0], pb[0]);
+                        const float t2 = R == 1 ? ca + ca : ca - cb;
+                        vv[0] = w32_pk_up(t01);
+                        vv[1][1] = t01[1] - t2;
                     } else {
+                        f32x2 t[2];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) tr[j] = R == 0 ? da[j] - db[j] : (R == 1 ? da[j] + db[j] : (R == 2 ? db[j] - da[j] : da[j] - db[j]));
-                        vv[0] = tr[0] - tr[2];
-                        vv[1] = tr[1] + tr[2];
-                        vv[2] = tr[2] - tr[1];
-                        vv[3] = tr[1] - tr[3];
+                        for (int e = 0; e < 2; ++e)
+                            t[e] = R == 1 ? w32_pk_add(pa[e], pb[e]) : (R == 2 ? w32_pk_sub(pb[e], pa[e]) : w32_pk_sub(pa[e], pb[e]));
+                        vv[0] = w32_pk_lo(t[0], t[1]);
+                        vv[1] = w32_pk_hi(t[0], t[1]);
                     }
                 };
                 auto fetch_u = [&](int s2) {
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
                         });
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[col] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[kk & 1][col], wf[s2 % RS], acc[col], 0, 0, 0);
+                    acc[col] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[kk & 1][col >> 1][col & 1], wf[s2 % RS], acc[col], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
