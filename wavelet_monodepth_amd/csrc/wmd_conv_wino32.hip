@@ -451,20 +451,26 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             //   FULL: dp[2 r + h] = (d[r][2h], d[r][2h+1]) straight from the 8-byte LDS reads; rows mix as whole pairs, the
             //         column mix of a row is two instructions with half selects (w32_pk_*), owned pairs only
             //   UP:   the 3x3 source pixels; pairs (d[r][0], d[r][1]) + the third column as scalars
+            // volatile LDS-space reads: one ds_read with an immediate offset each.  Left alone the compiler pairs them into
+            // ds_read2 forms whose 8-bit offsets do not reach a K-step's rows and spends a v_add_u32 per pair on a new base --
+            // and a VALU instruction costs the matrix pipe several times what a second ds_read does (mainloop_replica_probe).
+            typedef const volatile __attribute__((address_space(3))) float* lds_cv1_t;
+            typedef const volatile __attribute__((address_space(3))) f32x2* lds_cv2_t;
+            const lds_cv1_t psrc3 = (lds_cv1_t)psrc;
             f32x2 dp[8], tp[8], vp[2][8];
             float d2[3], wf[RS];
-            auto fetch_patch = [&](int kk) {   // elements no owned position depends on are dropped by the compiler
-                if constexpr (UP) {
+            auto fetch_patch = [&](int kk) {   // only the rows this half's positions depend on (a volatile read is never dropped)
+                if constexpr (UP) {   // half 0: source rows 0, 1; half 1: rows 1, 2
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const float* pr = psrc + kk * 2 * PSL + r * PWL;
+                    for (int r = HF; r < HF + 2; ++r) {
+                        const lds_cv1_t pr = psrc3 + kk * 2 * PSL + r * PWL;
                         dp[r] = f32x2{pr[0], pr[1]};
                         d2[r] = pr[2];
                     }
-                } else {
+                } else {              // half 0: patch rows 0, 1, 2; half 1: rows 1, 2, 3
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        dp[e] = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + (e >> 1) * PWS + (e & 1) * 2);
+                    for (int e = 2 * HF; e < 2 * HF + 6; ++e)
+                        dp[e] = *reinterpret_cast<lds_cv2_t>(psrc3 + kk * 2 * PSF + (e >> 1) * PWS + (e & 1) * 2);
                 }
             };
             auto transform_rows = [&]() {   // tr = B^T d  (UP: rows 0, 1, 3 from the 3x3 source pixels, whichever the half uses)
@@ -481,10 +487,10 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
                 } else {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        tp[0 + h] = w32_pk_sub(dp[0 + h], dp[4 + h]);
+                        if constexpr (HF == 0) tp[0 + h] = w32_pk_sub(dp[0 + h], dp[4 + h]);
                         tp[2 + h] = w32_pk_add(dp[2 + h], dp[4 + h]);
                         tp[4 + h] = w32_pk_sub(dp[4 + h], dp[2 + h]);
-                        tp[6 + h] = w32_pk_sub(dp[2 + h], dp[6 + h]);
+                        if constexpr (HF == 1) tp[6 + h] = w32_pk_sub(dp[2 + h], dp[6 + h]);
                     }
                 }
             };

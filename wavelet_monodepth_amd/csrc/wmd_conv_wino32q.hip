@@ -317,9 +317,14 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
 #ifdef WMD_STAMPS
                     if ((a.dbg_mode & 64) && kk > 0) return;   // timing experiment: no patch reads after the first K-step
 #endif
+                    // volatile LDS-space reads: one ds_read with an immediate offset each, no v_add_u32 for a ds_read2 base
+                    // (conv_wino32_kernel has the measurements)
+                    typedef const volatile __attribute__((address_space(3))) float* lds_cv1_t;
+                    typedef const volatile __attribute__((address_space(3))) f32x2* lds_cv2_t;
+                    const lds_cv1_t psrc3 = (lds_cv1_t)psrc;
                     if constexpr (UP) {
-                        const float* ra = psrc + kk * 2 * PSL + LA * PWL;
-                        const float* rb = psrc + kk * 2 * PSL + LB * PWL;
+                        const lds_cv1_t ra = psrc3 + kk * 2 * PSL + LA * PWL;
+                        const lds_cv1_t rb = psrc3 + kk * 2 * PSL + LB * PWL;
                         pa[0] = f32x2{ra[0], ra[1]};
                         ca = ra[2];
                         if constexpr (R != 1) {
@@ -329,8 +334,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
                     } else {
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            pa[e] = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + RA * PWS + e * 2);
-                            pb[e] = *reinterpret_cast<const f32x2*>(psrc + kk * 2 * PSF + RB * PWS + e * 2);
+                            pa[e] = *reinterpret_cast<lds_cv2_t>(psrc3 + kk * 2 * PSF + RA * PWS + e * 2);
+                            pb[e] = *reinterpret_cast<lds_cv2_t>(psrc3 + kk * 2 * PSF + RB * PWS + e * 2);
                         }
                     }
                 };
