@@ -8,6 +8,32 @@ namespace wmd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Epilogue activation of the 32x32x2 Winograd kernels, scalar and on register pairs (v_pk_add_f32 / v_pk_mul_f32 where the
+// operation is one; the exponentials and the selects stay per element).  One arithmetic for both so that every store path of
+// every instantiation (dense / masked / work-list) produces the same bits.  ELU through v_exp_f32: |error| <= 1.2e-7 absolute
+// (the cancellation in e^v - 1 near 0 costs RELATIVE accuracy of values that are themselves < 1e-3; the trunk's tolerance is
+// relative to the tensor's scale).
+template <int ACT>
+__device__ __forceinline__ float w32_act(float v, float slope) {
+    if constexpr (ACT == WMD_ACT_ELU) return v > 0.f ? v : __builtin_amdgcn_exp2f(v * 1.442695041f) - 1.f;
+    else if constexpr (ACT == WMD_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == WMD_ACT_SIGMOID) return 1.f / (1.f + __builtin_amdgcn_exp2f(v * -1.442695041f));
+    else return v;
+}
+template <int ACT>
+__device__ __forceinline__ f32x2 w32_act2(f32x2 v, float slope) {
+    if constexpr (ACT == WMD_ACT_ELU) {
+        const f32x2 t = v * 1.442695041f;
+        const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} - 1.f;
+        return f32x2{v[0] > 0.f ? v[0] : e[0], v[1] > 0.f ? v[1] : e[1]};
+    } else if constexpr (ACT == WMD_ACT_LEAKY) {
+        const f32x2 t = v * slope;
+        return f32x2{v[0] > 0.f ? v[0] : t[0], v[1] > 0.f ? v[1] : t[1]};
+    } else if constexpr (ACT == WMD_ACT_SIGMOID) {
+        return f32x2{w32_act<ACT>(v[0], slope), w32_act<ACT>(v[1], slope)};
+    } else return v;
+}
+
 // Column mix of the Winograd F(2x2,3x3) input transform, V = tr B, on register pairs: one v_pk_add_f32 with half selects per
 // output pair (the compiler does not fold a shuffle into op_sel for packed fp32 and would spend a v_mov per half).
 // a = (t0, t1), b = (t2, t3) of one transformed row:

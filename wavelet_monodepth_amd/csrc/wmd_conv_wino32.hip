@@ -72,17 +72,9 @@ __host__ __device__ constexpr int w32_slot(int hf, int xi) {   // accumulator in
 // A^T = [[1,1,1,0],[0,1,-1,-1]]
 __host__ __device__ constexpr int w32_at(int a, int r) { return a == 0 ? (r < 3 ? 1 : 0) : (r == 0 ? 0 : (r == 1 ? 1 : -1)); }
 
-// Activation with the kind as a compile-time constant: the epilogue selects ONE instantiation of its store loop per launch (a
-// run-time switch per element put ~100 scalar branches into every wave's epilogue: 12 k -> 5.5 k cycles on L14).  ELU goes
-// through v_exp_f32: |error| <= 1.2e-7 absolute (the cancellation in e^v - 1 near 0 costs RELATIVE accuracy of values that are
-// themselves < 1e-3; the trunk's tolerance is relative to the tensor's scale).
-template <int ACT>
-__device__ __forceinline__ float act_const(float v, float slope) {
-    if constexpr (ACT == WMD_ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
-    else if constexpr (ACT == WMD_ACT_LEAKY) return v > 0.f ? v : v * slope;
-    else if constexpr (ACT == WMD_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    else return v;
-}
+// Activation with the kind as a compile-time constant (w32_act / w32_act2, wmd_conv_common.h): the epilogue selects ONE instantiation
+// of its store loop per launch (a run-time switch per element put ~100 scalar branches into every wave's epilogue: 12 k -> 5.5 k
+// cycles on L14).
 
 // GENERIC = false: every chunk of CK channels lies inside one source tensor, no masks (every trunk layer of the decoders).
 //   The chunk's patch is staged as ONE flattened [channel][position] run: every LDS-DMA instruction moves 64 consecutive
@@ -574,83 +566,93 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         // Accumulator register g = 4q + r of lane l belongs to tile slot wn*32 + 8q + 4(l >> 5) + r and out channel l & 31.
         // Partial outputs of this half: Y[a][b] += A^T[a][r] A^T[b][c] M[r][c] over the owned (r, c).  Half hf keeps output
         // row a = hf and hands row 1 - hf to the other half: 32 values per lane through LDS (the staging buffers are free).
-        float keep[16][2], give[16][2];
+        // Everything on register pairs (g, g + 1) -- neighbouring accumulator registers of one position -- so that the sums are
+        // v_pk_add_f32: the epilogue's VALU instructions are paid by the SIMD's other wave like the main loop's (per tile and wave
+        // ~450 scalar instructions before, more than the main loop of a 12-chunk layer issues).  The row sums are factored
+        // (A^T's rows applied along c first): 12 packed sums per pair instead of 28 scalar ones.
+        f32x2 kp[8][2], gv[8][2];   // [g / 2][b]: kept row, given row
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            float y[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                if (!w32_owns(HF, xi)) continue;
-                const float m = acc[w32_slot(HF, xi)][g];
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) {
-                        const int cf = w32_at(aa, xi / 4) * w32_at(bb, xi % 4);
-                        if (cf > 0) y[aa][bb] += m;
-                        if (cf < 0) y[aa][bb] -= m;
-                    }
+        for (int gp = 0; gp < 8; ++gp) {
+            auto M = [&](int xi) { return f32x2{acc[w32_slot(HF, xi)][2 * gp], acc[w32_slot(HF, xi)][2 * gp + 1]}; };
+            if constexpr (HF == 0) {   // row 0 (all columns), (1,0) (1,1) (2,0) (2,1)
+                const f32x2 b0 = (M(0) + M(1)) + M(2), b1 = (M(1) - M(2)) - M(3);
+                const f32x2 p0 = M(4) + M(5), p1 = M(5), q0 = M(8) + M(9), q1 = M(9);
+                kp[gp][0] = (b0 + p0) + q0;   // Y[0][0]
+                kp[gp][1] = (b1 + p1) + q1;   // Y[0][1]
+                gv[gp][0] = p0 - q0;          // Y[1][0]
+                gv[gp][1] = p1 - q1;          // Y[1][1]
+            } else {                   // (1,2) (1,3) (2,2) (2,3), row 3 (all columns)
+                const f32x2 s1 = M(6) + M(7), s2 = M(10) + M(11);
+                const f32x2 b0 = (M(12) + M(13)) + M(14), b1 = (M(13) - M(14)) - M(15);
+                gv[gp][0] = M(6) + M(10);            // Y[0][0]
+                gv[gp][1] = -s1 - s2;                // Y[0][1]
+                kp[gp][0] = (M(6) - M(10)) - b0;     // Y[1][0]
+                kp[gp][1] = (s2 - s1) - b1;          // Y[1][1]
             }
-            keep[g][0] = y[HF][0];
-            keep[g][1] = y[HF][1];
-            give[g][0] = y[1 - HF][0];
-            give[g][1] = y[1 - HF][1];
         }
         WMD_STAMP(8);   // output transform
-        float* xch = lds + (size_t)wn * (2 * 32 * 64) + lane;   // [wn][sender half][value][lane]
+        float* xch = lds + (size_t)wn * (2 * 32 * 64) + lane * 2;   // [wn][sender half][pair j = 2 (g / 2) + b][lane][2]
 #pragma unroll
-        for (int e = 0; e < 32; ++e) xch[(HF * 32 + e) * 64] = give[e >> 1][e & 1];
+        for (int j = 0; j < 16; ++j) *reinterpret_cast<f32x2*>(xch + (HF * 16 + j) * 128) = gv[j >> 1][j & 1];
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 32; ++e) keep[e >> 1][e & 1] += xch[((1 - HF) * 32 + e) * 64];
+        for (int j = 0; j < 16; ++j) kp[j >> 1][j & 1] += *reinterpret_cast<const f32x2*>(xch + ((1 - HF) * 16 + j) * 128);
 
         WMD_STAMP(9);   // halves exchanged
         const bool final_out = (ks_n == 1);
         float* ybase = (LIST && final_out) ? a.y_final + (size_t)b * a.Cout * plane2 : a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
         const bool vec_ok = (W & 3) == 0;
-        auto store_rows = [&](auto act_tag) {   // ACT < 0: split-K partial sums (no bias, no activation)
+        const bool lines = !MASKED && a.st_coalesce != 0 && vec_ok;
+        // bias + activation in place (ACT < 0: split-K partial sums, neither), then one of the two store forms
+        auto finish = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
+            if constexpr (ACT >= 0) {
+                const f32x2 bias2 = f32x2{bias_v, bias_v};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tfirst = wn * 32 + 8 * q + 4 * (lane >> 5);
-                const int oy = y0 + (tfirst / TXB) * 2 + HF, ox = x0 + (tfirst % TXB) * 2;
-                if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W || skip) continue;
-                float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
-                float o[8];
+                for (int gp = 0; gp < 8; ++gp)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float yv = keep[4 * q + (e >> 1)][e & 1];
-                    o[e] = ACT < 0 ? yv : act_const<(ACT < 0 ? 0 : ACT)>(yv + bias_v, a.slope);
-                }
-                if (MASKED && a.out_mask) {   // branch-free: clamped byte loads + selects (elements past W are never stored)
-                    const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W;
-                    uint8_t mv[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) mv[e] = mp[min(ox + e, W - 1)];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = mv[e] ? o[e] : 0.f;
-                }
-#ifdef WMD_STAMPS
-                if ((a.dbg_mode & 1) && o[0] == o[0]) continue;
-#endif
-                if (vec_ok && ox + 7 < W) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (ox + e < W) dst[e] = o[e];
-                }
+                    for (int bb = 0; bb < 2; ++bb) kp[gp][bb] = w32_act2<(ACT < 0 ? 0 : ACT)>(kp[gp][bb] + bias2, a.slope);
             }
-        };
-        // Round 5: the kept output row leaves through whole 128-byte lines.  A lane holds 8-pixel runs of ONE out channel, so a
-        // store instruction of store_rows touches 64 different lines with 16 bytes each (cycle stamps: 4.2 k cycles from the
-        // exchange to the last store issued).  Here the wave first transposes its 32 channels x 32 tile slots x 2 pixels through the
-        // 8 KB of the exchange area only it has read ([co][16 pieces of two tiles], pieces XOR-swizzled by the channel so that the
-        // 8-lane write groups and the 16-lane read groups each cover distinct banks) and then stores [4 channels][256 bytes] per
-        // instruction.  LDS operations of one wave execute in order: no barrier.
-        auto store_lines = [&](auto act_tag) {
-            constexpr int ACT = decltype(act_tag)::value;
+            auto keep = [&](int g, int bb) { return kp[g >> 1][bb][g & 1]; };   // output value of accumulator register g, pixel bb
+            if (!lines) {
+                // a lane stores 8-pixel runs of ONE out channel (masked launches, widths that are not a multiple of 4)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tfirst = wn * 32 + 8 * q + 4 * (lane >> 5);
+                    const int oy = y0 + (tfirst / TXB) * 2 + HF, ox = x0 + (tfirst % TXB) * 2;
+                    if (co >= a.Cout || tfirst >= T::NTILES || oy >= H || ox >= W || skip) continue;
+                    float* dst = ybase + (size_t)co * plane2 + (size_t)oy * W + ox;
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = keep(4 * q + (e >> 1), e & 1);
+                    if (MASKED && a.out_mask) {   // branch-free: clamped byte loads + selects (elements past W are never stored)
+                        const uint8_t* mp = a.out_mask + (size_t)b * plane2 + (size_t)oy * W;
+                        uint8_t mv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) mv[e] = mp[min(ox + e, W - 1)];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = mv[e] ? o[e] : 0.f;
+                    }
+#ifdef WMD_STAMPS
+                    if ((a.dbg_mode & 1) && o[0] == o[0]) continue;
+#endif
+                    if (vec_ok && ox + 7 < W) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (ox + e < W) dst[e] = o[e];
+                    }
+                }
+                return;
+            }
+            // Round 5: the kept output row leaves through whole 128-byte lines.  A lane holds 8-pixel runs of ONE out channel, so a
+            // store instruction of the form above touches 64 different lines with 16 bytes each (cycle stamps: 4.2 k cycles from the
+            // exchange to the last store issued).  Here the wave first transposes its 32 channels x 32 tile slots x 2 pixels through the
+            // 8 KB of the exchange area only it has read ([co][16 pieces of two tiles], pieces XOR-swizzled by the channel so that the
+            // 8-lane write groups and the 16-lane read groups each cover distinct banks) and then stores [4 channels][256 bytes] per
+            // instruction.  LDS operations of one wave execute in order: no barrier.
             float* tb = lds + (size_t)wn * (2 * 32 * 64) + (size_t)(1 - HF) * (32 * 64);
             const int col = lane & 31, hh = lane >> 5;
             const int swz_w = ((col & 3) << 2) | ((col >> 2) & 3);
@@ -658,14 +660,8 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float yv = keep[4 * q + 2 * pr + (e >> 1)][e & 1];
-                        o[e] = ACT < 0 ? yv : act_const<(ACT < 0 ? 0 : ACT)>(yv + bias_v, a.slope);
-                    }
-                    const int pc = 4 * q + 2 * hh + pr;
-                    *reinterpret_cast<float4*>(tb + col * 64 + ((pc ^ swz_w) * 4)) = make_float4(o[0], o[1], o[2], o[3]);
+                    const int g = 4 * q + 2 * pr, pc = 4 * q + 2 * hh + pr;
+                    *reinterpret_cast<float4*>(tb + col * 64 + ((pc ^ swz_w) * 4)) = make_float4(keep(g, 0), keep(g, 1), keep(g + 1, 0), keep(g + 1, 1));
                 }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -682,22 +678,15 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
                     *reinterpret_cast<float4*>(ybase + (size_t)cg * plane2 + (size_t)oy * W + ox) = v;
             }
         };
-        const bool lines = !MASKED && a.st_coalesce != 0 && vec_ok;
         int act_sel = final_out ? a.act : -1;
 #ifdef WMD_STAMPS
         if ((a.dbg_mode & 2) && final_out) act_sel = WMD_ACT_NONE;
 #endif
-        if (lines) {
-            if (act_sel < 0) store_lines(std::integral_constant<int, -1>{});
-            else if (act_sel == WMD_ACT_ELU) store_lines(std::integral_constant<int, WMD_ACT_ELU>{});
-            else if (act_sel == WMD_ACT_LEAKY) store_lines(std::integral_constant<int, WMD_ACT_LEAKY>{});
-            else if (act_sel == WMD_ACT_SIGMOID) store_lines(std::integral_constant<int, WMD_ACT_SIGMOID>{});
-            else store_lines(std::integral_constant<int, WMD_ACT_NONE>{});
-        } else if (act_sel < 0) store_rows(std::integral_constant<int, -1>{});
-        else if (act_sel == WMD_ACT_ELU) store_rows(std::integral_constant<int, WMD_ACT_ELU>{});
-        else if (act_sel == WMD_ACT_LEAKY) store_rows(std::integral_constant<int, WMD_ACT_LEAKY>{});
-        else if (act_sel == WMD_ACT_SIGMOID) store_rows(std::integral_constant<int, WMD_ACT_SIGMOID>{});
-        else store_rows(std::integral_constant<int, WMD_ACT_NONE>{});
+        if (act_sel < 0) finish(std::integral_constant<int, -1>{});
+        else if (act_sel == WMD_ACT_ELU) finish(std::integral_constant<int, WMD_ACT_ELU>{});
+        else if (act_sel == WMD_ACT_LEAKY) finish(std::integral_constant<int, WMD_ACT_LEAKY>{});
+        else if (act_sel == WMD_ACT_SIGMOID) finish(std::integral_constant<int, WMD_ACT_SIGMOID>{});
+        else finish(std::integral_constant<int, WMD_ACT_NONE>{});
         WMD_STAMP(10);   // stores issued
 #ifdef WMD_STAMPS
         if (a.dbg && tid == 0) {

@@ -41,13 +41,6 @@ __device__ __forceinline__ void q_static_for(F&& f) {
 __host__ __device__ constexpr int q_count(int R, bool up) { return up ? (R == 2 ? 0 : 3) : 4; }
 __host__ __device__ constexpr int q_col(bool up, int p) { return up ? (p == 2 ? 3 : p) : p; }
 
-template <int ACT>
-__device__ __forceinline__ float q_act(float v, float slope) {
-    if constexpr (ACT == WMD_ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
-    else if constexpr (ACT == WMD_ACT_LEAKY) return v > 0.f ? v : v * slope;
-    else if constexpr (ACT == WMD_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    else return v;
-}
 
 // MASKED: block-sparse execution (wmd_conv_args.in_mask / out_mask: the sparse decoders' levels) -- input positions outside in_mask
 //   gather the out-of-range offset (read 0), a tile without an out_mask pixel walks an empty chunk range and stores nothing, stored
@@ -413,24 +406,24 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
 
         // ---- epilogue: P_R[g][b] = sum_c A^T[b][c] M[R][c] (A^T = [[1,1,1,0],[0,1,-1,-1]]), traded through LDS -----------------
         // accumulator register g = 4q + r of lane l: tile slot 8q + 4(l >> 5) + r, out channel l & 31
-        float* xch = lds + lane;   // [quarter][g][b][lane]: 4 x 32 x 64 floats = 32 KB of the (dead) staging buffers
+        // (on register pairs (g, g + 1), neighbouring accumulator registers: packed sums, 8-byte LDS traffic -- see conv_wino32_kernel)
+        float* xch = lds + lane * 2;   // [quarter][g / 2][b][lane][2]: 4 x 32 x 64 floats = 32 KB of the (dead) staging buffers
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float p0 = acc[0][g] + acc[1][g] + acc[2][g];
-            const float p1 = acc[1][g] - acc[2][g] - acc[3][g];
-            xch[((R * 16 + g) * 2 + 0) * 64] = p0;
-            xch[((R * 16 + g) * 2 + 1) * 64] = p1;
+        for (int gp = 0; gp < 8; ++gp) {
+            auto M = [&](int c) { return f32x2{acc[c][2 * gp], acc[c][2 * gp + 1]}; };
+            *reinterpret_cast<f32x2*>(xch + ((R * 8 + gp) * 2 + 0) * 128) = (M(0) + M(1)) + M(2);
+            *reinterpret_cast<f32x2*>(xch + ((R * 8 + gp) * 2 + 1) * 128) = (M(1) - M(2)) - M(3);
         }
         __syncthreads();
         // quarter R finishes output row A = R >> 1 of the tiles g in [8 (R & 1), +8): Y[0] = P0 + P1 + P2, Y[1] = P1 - P2 - P3
         constexpr int A = R >> 1, G0 = 8 * (R & 1);
-        float y[8][2];
+        f32x2 y2[4][2];   // [(g - G0) / 2][b]
 #pragma unroll
-        for (int gi = 0; gi < 8; ++gi)
+        for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                auto P = [&](int rr) { return xch[((rr * 16 + G0 + gi) * 2 + bb) * 64]; };
-                y[gi][bb] = A == 0 ? P(0) + P(1) + P(2) : P(1) - P(2) - P(3);
+                auto P = [&](int rr) { return *reinterpret_cast<const f32x2*>(xch + ((rr * 8 + G0 / 2 + gi) * 2 + bb) * 128); };
+                y2[gi][bb] = A == 0 ? (P(0) + P(1)) + P(2) : (P(1) - P(2)) - P(3);
             }
         __syncthreads();   // every quarter has read what it needs: the exchange area is free for the output transposes
 
@@ -448,14 +441,13 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
             for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float yv = y[4 * q2 + 2 * pr + (e >> 1)][e & 1];
-                        o[e] = ACT < 0 ? yv : q_act<(ACT < 0 ? 0 : ACT)>(yv + bias_v, a.slope);
+                    f32x2 o0 = y2[2 * q2 + pr][0], o1 = y2[2 * q2 + pr][1];   // pixels 0 / 1 of the slot pair
+                    if constexpr (ACT >= 0) {
+                        o0 = w32_act2<(ACT < 0 ? 0 : ACT)>(o0 + f32x2{bias_v, bias_v}, a.slope);
+                        o1 = w32_act2<(ACT < 0 ? 0 : ACT)>(o1 + f32x2{bias_v, bias_v}, a.slope);
                     }
                     const int pc = 4 * q2 + 2 * hh + pr;     // piece 0..7: slots 2 pc, 2 pc + 1 of this quarter's sixteen
-                    *reinterpret_cast<float4*>(tb + col * 32 + ((pc ^ (col & 7)) * 4)) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(tb + col * 32 + ((pc ^ (col & 7)) * 4)) = make_float4(o0[0], o1[0], o0[1], o1[1]);
                 }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
