@@ -72,12 +72,52 @@ __device__ __forceinline__ f32x2 w32_pk_up(f32x2 a) {
     asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,0]\n\ts_nop 1" : "=v"(r) : "v"(a));
     return r;
 }
+// Variants for the weight-gradient kernel (conv_wgrad_wino32_kernel), every one with its own s_nop 1 (all are MFMA operands):
+//   w32_pk_addn / w32_pk_subn: a + b, a - b          w32_pk_pm: (a.lo + a.hi, a.lo - a.hi)
+//   column mixes with the sign of some results flipped (the matching dM operand is used without ITS minus sign: the product is the same
+//   bits): w32_pk_hi_f -> (t2 - t1, t3 - t1),  w32_pk_lo_ff -> (t2 - t0, -t1 - t2),  w32_pk_hi_fl -> (t1 - t2, t1 - t3)
+__device__ __forceinline__ f32x2 w32_pk_addn(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_subn(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_pm(f32x2 a) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_hi_f(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_lo_ff(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 w32_pk_hi_fl(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 #else
 __device__ __forceinline__ f32x2 w32_pk_add(f32x2 a, f32x2 b) { return a + b; }
 __device__ __forceinline__ f32x2 w32_pk_sub(f32x2 a, f32x2 b) { return a - b; }
 __device__ __forceinline__ f32x2 w32_pk_lo(f32x2 a, f32x2 b) { return f32x2{a[0] - b[0], a[1] + b[0]}; }
 __device__ __forceinline__ f32x2 w32_pk_hi(f32x2 a, f32x2 b) { return f32x2{b[0] - a[1], a[1] - b[1]}; }
 __device__ __forceinline__ f32x2 w32_pk_up(f32x2 a) { return f32x2{a[0] - a[1], a[1] + a[1]}; }
+__device__ __forceinline__ f32x2 w32_pk_addn(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 w32_pk_subn(f32x2 a, f32x2 b) { return a - b; }
+__device__ __forceinline__ f32x2 w32_pk_pm(f32x2 a) { return f32x2{a[0] + a[1], a[0] - a[1]}; }
+__device__ __forceinline__ f32x2 w32_pk_hi_f(f32x2 a, f32x2 b) { return f32x2{b[0] - a[1], b[1] - a[1]}; }
+__device__ __forceinline__ f32x2 w32_pk_lo_ff(f32x2 a, f32x2 b) { return f32x2{b[0] - a[0], -a[1] - b[0]}; }
+__device__ __forceinline__ f32x2 w32_pk_hi_fl(f32x2 a, f32x2 b) { return f32x2{a[1] - b[0], a[1] - b[1]}; }
 #endif
 
 struct ConvKArgs {

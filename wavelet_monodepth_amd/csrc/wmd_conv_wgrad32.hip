@@ -7,7 +7,7 @@
 // rows and of the padded / upsampled / concatenated patch rows.  What changes is the work around the matrix pipe, as in
 // conv_wino32_kernel: a wave owns a 32 x 32 (out x in channel) block of dU for 8 of the 16 transformed positions (8 x 16
 // accumulator registers), the K index of the 32x32x2 MFMA walks two tiles of a row.  A lane holds one channel (l & 31) and
-// one tile (l >> 5) for both operands: 2 + 6 ds_read_b64 and ~26 adds feed 8 MFMAs of 64 cycles -- no weight fragments at
+// one tile (l >> 5) for both operands: 2 + 6 ds_read_b64 and 15 packed adds (round 5; ~33 scalar ones before) feed 8 MFMAs of 64 cycles -- no weight fragments at
 // all on this side -- against 36 reads + 76 adds per 32 MFMAs of 32 cycles in the 16x16x4 form, which runs at 25-36 % of the
 // pipe.  Block = WCO x WCI slabs x the two position halves; the halves of a slab pair share a SIMD.
 // For the 2x-upsampled operand B^T d B vanishes on transformed row 2 / column 2 (see conv_wino32_kernel): waves whose 32 input
@@ -20,7 +20,6 @@
 namespace wmd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <class F, int... I>
 __device__ __forceinline__ void wg_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -153,26 +152,33 @@ __global__ __launch_bounds__(WCO* WCI * 128, (WCO * WCI >= 4 ? 2 : 1)) void conv
         }
         return ts;
     };
-    // piece q of this wave's share of a tile: rows wave, wave + NW, ... of the dz block, then of the patch block
-    auto stage_piece = [&](const TileSrc& ts, float* bufA, int q) {
+    // piece q of this wave's share of a tile: rows wave, wave + NW, ... of the dz block, then of the patch block.
+    // A row beyond Cout / Cin is staged from the last valid channel instead of being zeroed per lane: it only feeds accumulator rows /
+    // columns (and bias sums) that are never stored.  `wave_t` is the wave index laundered once per tile: left to itself the compiler
+    // hoists every piece's scalar channel offset out of the tile loop, runs out of scalar registers and fetches them back with
+    // v_readlane -- vector-ALU instructions in the MFMA stream, four per piece.
+    // (Round 5 also built per-tile LDS tables of the folded patch rows / columns, filled by PH + PW threads two tiles ahead, in place of
+    //  every lane folding its own coordinates in tile_src: slower, 0.237 -> 0.246 ms per step for <2,40,2,2> -- the table reads sit
+    //  between a tile's barrier and its first LDS-DMA issue.)
+    auto stage_piece = [&](const TileSrc& ts, float* bufA, int q, int wave_t) {
         if (q < T::ROWS_A * T::PA) {
             const int j = q / T::PA, i = q % T::PA;
-            const int c = wave + j * NW, co = co0 + c;
+            const int c = wave_t + j * NW, co = co0 + c;
             const unsigned so = (unsigned)min(co, a.Cout - 1) * pbz;
             if ((i + 1) * 64 <= NPIX || i * 64 + lane < NPIX)   // partial last piece: exec-masked
-                lds_dma4(ts.rz, (lds_ptr_t)(bufA + c * SA + i * 64), co < a.Cout ? ts.oz[i] : kOOB, so);
+                lds_dma4(ts.rz, (lds_ptr_t)(bufA + c * SA + i * 64), ts.oz[i], so);
         } else {
             const int q2 = q - T::ROWS_A * T::PA;
             const int j = q2 / T::PB, i = q2 % T::PB;
-            const int c = wave + j * NW, ci = ci0 + c;
+            const int c = wave_t + j * NW, ci = min(ci0 + c, a.Cin - 1);
             const bool from1 = ci < a.C1;   // wave-uniform
-            const unsigned so = from1 ? (unsigned)ci * pb1 : (unsigned)min(max(ci - a.C1, 0), max(a.C2 - 1, 0)) * pbz;
+            const unsigned so = from1 ? (unsigned)ci * pb1 : (unsigned)(ci - a.C1) * pbz;
             // (a wave-uniform branch, not a select: selecting between the two descriptors of the struct by address would
             // turn the whole struct into an LDS-resident array)
             if ((i + 1) * 64 <= T::NPATCH || i * 64 + lane < T::NPATCH) {
                 lds_ptr_t d = (lds_ptr_t)(bufA + T::COT * SA + c * SB + i * 64);
-                if (from1) lds_dma4(ts.r1, d, ci < a.Cin ? ts.o1[i] : kOOB, so);
-                else lds_dma4(ts.r2, d, ci < a.Cin ? ts.o2[i] : kOOB, so);
+                if (from1) lds_dma4(ts.r1, d, ts.o1[i], so);
+                else lds_dma4(ts.r2, d, ts.o2[i], so);
             }
         }
     };
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(WCO* WCI * 128, (WCO * WCI >= 4 ? 2 : 1)) void conv
 
     if (t_begin < t_end) {
         const TileSrc ts0 = tile_src(t_begin);
-        wg_static_for<T::NPIECES>([&](auto qc) { stage_piece(ts0, lds, decltype(qc)::value); });
+        wg_static_for<T::NPIECES>([&](auto qc) { stage_piece(ts0, lds, decltype(qc)::value, wave); });
     }
     __syncthreads();
 
@@ -210,26 +216,28 @@ __global__ __launch_bounds__(WCO* WCI * 128, (WCO * WCI >= 4 ? 2 : 1)) void conv
             float* nbuf = lds + (buf ^ 1) * T::BUF;
             TileSrc tsn;
             if constexpr (NEXT) tsn = tile_src(tile + 1);
+            int wave_t = wave;
+            asm volatile("" : "+s"(wave_t));   // (see stage_piece)
             // lane = (channel l & 31, tile l >> 5 of the K-step): the tile's column offset lives in the base pointers
             const float* pa = ldsA + (wco * 32 + (lane & 31)) * SA + 2 * (lane >> 5);
             const float* pb = ldsB + (wci * 32 + (lane & 31)) * SB + 2 * (lane >> 5);
-            float dzr[2][4], xr[2][16];
+            // Operand transforms in packed fp32 on register pairs along the pixel column (wmd_conv_common.h, w32_pk_*): fp32 MFMA
+            // and the vector ALU are the same hardware, and this loop used to issue ~33 scalar VALU instructions per 8 MFMAs.
+            // dM = A dY A^T's minus signs on positions (r,3), r < 3, and (3,c), c < 3, move into V's column mix, which produces
+            // either sign in the same instruction: every product is the same bits as before.  15 packed instructions per K-step.
+            // Volatile LDS-space reads: one ds_read_b64 with an immediate offset each (no v_add_u32 for a ds_read2 base), and only
+            // the three patch rows this half's positions use.
+            typedef const volatile __attribute__((address_space(3))) f32x2* lds_cv2_t;
+            typedef const volatile __attribute__((address_space(3))) float* lds_cv1_t;
+            const lds_cv1_t pa3 = (lds_cv1_t)pa, pb3 = (lds_cv1_t)pb;
+            f32x2 dzp[2][2], xp[2][8];   // [slot][row] of dY, [slot][2 row + half] of the patch
             auto fetch = [&](int ks) {
                 const int t0 = ks * 2, trow = t0 / T::TXW, tcol = t0 % T::TXW, sl = ks & 1;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(pa + (2 * trow + r) * TW + 2 * tcol);
-                    dzr[sl][r * 2 + 0] = v[0];
-                    dzr[sl][r * 2 + 1] = v[1];
-                }
+                for (int r = 0; r < 2; ++r) dzp[sl][r] = *reinterpret_cast<lds_cv2_t>(pa3 + (2 * trow + r) * TW + 2 * tcol);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x2 v = *reinterpret_cast<const f32x2*>(pb + (2 * trow + r) * PW + 2 * tcol + 2 * h);
-                        xr[sl][r * 4 + 2 * h + 0] = v[0];
-                        xr[sl][r * 4 + 2 * h + 1] = v[1];
-                    }
+                for (int e = 2 * HF; e < 2 * HF + 6; ++e)
+                    xp[sl][e] = *reinterpret_cast<lds_cv2_t>(pb3 + (2 * trow + (e >> 1)) * PW + 2 * tcol + 2 * (e & 1));
             };
             constexpr int NPIECES = NEXT ? T::NPIECES : 0;
             constexpr int NP = UP ? (HF == 0 ? 5 : 4) : 8;
@@ -239,34 +247,45 @@ __global__ __launch_bounds__(WCO* WCI * 128, (WCO * WCI >= 4 ? 2 : 1)) void conv
                 constexpr int ks = decltype(ksc)::value;
                 constexpr int sl = ks & 1;
                 if constexpr (ks + 1 < T::KS) fetch(ks + 1);
-                // dM = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]   (positions this half does not own are dropped)
-                float dm[16], v[16];
+                // dM = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]], up to the signs V takes over
+                float dm[16];   // (elements of the pair results: no instruction of their own)
+                f32x2 vp[8];
                 {
-                    const float d00 = dzr[sl][0], d01 = dzr[sl][1], d10 = dzr[sl][2], d11 = dzr[sl][3];
-                    const float t[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dm[r * 4 + 0] = t[r][0];
-                        dm[r * 4 + 1] = t[r][0] + t[r][1];
-                        dm[r * 4 + 2] = t[r][0] - t[r][1];
-                        dm[r * 4 + 3] = -t[r][1];
+                    const f32x2 d0 = dzp[sl][0], d1 = dzp[sl][1];
+                    const f32x2 sm = w32_pk_addn(d0, d1), df = w32_pk_subn(d0, d1);   // rows 1, 2 of A dY
+                    if constexpr (HF == 0) {   // row 0 (all columns), (1,0) (1,1) (2,0) (2,1)
+                        const f32x2 pm = w32_pk_pm(d0);   // (d00 + d01, d00 - d01)
+                        dm[0] = d0[0], dm[1] = pm[0], dm[2] = pm[1];
+                        dm[3] = d0[1];                    // + d01: V carries the minus
+                        dm[4] = sm[0], dm[5] = sm[0] + sm[1];
+                        dm[8] = df[0], dm[9] = df[0] + df[1];
+                    } else {                   // (1,2) (1,3) (2,2) (2,3), row 3 (all columns)
+                        const f32x2 pm = w32_pk_pm(d1);   // (d10 + d11, d10 - d11)
+                        dm[6] = sm[0] - sm[1], dm[7] = sm[1];     // (1,3): + s1, V carries the minus
+                        dm[10] = df[0] - df[1], dm[11] = df[1];   // (2,3) likewise
+                        dm[12] = d1[0], dm[13] = pm[0], dm[14] = pm[1];   // row 3, columns 0-2: V carries the minus
+                        dm[15] = d1[1];
                     }
                 }
-                {   // V = B^T d B
-                    float tr[16];
+                {   // V = B^T d B: rows mix as whole pairs (rows 0-2 / 1-3), then the column mix of each owned row pair
+                    f32x2 tp[8];
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        tr[0 * 4 + cc] = xr[sl][0 * 4 + cc] - xr[sl][2 * 4 + cc];
-                        tr[1 * 4 + cc] = xr[sl][1 * 4 + cc] + xr[sl][2 * 4 + cc];
-                        tr[2 * 4 + cc] = xr[sl][2 * 4 + cc] - xr[sl][1 * 4 + cc];
-                        tr[3 * 4 + cc] = xr[sl][1 * 4 + cc] - xr[sl][3 * 4 + cc];
+                    for (int h = 0; h < 2; ++h) {
+                        if constexpr (HF == 0) tp[0 + h] = w32_pk_sub(xp[sl][0 + h], xp[sl][4 + h]);
+                        tp[2 + h] = w32_pk_add(xp[sl][2 + h], xp[sl][4 + h]);
+                        tp[4 + h] = w32_pk_sub(xp[sl][4 + h], xp[sl][2 + h]);
+                        if constexpr (HF == 1) tp[6 + h] = w32_pk_sub(xp[sl][2 + h], xp[sl][6 + h]);
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r * 4 + 0] = tr[r * 4 + 0] - tr[r * 4 + 2];
-                        v[r * 4 + 1] = tr[r * 4 + 1] + tr[r * 4 + 2];
-                        v[r * 4 + 2] = tr[r * 4 + 2] - tr[r * 4 + 1];
-                        v[r * 4 + 3] = tr[r * 4 + 1] - tr[r * 4 + 3];
+                    if constexpr (HF == 0) {
+                        vp[0] = w32_pk_lo(tp[0], tp[1]);
+                        vp[1] = w32_pk_hi_f(tp[0], tp[1]);      // (0,2), -(0,3)
+                        vp[2] = w32_pk_lo(tp[2], tp[3]);
+                        vp[4] = w32_pk_lo(tp[4], tp[5]);
+                    } else {
+                        vp[3] = w32_pk_hi_f(tp[2], tp[3]);      // (1,2), -(1,3)
+                        vp[5] = w32_pk_hi_f(tp[4], tp[5]);      // (2,2), -(2,3)
+                        vp[6] = w32_pk_lo_ff(tp[6], tp[7]);     // -(3,0), -(3,1)
+                        vp[7] = w32_pk_hi_fl(tp[6], tp[7]);     // -(3,2), (3,3)
                     }
                 }
                 wg_static_for<NP>([&](auto pc) {
@@ -277,10 +296,10 @@ __global__ __launch_bounds__(WCO* WCI * 128, (WCO * WCI >= 4 ? 2 : 1)) void conv
                         constexpr int s = ks * NP + p;
                         constexpr int q0 = (s * NPIECES + S - 1) / S, q1 = ((s + 1) * NPIECES + S - 1) / S;
                         constexpr int qb = q0 < NPIECES ? q0 : NPIECES, qe = q1 < NPIECES ? q1 : NPIECES;
-                        wg_static_for<qe - qb>([&](auto qc) { stage_piece(tsn, nbuf, qb + decltype(qc)::value); });
+                        wg_static_for<qe - qb>([&](auto qc) { stage_piece(tsn, nbuf, qb + decltype(qc)::value, wave_t); });
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[wg32_slot(HF, xi)] = __builtin_amdgcn_mfma_f32_32x32x2f32(dm[xi], v[xi], acc[wg32_slot(HF, xi)], 0, 0, 0);
+                    acc[wg32_slot(HF, xi)] = __builtin_amdgcn_mfma_f32_32x32x2f32(dm[xi], vp[xi >> 1][xi & 1], acc[wg32_slot(HF, xi)], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
