@@ -9,4 +9,4 @@ WMD_BENCH_BACKEND=gloo WMD_BENCH_SHARE_DEVICES=1 timeout 900 python bench.py --g
 tail -c 700 $OUT/bench_2rank_rehearsal.json; echo
 # ... and with the RCCL exchange, which cannot come up between two ranks on ONE device: the line must carry every rank's error
 WMD_BENCH_BACKEND=gloo WMD_BENCH_SHARE_DEVICES=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --train-steps 3 --exchange-backend rccl --no-train-nyu > $OUT/bench_2rank_rccl_failure.json 2> $OUT/bench_2rank_rccl_failure.err
-python -c "import json; d=json.load(open('$OUT/bench_2rank_rccl_failure.json')); print('train:', json.dumps(d['train'])[:900])"
+python -c "import json; d=json.loads([l for l in open('$OUT/bench_2rank_rccl_failure.json') if l.startswith('{')][-1]); print('train:', json.dumps(d['train'])[:900])"   # (RCCL / gloo banners precede the line)
