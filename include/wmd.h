@@ -135,7 +135,10 @@ typedef struct {
     /* Block-sparse execution (3x3; the threshold-gated sparse decoders on the dense MFMA kernels when several frames are
      * decoded together): with out_mask [B,H,W] only the pixel tiles that contain an active output pixel are computed (every
      * block tests its own tile's mask bytes and returns when there is none), outputs outside the mask are written as 0 and
-     * tiles without active pixels are NOT touched (y must be zero-initialised); with in_mask [B,H,W] a padded input
+     * tiles without active pixels are NOT touched (y must be zero-initialised -- or every consumer of y must select on the
+     * mask rather than multiply by it, which is how the sparse decoders use their never-refilled activation pool: the next
+     * layer's in_mask / the head's yh_mask gate every read, tests/test_gpu_configs.py poisons the pool with NaN); with in_mask
+     * [B,H,W] a padded input
      * position outside the mask reads 0 for x1 and x2 alike -- the mask test after the coordinate padding of
      * sparse_conv3x3 (KITTI/layers.py:439-453).  Split-K stays available (the reduce pass writes 0 outside out_mask and
      * never reads the slots of a skipped tile); implemented by the Winograd kernels (needs wp_wino).
