@@ -462,16 +462,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Order of the passes.  The driver's protocol is short (--steps 20 --warmup 5 = 18 ms of GPU work), and an MI355X that has
-    # idled through the model set-up spends its first milliseconds below its steady clocks (tools/probes/bench_protocol_probe.py,
-    # same box: 0.750 ms/step measured cold against 0.716 after activity, 0.712 steady).  So the per-kernel roofline pass --
-    # K eager steps with a hipEvent pair around every launch, needed anyway -- runs FIRST; the W warm-up replays follow
-    # directly (the first of them captures the graphs), then the timed region: EXACTLY K steps between barrier + synchronize,
-    # nothing but the K forward calls inside.  The per-step spread (p10 / median / p90) comes from one more K-step pass with an
-    # event after every step, outside the timed region (the event records cost 0.5-1 %).
+    # Order of the passes.  The driver's protocol is short (--steps 20 --warmup 5 = 15 ms of GPU work), and an MI355X that has
+    # idled -- through the model set-up, or through a graph capture (host work, tens of ms) -- spends its next ~12 steps below
+    # its steady clocks (tools/probes/bench_protocol_probe.py: first steps 0.625 ms against 0.565 steady; K = 20 after an idle
+    # gap 0.603 ms/step, without 0.565).  Round 4 ran the eager per-kernel pass first and let the first warm-up step capture
+    # the graphs: that put the capture's idle gap directly in front of the timed replays (driver protocol 0.607 ms/step on a box
+    # whose 50-step loop read 0.575).  So: (1) set-up, which includes the graph capture; (2) the per-kernel roofline pass -- K
+    # eager steps with a hipEvent pair around every launch, needed anyway, and 12+ ms of GPU work -- with the captured graphs
+    # kept (decoder.eager()); (3) directly behind it the W warm-up steps, which are replays like the timed ones; (4) the timed
+    # region: EXACTLY K steps between barrier + synchronize, nothing but the K forward calls inside.  The per-step spread (p10 /
+    # median / p90) comes from one more K-step pass with an event after every step, outside the timed region.
     graph_on = os.environ.get("WMD_BENCH_GRAPH", "1") != "0"
+    dec.enable_graph(graph_on)
+    with torch.no_grad():
+        dec(feats)                              # set-up: tunes what the committed choices do not cover, captures the graphs
+        for _ in range(30):                     # ... and 17 ms of replays bring the clocks back up before the per-kernel pass,
+            dec(feats)                          #     whose launch durations are what `roofline` reports
     roof = roofline(dec, feats, args.steps)     # every rank runs it (same state on every GPU); rank 0's goes into the line
-    dec.enable_graph(graph_on)                  # (the pass leaves the decoder in eager mode)
     with torch.no_grad():
         for _ in range(args.warmup):
             dec(feats)
@@ -633,12 +640,13 @@ def forward_extra(dev, chans, B, H, W, steps, label, graph=True):
     dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
     feats = [torch.from_numpy(f).to(dev) for f in synth.encoder_features(B, H, W, chans, seed=1)]
     with torch.no_grad():
-        dec(feats)                      # tunes what the committed choices do not cover
-        _lib.profile_begin()
-        for _ in range(3):
-            dec(feats)
-        recs = _lib.profile_end()
         dec.enable_graph(graph)
+        dec(feats)                      # tunes what the committed choices do not cover, captures the graphs
+        with dec.eager():               # (the idle gap of a capture must not sit in front of the timed replays: see main())
+            _lib.profile_begin()
+            for _ in range(3):
+                dec(feats)
+            recs = _lib.profile_end()
         for _ in range(5):
             dec(feats)
         torch.cuda.synchronize()
@@ -675,8 +683,7 @@ def roofline(dec, feats, steps):
     fraction of a hardware limit); the algorithmic rate (SURVEY.md §8(d)'s per-unit figure x units per launch / duration)
     is kept beside it as `achieved_algorithmic` / `frac_algorithmic` and can exceed 1."""
     from wavelet_monodepth_amd import _lib
-    with torch.no_grad():
-        dec.enable_graph(False)   # per-launch hipEvents need eager launches
+    with torch.no_grad(), dec.eager():   # per-launch hipEvents need eager launches; captured graphs are kept
         dec(feats)
         _lib.profile_begin()
         for _ in range(steps):

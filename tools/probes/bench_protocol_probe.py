@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from wavelet_monodepth_amd import synth, tuner
 from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
-tuner.preload(os.path.join(ROOT, "profiles", "r04_tune_cache.json"))
+tuner.preload(os.path.join(ROOT, "profiles", "r05_tune_cache.json"))
 dev = torch.device("cuda:0")
 R18 = [64, 64, 128, 256, 512]
 dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(R18)), seed=1).to(dev).eval()

@@ -258,6 +258,22 @@ class DepthWaveProgressiveDecoder(nn.Module):
             self.static_inputs = None
         return self
 
+    def eager(self):
+        """Context manager: forwards inside it are launched eagerly WITHOUT dropping the captured graphs (enable_graph(False)
+        clears them).  For a profiling pass between capture and replay -- bench.py's per-kernel hipEvent pass -- that must not
+        leave the GPU idle through a second capture right before the timed replays."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            was = self._graph_mode
+            self._graph_mode = False
+            try:
+                yield self
+            finally:
+                self._graph_mode = was
+        return _cm()
+
     def _forward_impl(self, input_features):
         self.outputs = {}
         ops.prepack_module(self)      # one launch for every weight image this pass (and its backward) will ask for
