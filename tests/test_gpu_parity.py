@@ -553,6 +553,27 @@ def test_bound_static_inputs_replay_fresh_tensors_without_recapturing(dev):
         assert_close(out[("disp", 0)], _kitti_decoder(dev, seed=4)(small)[("disp", 0)], 2e-6, "fallback")
 
 
+def test_eager_context_keeps_the_captured_graphs(dev):
+    """decoder.eager() (round 5; bench.py's per-kernel pass between capture and the timed replays): forwards inside the context are
+    eager launches, the captured graphs survive it -- no second capture afterwards, same maps on every path."""
+    dec = _kitti_decoder(dev, seed=6)
+    feats = [f.to(dev) for f in kitti_feats(2, 64, 96, seed=6)]
+    with torch.no_grad():
+        ref = {k: v.clone() for k, v in dec(feats).items()}
+        dec.enable_graph(True)
+        dec(feats)
+        n0 = dec.capture_count
+        assert n0 >= 1
+        with dec.eager():
+            out_e = {k: v.clone() for k, v in dec(feats).items()}
+            assert dec.capture_count == n0
+        out_g = dec(feats)
+        assert dec.capture_count == n0, "the eager context dropped the captured graphs"
+        for k in ref:
+            assert_close(out_e[k], ref[k], 2e-6, "eager context " + key_str(k))
+            assert_close(out_g[k], ref[k], 2e-6, "replay after the eager context " + key_str(k))
+
+
 @pytest.mark.parametrize("two_streams", [False, True])
 def test_kitti_dense_decoder_graph_modes_repeatable_in_place(dev, two_streams):
     """Graph replay (one graph / trunk + heads as graph segments on two streams): the inputs are live buffers -- new
