@@ -221,6 +221,31 @@ def test_reference_format_checkpoint_roundtrip(tmp_path):
             assert torch.equal(dst.state_dict()[k], v) and torch.equal(dst2.state_dict()[k], v), k
 
 
+def test_eager_context_suspends_graph_mode_and_keeps_the_cache():
+    """decoder.eager() (bench.py's per-kernel pass between capture and the timed replays): graph mode is off inside the context and
+    back on behind it -- also when the body raises -- and the cache of captured graphs is the same object with the same entries
+    (enable_graph(False) would have cleared it)."""
+    import pytest
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+    dec = DepthWaveProgressiveDecoder(np.array(R18))
+    dec.enable_graph(True)
+    cache = dec._graphs
+    cache._entries["sentinel"] = object()
+    with dec.eager() as d:
+        assert d is dec and dec._graph_mode is False
+        assert dec._graphs is cache and "sentinel" in cache._entries
+    assert dec._graph_mode is True and "sentinel" in cache._entries
+    with pytest.raises(RuntimeError):
+        with dec.eager():
+            raise RuntimeError("body failed")
+    assert dec._graph_mode is True
+    dec.enable_graph(False)
+    with dec.eager():
+        assert dec._graph_mode is False
+    assert dec._graph_mode is False          # an eager decoder stays eager
+    assert "sentinel" not in dec._graphs._entries
+
+
 # ---- no CPU fallback anywhere in the product ----------------------------------------------------------------------------
 def test_every_module_refuses_cpu_tensors():
     """The product path must fail loudly instead of computing on the host: decoders, wavelet modules, loss and
