@@ -528,7 +528,7 @@ def test_bound_static_inputs_replay_fresh_tensors_without_recapturing(dev):
     dec = _kitti_decoder(dev, seed=4)
     base = [f.to(dev) for f in kitti_feats(2, 64, 96, seed=4)]
     with torch.no_grad():
-        dec.bind_inputs(base)
+        dec.bind_inputs(base, pointer_sets=0)     # the copy route alone (the recurring-address route has its own test below)
         n0 = dec.capture_count
         assert n0 >= 1
         for step, scale in enumerate((1.0, 0.6, 1.7, 0.6)):
@@ -551,6 +551,60 @@ def test_bound_static_inputs_replay_fresh_tensors_without_recapturing(dev):
         small = [f[:1].contiguous() for f in base]
         out = dec(small)
         assert_close(out[("disp", 0)], _kitti_decoder(dev, seed=4)(small)[("disp", 0)], 2e-6, "fallback")
+
+
+def test_bound_static_inputs_zero_copy_routes(dev):
+    """Round 6 (trainer.py:240-241 hands the decoder fresh encoder outputs every step): the two hand-overs that
+    reach the captured launches WITHOUT the 167.7 MB copy.  (a) Tensors that come back at recurring device addresses -- what a
+    caching allocator in steady state returns -- get ONE capture per address set on their second sighting and are then replayed
+    in place; the captures are bounded (`pointer_sets`), a one-off address set never captures, and new values written at the
+    same addresses flow through.  (b) adopt=True: the caller's own tensors become the graph's input buffers
+    (`decoder.input_buffers()`), an encoder writes into them, no copy and no capture ever again."""
+    ref_dec = _kitti_decoder(dev, seed=4)
+    base = [f.to(dev) for f in kitti_feats(2, 64, 96, seed=4)]
+
+    def check(out, feats, what):
+        ref = ref_dec(feats)
+        for k in ref:
+            assert_close(out[k], ref[k], 2e-6, what + " " + key_str(k))
+
+    with torch.no_grad():
+        # (a) recurring addresses
+        dec = _kitti_decoder(dev, seed=4)
+        dec.bind_inputs(base, pointer_sets=2)
+        n0 = dec.capture_count
+        sets = [[f.clone() for f in base] for _ in range(3)]          # three address sets that keep coming back
+        for step in range(9):
+            cur = sets[step % 3]
+            for f, b in zip(cur, base):
+                f.copy_(b * (0.5 + 0.25 * step))                         # new values at old addresses
+            out = {k: v.clone() for k, v in dec(cur).items()}
+            check(out, cur, "recurring set, step %d" % step)
+        assert dec.capture_count == n0 + 2, "one capture per recurring address set, at most pointer_sets of them (%d -> %d)" % (n0, dec.capture_count)
+        r = dict(dec.static_route)
+        # first sightings (3) copy; sets 0 and 1 capture at their second sighting and replay in place from then on; set 2 keeps copying
+        assert r["copy"] == 3 + 2 and r["pointer_replay"] == 4, r
+        once = [f * 1.25 for f in base]                                  # an address set seen once: the copy route, no capture
+        out = {k: v.clone() for k, v in dec(once).items()}
+        check(out, once, "one-off set")
+        assert dec.capture_count == n0 + 2
+        for g in (dec._graphs._entries.values()):                        # the pointer-set captures keep no input tensor alive
+            assert g[2] is None or all(a is b for a, b in zip(g[2], dec.static_inputs))
+
+        # (b) adopted buffers
+        dec = _kitti_decoder(dev, seed=4)
+        mine = [f.clone() for f in base]
+        dec.bind_inputs(mine, adopt=True)
+        n0 = dec.capture_count
+        assert all(a is b for a, b in zip(dec.input_buffers(), mine))
+        for scale in (0.3, 1.9):
+            for dst, src in zip(dec.input_buffers(), base):
+                torch.mul(src, scale, out=dst)                           # "the encoder's last operator" writes in place
+            out = dec(mine)
+            check(out, [f * scale for f in base], "adopted buffers x%.1f" % scale)
+        assert dec.capture_count == n0 and dec.static_route["copy"] == 0 and dec.static_route["buffers"] == 3
+        with pytest.raises(ValueError):
+            dec.bind_inputs([f[:, :, ::2] for f in base], adopt=True)   # strided views cannot be adopted
 
 
 def test_eager_context_keeps_the_captured_graphs(dev):

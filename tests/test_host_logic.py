@@ -671,3 +671,76 @@ def test_resnet_encoder_can_defer_its_last_relu():
         feats, edge = split_edge(got)
         assert edge is got[-1] and feats[-1] is edge.tensor and split_edge(want)[1] is None
         assert torch.is_tensor(enc(x)[-1])                             # autograd on: ordinary path
+
+
+# ---- round 6: host-side pieces added for VERDICT r5 #4 / ADVICE r5 ---------------------------------------------------------
+def _load_bench():
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(__file__))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_deadline_reports_and_leaves_when_the_status_exchange_hangs():
+    """bench.py's Deadline: a rank whose peers never reach the set-up status exchange must not wait forever.  On
+    expiry every rank writes its record to stderr; rank 0 still prints the headline line (train.error = the record) and leaves
+    with 0, the others leave with 3; a cancelled deadline does nothing."""
+    import io, json, time
+    bench = _load_bench()
+    codes, out = [], io.StringIO()
+    bench._EMERGENCY["line"] = {"metric": "m", "value": 1.0, "train": None}
+    d = bench.Deadline(0.05, lambda: {"rank": 0, "error": "WmdError: wmd_comm_init"}, 0, _exit=codes.append, _out=out)
+    time.sleep(0.4)
+    assert codes == [0]
+    line = json.loads(out.getvalue())
+    assert line["value"] == 1.0 and line["train"]["error"]["error"].startswith("WmdError") and line["train"]["error"]["deadline_s"] == 0.05
+    codes.clear()
+    d = bench.Deadline(0.05, lambda: {"rank": 1, "error": None}, 1, _exit=codes.append, _out=out)
+    time.sleep(0.4)
+    assert codes == [3]                                   # a non-zero rank prints no line
+    codes.clear()
+    d = bench.Deadline(0.2, lambda: {"rank": 0, "error": None}, 0, _exit=codes.append, _out=out)
+    d.cancel()
+    time.sleep(0.4)
+    assert codes == []
+    bench._EMERGENCY["line"] = None
+
+
+def test_list_tile_query_agrees_with_the_planner_table():
+    """wmd_conv_list_tile_supported (what sparse_decoder.tile_for asks) and plan_conv's work-list filter are ONE
+    predicate now; the two shapes with LIST instantiations must be reported, others not."""
+    from wavelet_monodepth_amd import _lib
+    l = _lib.lib()
+    assert l.wmd_conv_list_tile_supported(8, 16) == 1 and l.wmd_conv_list_tile_supported(16, 16) == 1
+    for th, tw in ((8, 32), (4, 32), (6, 40), (16, 32), (12, 40), (0, 0), (8, 8)):
+        assert l.wmd_conv_list_tile_supported(th, tw) == 0, (th, tw)
+
+
+def test_bind_inputs_routes_are_decided_on_the_host():
+    """decoder._bound (round 6): the route of a graph-mode forward is host logic -- buffers themselves / a recurring address set /
+    copy -- and is decided before anything is launched.  Checked on stand-in tensors that record their copies (no GPU here)."""
+    from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+
+    class T:          # the handful of tensor attributes _bound looks at
+        def __init__(self, addr):
+            self.addr, self.shape, self.device, self.dtype, self.copies = addr, (2, 4), "d", "f", 0
+        def data_ptr(self): return self.addr
+        def is_contiguous(self): return True
+        def copy_(self, src, non_blocking=False): self.copies += 1
+
+    dec = DepthWaveProgressiveDecoder(np.array(R18))
+    dec.static_inputs = [T(1), T(2)]
+    dec._ptr_max, dec._ptr_seen, dec._ptr_keys = 1, {}, set()
+    dec.static_route = {"buffers": 0, "pointer_replay": 0, "copy": 0}
+    a, b = [T(10), T(20)], [T(30), T(40)]
+    assert dec._bound(dec.static_inputs) == (dec.static_inputs, True)
+    assert dec._bound(a) == (dec.static_inputs, True) and dec.static_inputs[0].copies == 1      # first sighting: copy
+    assert dec._bound(a) == (a, False)                                                          # second: its own capture, in place
+    assert dec._bound(b)[0] is dec.static_inputs and dec._bound(b)[0] is dec.static_inputs      # the cap (1) is reached: b keeps copying
+    assert dec._bound(a) == (a, False)
+    assert dec.static_route == {"buffers": 1, "pointer_replay": 2, "copy": 3}
+    c = [T(10), T(20)]
+    c[1].shape = (9, 9)
+    assert dec._bound(c) == (c, True)                                                           # other shapes: the ordinary keyed path

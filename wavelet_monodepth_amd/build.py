@@ -46,6 +46,12 @@ def _compile(src):
 def build(force=False, verbose=False):
     """Compile every csrc/*.hip for gfx950 and link libwmd_hip.so. Returns the library path."""
     srcs = _sources()
+    # the library is newer than every source and header: nothing to do -- also on a GPU box, where the objects do not travel
+    # (.gpurunignore keeps csrc/*.o out of the push; the built .so does travel)
+    if not force and not _stale(LIB, srcs + _deps()):
+        if verbose:
+            print("up to date", LIB)
+        return LIB
     if force:
         for s in srcs:
             o = s[:-4] + ".o"

@@ -904,8 +904,8 @@ static void launch_wino(const ConvKArgs& a, dim3 grid, hipStream_t s) {
             (int)sizeof(float) * (W32Tile<TH, TW, WN, CK>::LDS_FLOATS + W32Tile<TH, TW, WN, CK>::TAB_FLOATS),          \
             &launch_wino32<TH, TW, WN, CK>, "conv_wino32_kernel<" #TH "," #TW "," #WN "," #CK ">"},
 
-// conv_wino32q_kernel (wmd_conv_wino32q.hip, round 5) entries: TAPS = 18 marks the family (quarter-position waves: pure unmasked
-// layers only); MR = 2 (a block's slab = 32 out channels), WN = its four waves
+// conv_wino32q_kernel (wmd_conv_wino32q.hip, round 5) entries: TAPS = 18 marks the family (quarter-position waves: pure
+// channel chunking required; MASKED / LIST instantiations serve the block-sparse levels); MR = 2 (a block's slab = 32 out channels), WN = its four waves
 #define WMD_W32Q_INST(TH, TW, CK)                                                                                      \
     ConvCfg{TH, TW, 2, 1, 1, 4, CK, 18,                                                                                \
             (int)sizeof(float) * (W32QTile<TH, TW, CK>::LDS_FLOATS + W32QTile<TH, TW, CK>::TAB_FLOATS),                \
@@ -999,6 +999,22 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+
+// Does table entry c run a work list (wmd_conv_args.out_tiles) on its own tile shape?  ONE predicate for the planner and for
+// wmd_conv_list_tile_supported (the two used to disagree on shapes only the quarter family can serve).  Both 32x32x2
+// families have LIST instantiations; where both serve a shape the quarter-position kernel takes it unless WMD_LIST_FAMILY=17
+// (forced = an explicit table index was asked for: either twin may run).
+static bool cfg_serves_list(const ConvCfg& c, bool forced) {
+    static const int list_family = env_int("WMD_LIST_FAMILY", 18);
+    const bool has17 = c.TAPS == 17 && wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK);
+    const bool has18 = c.TAPS == 18 && wino32q_has_list(c.TH, c.TW, c.CK);
+    if (!has17 && !has18) return false;
+    if (forced) return true;
+    if (has17 && list_family == 18 && wino32q_has_list(c.TH, c.TW, c.CK)) return false;   // its quarter twin follows in the table
+    if (has18 && list_family == 17 && (wino32_has_list(c.TH, c.TW, 1, c.CK) || wino32_has_list(c.TH, c.TW, 2, c.CK))) return false;
+    return true;
+}
+
 static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size_t ws_floats) {
     const int taps = g->ksize == 3 ? 9 : 1;
     const int Cin = g->C1 + g->C2;
@@ -1019,12 +1035,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             continue;                                         // quarter-position kernel: flattened staging of pure layers only (wino32_pure)
         if (g->out_tiles) {   // work-list form: the LIST instantiations of the 32x32x2 kernels on the list's own tile shape
             // (both families have one for 8 x 16 tiles: the quarter-position kernel unless WMD_LIST_FAMILY=17)
-            static const int list_family = env_int("WMD_LIST_FAMILY", 18);
-            const bool has17 = c.TAPS == 17 && wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK);
-            const bool has18 = c.TAPS == 18 && wino32q_has_list(c.TH, c.TW, c.CK);
-            if ((!has17 && !has18) || c.TH != g->out_tile_h || c.TW != g->out_tile_w) continue;
-            if (has17 && list_family == 18 && wino32q_has_list(c.TH, c.TW, c.CK) && force < 0) continue;   // its quarter twin follows in the table
-            if (has18 && list_family == 17 && force < 0) continue;
+            if (!cfg_serves_list(c, force >= 0) || c.TH != g->out_tile_h || c.TW != g->out_tile_w) continue;
             if (Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK) || (g->in_mask && g->up1 == 2 && !g->in_mask_2x2)) continue;   // wino32_pure
         }
         if (force >= 0 && force != i) continue;
@@ -1350,7 +1361,7 @@ extern "C" int wmd_conv_pack_many(const wmd_pack_item* items, int n, void* strea
 extern "C" int wmd_conv_list_tile_supported(int tile_h, int tile_w) {
     for (int i = 0; i < kNumCfgs; ++i) {
         const ConvCfg& c = kCfgs[i];
-        if (c.TAPS == 17 && c.TH == tile_h && c.TW == tile_w && wino32_has_list(c.TH, c.TW, c.WN / 2, c.CK)) return 1;
+        if (c.TH == tile_h && c.TW == tile_w && cfg_serves_list(c, false)) return 1;
     }
     return 0;
 }

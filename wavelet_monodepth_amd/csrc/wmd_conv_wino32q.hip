@@ -18,7 +18,11 @@
 //   * Y = A^T M A row by row: quarter r reduces its row to P_r[b] = sum_c A^T[b][c] M[r][c] (2 values per tile), all four trade
 //     them through LDS, and Y[0] = P0 + P1 + P2, Y[1] = P1 - P2 - P3 are finished by quarters (0, 1) and (2, 3), eight tiles of a
 //     lane each; the output leaves through whole 128-byte lines like conv_wino32_kernel's (LDS transpose inside the wave).
-// Pure layers only (every CK-chunk inside one source tensor, no masks): the planner offers these entries to nothing else.
+// Contract: PURE channel chunking is required (every CK-chunk inside one source tensor; no generic gather).  Masks and work
+// lists ARE supported -- the MASKED and LIST instantiations below serve the block-sparse levels (input mask in the dword gather
+// offsets, tile-activity test, output select; 8x16 list tile with the device-chosen K split) and plan_conv offers TAPS == 18 to
+// in_mask / out_mask / out_tiles launches; the only masked case declined is an upsampled input mask without the 2x2 promise
+// (wmd_conv_args.in_mask_2x2 == 0), which returns WMD_ERR_UNSUPPORTED when forced.
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -196,7 +200,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
         const int cot = min(by * 2 + run, a.ncot - 1);
         aoff[v] = e < 2 * CK * 64 ? (unsigned)(((size_t)cot * a.nci4 * 16 * 64 + (size_t)rem * 4) * 4) : kOOB;
     }
+#ifdef WMD_STAMPS
     const int c_begin_dbg = blockIdx.z * a.chunks_per_split;
+#endif
     auto is_up = [&](int chunk) { return upl && (chunk + 1) * CK <= a.C1; };
     struct ChunkSrc {
         __amdgpu_buffer_rsrc_t r;

@@ -13,13 +13,25 @@ class GraphCache:
         self._entries = {}
         self._max = max_entries
         self.captures = 0
+        self.shared_pool = None   # set to a torch.cuda.graph_pool_handle(): every capture allocates from it (replays of one cache are never concurrent)
 
     def clear(self):
         self._entries.clear()
 
-    def run(self, fn, inputs, params, extra_key=()):
-        key = tuple((t.data_ptr(), tuple(t.shape)) for t in inputs) + tuple((p.data_ptr(), p._version) for p in params) \
+    def key_of(self, inputs, params, extra_key=()):
+        return tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride())) for t in inputs) + tuple((p.data_ptr(), p._version) for p in params) \
             + tuple(extra_key) + (_ops.pack_generation(),)
+
+    def has(self, key):
+        return key in self._entries
+
+    def run(self, fn, inputs, params, extra_key=(), retain_inputs=True, key=None):
+        """Replay the capture of `fn(inputs)` for this input signature (device pointers, shapes, strides, parameter versions),
+        capturing it first if there is none.  retain_inputs=False: the entry does NOT keep the input tensors alive -- for callers
+        whose inputs come back at RECURRING addresses (a caching allocator in steady state: decoder.bind_inputs); the graph reads
+        whatever lives at the captured addresses at replay time, and that is the tensors of the call that hits the key."""
+        if key is None:
+            key = self.key_of(inputs, params, extra_key)
         ent = self._entries.get(key)
         if ent is None:
             if len(self._entries) >= self._max:
@@ -32,10 +44,10 @@ class GraphCache:
                 fn(inputs)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=self.shared_pool):
                 out = fn(inputs)
             self.captures += 1
-            ent = (g, out, list(inputs))  # keep the inputs alive: the graph reads their storage
+            ent = (g, out, list(inputs) if retain_inputs else None)  # retained inputs stay alive: the graph reads their storage
             self._entries[key] = ent
         ent[0].replay()
         return dict(ent[1]) if isinstance(ent[1], dict) else ent[1]

@@ -73,6 +73,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
         # 200-register blocks per CU) the side-stream heads no longer find idle CUs: 0.648 vs 0.625 ms (round 3, same box)
         self.two_stream_graphs = os.environ.get("WMD_TWO_STREAM_GRAPHS", "0") == "1"
         self.static_inputs = None      # bind_inputs(): decoder-owned input buffers of the replayed graphs
+        self._ptr_max, self._ptr_seen, self._ptr_keys = 0, {}, set()     # ... and its recurring-address captures
+        self.static_route = {"buffers": 0, "pointer_replay": 0, "copy": 0}
         self._segment_captures = 0
         self._segments = {}
 
@@ -143,34 +145,77 @@ class DepthWaveProgressiveDecoder(nn.Module):
         """Graph captures so far, in either graph mode (a caller that thrashes the replay cache sees it grow)."""
         return self._segment_captures + self._graphs.captures
 
-    def bind_inputs(self, example_features):
+    def bind_inputs(self, example_features, adopt=False, pointer_sets=4):
         """Static-input entry for graph replay.  The replay key of `enable_graph` is the identity of the input tensors, so a
         caller whose encoder returns fresh tensors every step (every real caller: trainer.py:240-241) would re-capture on
-        every call.  After `bind_inputs`, the decoder OWNS one static buffer per feature map (`decoder.static_inputs`, shapes
-        of `example_features`): `forward` copies whatever it is handed into them -- or nothing, when it is handed the buffers
-        themselves, e.g. an encoder writing its outputs in place -- and replays the one capture.  Inference only; a call with
-        other shapes, or with autograd enabled, takes the ordinary path."""
-        self.static_inputs = [torch.empty_like(f, memory_format=torch.contiguous_format) for f in example_features]
-        for dst, src in zip(self.static_inputs, example_features):
-            dst.copy_(src)
+        every call.  After `bind_inputs`, the decoder has one static buffer per feature map (`decoder.input_buffers()`), and
+        `forward` reaches the captured launches by the cheapest of three routes:
+
+          1. handed the static buffers themselves -- an encoder whose last operators write into `decoder.input_buffers()`
+             (`out=` / in-place), or `adopt=True`, which makes the caller's OWN tensors the static buffers -- it replays: no copy;
+          2. handed tensors at device addresses it has seen before (a caching allocator in steady state returns the same blocks
+             step after step), it captures once per recurring address set -- on the second sighting, at most `pointer_sets`
+             sets, none retained -- and from then on replays that capture on the caller's tensors in place: no copy;
+          3. otherwise it copies into the static buffers and replays the first capture (167.7 MB per config-2 batch: +0.07 ms).
+
+        Inference only; a call with other shapes, or with autograd enabled, takes the ordinary path."""
+        if adopt:
+            for f in example_features:
+                if not (f.is_cuda and f.is_contiguous() and f.dtype == torch.float32):
+                    raise ValueError("bind_inputs(adopt=True) takes contiguous float32 device tensors (they become the graph's input buffers)")
+            self.static_inputs = list(example_features)
+        else:
+            self.static_inputs = [torch.empty_like(f, memory_format=torch.contiguous_format) for f in example_features]
+            for dst, src in zip(self.static_inputs, example_features):
+                dst.copy_(src)
+        self._ptr_max, self._ptr_seen, self._ptr_keys = int(pointer_sets), {}, set()
+        self.static_route = {"buffers": 0, "pointer_replay": 0, "copy": 0}    # forwards by route (diagnostics; bench.py reports it)
         self._graph_mode = True
+        self._graphs.shared_pool = torch.cuda.graph_pool_handle()   # the pointer-set captures share one memory pool
         with torch.no_grad():
             self.forward(self.static_inputs)          # warm-up + capture now, not inside the first timed call
         return self
 
+    def input_buffers(self):
+        """The static input buffers of `bind_inputs` (None before): whatever is written into them is what the next forward on
+        them decodes -- the zero-copy hand-over for an encoder that can direct its outputs (`torch.add(a, b, out=buf)`, `buf.copy_`
+        fused into its last kernel, ...)."""
+        return self.static_inputs
+
     def _bound(self, input_features):
+        """-> (features to run on, retain them in the graph cache?) for a graph-mode forward (see bind_inputs)."""
         st = self.static_inputs
         if st is None or len(st) != len(input_features):
-            return None
+            return input_features, True
+        same = True
         for dst, src in zip(st, input_features):
             if src is dst:
                 continue
+            same = False
             if src.shape != dst.shape or src.device != dst.device or src.dtype != dst.dtype:
-                return None
+                return input_features, True
+        if same:
+            self.static_route["buffers"] += 1
+            return st, True
+        if self._ptr_max > 0 and all(f.is_contiguous() for f in input_features):
+            pk = tuple(f.data_ptr() for f in input_features)
+            if pk in self._ptr_keys:
+                self.static_route["pointer_replay"] += 1
+                return input_features, False
+            n = self._ptr_seen.get(pk, 0) + 1
+            if n >= 2 and len(self._ptr_keys) < self._ptr_max:      # a RECURRING address set: worth a capture of its own
+                self._ptr_keys.add(pk)
+                self._ptr_seen.pop(pk, None)
+                self.static_route["pointer_replay"] += 1
+                return input_features, False
+            if len(self._ptr_seen) >= 64:
+                self._ptr_seen.clear()
+            self._ptr_seen[pk] = n
         for dst, src in zip(st, input_features):
             if src is not dst:
                 dst.copy_(src, non_blocking=True)
-        return st
+        self.static_route["copy"] += 1
+        return st, True
 
     def forward(self, input_features):
         # encoder edge: the last feature may arrive as a layers.DeferredActivation (pre-activation + what to apply on load)
@@ -179,12 +224,12 @@ class DepthWaveProgressiveDecoder(nn.Module):
             input_features[-1], edge = edge.activate(), None        # training: the ordinary path on the activated tensor
         self._edge = edge
         if self._graph_mode and not torch.is_grad_enabled():
-            input_features = self._bound(input_features) or input_features
-            if self.two_stream_graphs and edge is None:
+            input_features, retain = self._bound(input_features)
+            if self.two_stream_graphs and edge is None and retain:
                 self.outputs = self._forward_two_streams(input_features)
             else:
                 self.outputs = self._graphs.run(self._forward_impl, input_features, self.parameters(),
-                                                extra_key=("edge",) + edge.key() if edge is not None else ())
+                                                extra_key=("edge",) + edge.key() if edge is not None else (), retain_inputs=retain)
             return self.outputs
         return self._forward_impl(input_features)
 
@@ -256,6 +301,7 @@ class DepthWaveProgressiveDecoder(nn.Module):
         self._segments.clear()
         if not on:
             self.static_inputs = None
+            self._ptr_keys, self._ptr_seen = set(), {}
         return self
 
     def eager(self):

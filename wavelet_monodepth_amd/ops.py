@@ -998,6 +998,7 @@ def head_shiftsum_chain_nograd(items, scales, disp_scales, scale_ll=1.0, yl=None
     n = len(items)
     arr = (_lib.HeadShiftsumArgs * n)()
     res = []
+    yl_c = _c(yl) if yl is not None else None   # held until after the launch: a dropped temporary's block could be handed to yh / out / disp below
     for k, it in enumerate(items):
         B, H, W = it["B"], it["H"], it["W"]
         dev = it["t"].device
@@ -1008,12 +1009,13 @@ def head_shiftsum_chain_nograd(items, scales, disp_scales, scale_ll=1.0, yl=None
         if k == 0 and not it["has_ll"] and yl is None:
             raise _lib.WmdError("head_shiftsum_chain_nograd: the first level needs its low-pass input (yl) or the low-pass head")
         arr[k] = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scales[k]), t=ptr(it["t"]), bias_p=ptr(it["b3p"]),
-                                       bias_n=ptr(it["b3n"]), yh=ptr(yh), yl=ptr(_c(yl)) if (k == 0 and yl_ll is None) else None, out=ptr(out),
+                                       bias_n=ptr(it["b3n"]), yh=ptr(yh), yl=ptr(yl_c) if (k == 0 and yl_ll is None) else None, out=ptr(out),
                                        disp=ptr(disp), disp_scale=float(disp_scales[k]), clamp01=int(clamp01),
                                        bias_ll=ptr(it["b3l"]) if yl_ll is not None else None, scale_ll=float(scale_ll),
                                        yl_out=ptr(yl_ll))
         res.append((yh.unsqueeze(1), out, disp, yl_ll))
     check(l.wmd_head_shiftsum_chain_fwd(arr, n, current_stream()), "wmd_head_shiftsum_chain_fwd")
+    del yl_c   # (the items' `keep` lists -- contiguous copies the GEMM launches read -- live in `items` until the caller drops them)
     return res
 
 
