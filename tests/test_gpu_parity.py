@@ -676,6 +676,39 @@ def test_fused_head_level_vs_oracle(dev, C, H, W):
     assert_close(disp, torch.clamp(out_ref / 2 ** (s - 1), 0, 1), 2e-6, "disp")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 160, 320), (3, 131, 270), (1, 322, 320), (7, 96, 160)])
+def test_streaming_head_level_vs_oracle(dev, B, H, W):
+    """Round 6: head_stream_kernel (wmd_head_stream.hip) takes wmd_head_level_fwd's plain inference launches from 100 000
+    pixels on (strip segments of 32 columns streamed through a ring of tap-partial planes; the GEMM waves' LDS traffic and
+    wait counts are hand-written) -- same contract as the tile kernel: Conv1x1 -> LeakyReLU -> Conv3x3(refl) -> sigmoid combine
+    -> IDWT -> clamp.  Whole strips, ragged last strips / segments (270 = 8 x 32 + 14 columns, 131 rows), one frame taller than
+    wide, several units per block; every output against the oracle, and the launch must really be the streaming kernel."""
+    from wavelet_monodepth_amd import _lib, ops
+    C, s = 32, 1
+    x = t(synth.normal((B, C, H, W), "sx", 16))
+    yl = t(synth.normal((B, 1, H, W), "syl", 16)) * 2 + 4
+    hp = [t(a) for a in synth.conv_params("s1p", C, C, 1, 16)] + [t(a) for a in synth.conv_params("s3p", 3, C, 3, 16)]
+    hn = [t(a) for a in synth.conv_params("s1n", C, C, 1, 16)] + [t(a) for a in synth.conv_params("s3n", 3, C, 3, 16)]
+    lk = lambda v: torch.nn.functional.leaky_relu(v, 0.1)
+    sp = torch.sigmoid(R.conv3x3(lk(R.conv1x1(x, hp[0], hp[1])), hp[2], hp[3], "reflect"))
+    sn = torch.sigmoid(R.conv3x3(lk(R.conv1x1(x, hn[0], hn[1])), hn[2], hn[3], "reflect"))
+    yh_ref = (2 ** (s - 1) * sp - 2 ** (s - 1) * sn).unsqueeze(1)
+    out_ref = R.haar_idwt(yl, yh_ref)
+    g = lambda v: v.to(dev)
+    _lib.profile_begin()
+    yh, out, disp = ops.head_fused_level_nograd(g(x), [g(v) for v in hp], [g(v) for v in hn], scale=2.0 ** (s - 1), yl=g(yl),
+                                                disp_scale=1.0 / 2 ** (s - 1), clamp01=True)
+    recs = _lib.profile_end()
+    if os.environ.get("WMD_HEAD_STREAM", "1") != "0" and "WMD_HEAD_STREAM_MIN_PIXELS" not in os.environ:
+        assert [r["kernel"] for r in recs if not r["kernel"].startswith("conv_pack")] == ["head_stream_kernel"], recs
+    assert float((yh.cpu() - yh_ref).abs().max()) < 4e-6          # differences of sigmoids: absolute tolerance
+    assert_close(out, out_ref, 2e-6, "idwt")
+    assert_close(disp, torch.clamp(out_ref / 2 ** (s - 1), 0, 1), 2e-6, "disp")
+    # without the synthesis (yl = None): yh alone
+    yh2, out2, disp2 = ops.head_fused_level_nograd(g(x), [g(v) for v in hp], [g(v) for v in hn], scale=2.0 ** (s - 1))
+    assert out2 is None and disp2 is None and torch.equal(yh2, yh)
+
+
 @pytest.mark.parametrize("C,H,W", [(256, 12, 40), (64, 9, 28), (128, 5, 7), (32, 6, 10)])
 def test_fused_head_level_with_the_low_pass_head_as_third_chain(dev, C, H, W):
     """Coarsest level (depth_decoder.py:104-106,126-136): the LL head C -> C/4 -> 1 rides in the fused launches as a third,

@@ -360,9 +360,10 @@ extern "C" int wmd_head_level_fwd(const wmd_head_level_args* g, void* stream) {
         return fail(WMD_ERR_BAD_ARG, "wmd_head_level_fwd: sig_p and sig_n go together; the training outputs take no yh_mask");
     if (g->mid_out && (g->mid_ct <= 0 || g->mid_off_p < 0 || g->mid_off_n < 0 || g->mid_off_p + g->C > g->mid_ct || g->mid_off_n + g->C > g->mid_ct))
         return fail(WMD_ERR_BAD_ARG, "wmd_head_level_fwd: mid_out channel offsets outside mid_ct = %d", g->mid_ct);
+    hipStream_t s = (hipStream_t)stream;
+    if (head_stream_launch(g, s)) return check_launch("head_stream_kernel");   // round 6: plain inference outputs stream (wmd_head_stream.hip)
     const int tiles_x = (g->W + HL_TW - 1) / HL_TW, tiles_y = (g->H + HL_TH - 1) / HL_TH;
     const double pix = (double)g->B * g->H * g->W;
-    hipStream_t s = (hipStream_t)stream;
     ProfScope prof("head_level_kernel", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C),
                    4.0 * pix * (g->C + 3 + (g->out ? (g->disp ? 9 : 5) : 0)), s);
     const int ntiles = g->B * tiles_x * tiles_y;
