@@ -123,7 +123,12 @@ typedef struct {
     float* workspace;   /* split-K partial sums; may be NULL -> never split            */
     size_t workspace_floats;
     int tune_cfg;       /* 0: built-in cost model; k>0: force tile configuration k-1     */
-    int tune_ksplit;    /* 0: cost model; k>0: force k-way split of the Cin reduction    */
+    int tune_ksplit;    /* 0: cost model; k>0: force k-way split of the Cin reduction,
+                           finished inside the convolution where the kernel can (the
+                           32x32x2 Winograd kernels: the last K-slice block of a tile sums
+                           the slices -- same order, same bits as the second-stage kernel);
+                           k<0: |k| slices summed by the second-stage kernel (only for
+                           kernels that have both forms; WMD_ERR_UNSUPPORTED otherwise)     */
     const float* wp_wino; /* optional (3x3 only): wmd_conv_pack_weights_wino image; enables the Winograd F(2x2,3x3)
                              configurations ("conv_wino_kernel<...>": 2.25x fewer MFMAs, ~1e-6 relative rounding) */
     const float* gate;  /* optional [B,Cout,H,W]: y = act(conv + bias) * act_gate'(gate), the derivative written in terms of

@@ -207,7 +207,8 @@ def test_conv_winograd_configurations(dev, case):
     for i, name in enumerate(tuner.config_names()):
         if not name.startswith("conv_wino"):
             continue
-        for ks in (1, 2):
+        got = {}
+        for ks in (1, 2, -2):     # (round 6) 2: finished inside the convolution where the kernel can; -2: by the second-stage kernel
             y = torch.full((B, Cout, H, W), float("nan"), device=dev)
             a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=C2, Cout=Cout, ksize=3, pad_mode=ops.PAD[pad], act=ops.ACT[act],
                               slope=slope, x1=x1d.data_ptr(), x2=None if x2d is None else x2d.data_ptr(), wp=wp.data_ptr(),
@@ -217,15 +218,70 @@ def test_conv_winograd_configurations(dev, case):
             ws = torch.empty(max(n, 1), device=dev)
             a.workspace, a.workspace_floats = ws.data_ptr(), n
             st = l.wmd_conv_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream)
-            if st == -3 and ks > 1:
-                continue
+            if st == -3 and ks != 1:
+                continue      # fewer than two chunks to split / a kernel without the in-kernel finish refuses "-k"
             if quarter_family_declines(name, C1, C2):
                 assert st == -3, name
                 continue
             _lib.check(st, name)
             assert_close(y, ref, 5e-5, "%s ksplit %d" % (name, ks))
+            got[ks] = y
             tested += 1
+        if 2 in got and -2 in got:    # same partial planes, same summation order: the two finishes differ by the activation's arithmetic only
+            assert name.startswith("conv_wino32"), name
+            if act in ("none", "leaky"):
+                assert torch.equal(got[2], got[-2]), "%s: in-kernel finish != second-stage sum" % name
+            else:
+                assert_close(got[2], got[-2], 2e-6, "%s in-kernel finish vs second-stage sum" % name)
     assert tested >= 2
+
+
+@pytest.mark.skipif(os.environ.get("WMD_WINOGRAD", "1") == "0", reason="Winograd family switched off (WMD_WINOGRAD=0)")
+@pytest.mark.parametrize("name,ks,shape", [("conv_wino32_kernel<6,40,2,8>", 4, (12, 12, 40, 256, 2, 256, 256)),
+                                           ("conv_wino32q_kernel<4,32,8>", 4, (12, 6, 20, 512, 1, 0, 256)),
+                                           ("conv_wino32_kernel<12,40,4,8>", 8, (12, 12, 40, 256, 1, 0, 128)),
+                                           ("conv_wino32q_kernel<8,16,8>", 6, (1, 48, 160, 64, 2, 64, 64))])
+def test_splitk_in_kernel_finish_is_coherent_across_xcds(dev, name, ks, shape):
+    """Round 6 (VERDICT r5 #2a): the K-slice blocks of a tile run on different XCDs, whose L2s are not coherent with each other;
+    the partial tiles travel by write-through stores + agent-scope loads behind a relaxed ticket (splitk_ticket_finish).  A stale
+    line or a ticket drawn before the stores landed would show as a changed value: the forward's split layers at their real sizes,
+    40 launches each into a NaN-filled output over a workspace poisoned before every launch -- every launch bit-identical to the
+    first and equal to the second-stage sum of the same slices (activation ELU: 2e-6), and the ticket region back at zero (the
+    next launch on it -- a graph replay -- must start from armed counters)."""
+    import ctypes as C
+    from wavelet_monodepth_amd import _lib, ops, tuner
+    B, H, W, C1, up, C2, Cout = shape
+    names = tuner.config_names()
+    if name not in names:
+        pytest.skip("%s is not in this build's table" % name)
+    x1 = t(synth.normal((B, C1, H // up, W // up), "kx1", 21)).to(dev)
+    x2 = t(synth.normal((B, C2, H, W), "kx2", 21)).to(dev) if C2 else None
+    w, b = [t(a).to(dev) for a in synth.conv_params("kw", Cout, C1 + C2, 3, 21)]
+    wp, ww = ops.pack_weights(w), ops.pack_weights_wino(w)
+    l = _lib.lib()
+
+    def run(k, y, ws=None):
+        a = _lib.ConvArgs(B=B, H=H, W=W, C1=C1, up1=up, C2=C2, Cout=Cout, ksize=3, pad_mode=1, act=1, slope=0.0, x1=x1.data_ptr(),
+                          x2=None if x2 is None else x2.data_ptr(), wp=wp.data_ptr(), bias=b.data_ptr(), y=y.data_ptr(), workspace=None,
+                          workspace_floats=0, tune_cfg=names.index(name) + 1, tune_ksplit=k, wp_wino=ww.data_ptr())
+        n = l.wmd_conv_fwd_workspace_floats(C.byref(a))
+        ws = torch.empty(max(n, 1), device=dev) if ws is None else ws
+        ws.fill_(float("nan"))
+        a.workspace, a.workspace_floats = ws.data_ptr(), n
+        _lib.check(l.wmd_conv_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream), name)
+        return ws
+
+    ref = torch.full((B, Cout, H, W), float("nan"), device=dev)
+    run(-ks, ref)
+    first = torch.full_like(ref, float("nan"))
+    ws = run(ks, first)
+    assert bool(torch.isfinite(first).all())
+    assert_close(first, ref, 2e-6, "%s: in-kernel finish vs second-stage sum, %d slices" % (name, ks))
+    for rep in range(40):
+        y = torch.full_like(ref, float("nan"))
+        run(ks, y, ws)
+        assert torch.equal(y, first), "%s: launch %d differs from the first" % (name, rep)
+
 
 
 @pytest.mark.skipif(os.environ.get("WMD_WINOGRAD", "1") == "0", reason="Winograd family switched off (WMD_WINOGRAD=0)")

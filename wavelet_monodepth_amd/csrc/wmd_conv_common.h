@@ -165,6 +165,9 @@ struct ConvKArgs {
     int ksmax;
     int list_slots;          // workgroup slots of the machine for this kernel (blocks per CU x CUs): the device's K-split target
     float* y_final;
+    // split-K finished inside the convolution (round 6, 32x32x2 kernels): one zero-at-rest counter per (pixel tile, out-channel
+    // slab); null = the partial planes are summed by the second-stage kernels (conv_splitk_reduce[_list]_kernel)
+    int* tickets;
     // conv_wino32_kernel (round 5): output rows transposed through LDS into whole 128-byte lines (WMD_W32_COALESCE=0: 16-byte
     // pieces of 64 different lines per store instruction)
     int st_coalesce;
@@ -182,6 +185,97 @@ struct ConvKArgs {
 #define WMD_STAMP(k) do { } while (0)
 #define WMD_STAMP_AFTER(k, dep) do { } while (0)
 #endif
+
+// ---- split-K finished inside the convolution (round 6) --------------------------------------------------------------------
+// Every K-slice block of a (pixel tile, slab) stores its partial tile WRITE-THROUGH at agent scope (`sc1`: the eight XCD L2s are
+// not coherent with each other; a plain store may sit dirty in the writer's L2), waits for the stores' acknowledgement, then one
+// thread draws a ticket from the item's counter (relaxed agent-scope atomic: executed at the memory side).  The block that draws
+// the LAST ticket re-reads all slices of the tile with agent-scope loads in slice order s = 0 .. ks-1 -- the same order, the same
+// bits as conv_splitk_reduce_kernel, whichever block happens to be last --, applies bias + activation + the out-mask select,
+// stores the final tile and re-arms the counter (zero at rest: no fill, no second launch).  No fence: a release fence would
+// write back the whole L2 of the XCD (58 us in round 4's mask kernel); the data path is coherent by construction instead.
+// (raw buffer instructions with the sc1 cache-policy bit -- aux = 16 on gfx950: compiler-visible, so its hazard recognizer and
+//  wait-count pass cover them.  An inline-asm global_store_dwordx4 did not survive: the compiler reused the store's data registers
+//  for the next address one instruction later, and one s_nop -- the documented wait state -- was not enough on this part.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxAgent = 16;   // sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_rsrc(const float* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void st16_agent(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r, off, 0, kAuxAgent);
+}
+__device__ __forceinline__ void st4_agent(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, kAuxAgent);
+}
+__device__ __forceinline__ f32x4 ld16_agent(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kAuxAgent));
+}
+__device__ __forceinline__ float ld4_agent(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, kAuxAgent));
+}
+
+// c0: first out channel of the block's slab (NCH of them), (y0, x0): its TH x TW pixel tile of frame b; flag: one int of LDS.
+// Called by EVERY thread of the block after its partial stores (contains barriers).
+template <int NTHREADS, int TH, int TW, int NCH, bool MASKED>
+__device__ __forceinline__ void splitk_ticket_finish(const ConvKArgs& a, int* flag, int tick, int ks_n, int b, int y0, int x0, int c0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = atomicAdd(a.tickets + tick, 1);
+    __syncthreads();
+    if (*flag != ks_n - 1) return;                      // (uniform)
+    if (threadIdx.x == 0) atomicExch(a.tickets + tick, 0);
+    const int H = a.H, W = a.W;
+    const size_t plane = (size_t)H * W, fr = (size_t)a.Cout * plane;     // floats of one frame of one slice (< 2^29: host check)
+    const bool vec = (W & 3) == 0;
+    constexpr int PPR = (TW + 3) / 4, NP = NCH * TH * PPR;
+    for (int e = threadIdx.x; e < NP; e += NTHREADS) {
+        const int ch = e / (TH * PPR), rem = e - ch * (TH * PPR), r = rem / PPR, c4 = rem - r * PPR;
+        const int cg = c0 + ch, oy = y0 + r, ox = x0 + 4 * c4;
+        if (cg >= a.Cout || oy >= H || ox >= W || 4 * c4 >= TW) continue;
+        const size_t off = (size_t)cg * plane + (size_t)oy * W + ox;   // inside the frame
+        const unsigned ob = (unsigned)(off * 4);
+        const int nv = min(min(4, W - ox), TW - 4 * c4);
+        const bool v16 = vec && nv == 4;
+        auto slice = [&](int s) {       // this piece of slice s (agent-scope loads: another XCD wrote it)
+            const __amdgpu_buffer_rsrc_t rs = agent_rsrc(a.y + ((size_t)s * a.B + b) * fr, fr * 4);
+            if (v16) return ld16_agent(rs, ob);
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) q[k] = ld4_agent(rs, ob + 4 * k);
+            return q;
+        };
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= ks_n; s += 4) {                 // four slices in flight, summed in slice order
+            const f32x4 p0 = slice(s), p1 = slice(s + 1), p2 = slice(s + 2), p3 = slice(s + 3);
+            acc4 = (((acc4 + p0) + p1) + p2) + p3;
+        }
+        for (; s < ks_n; ++s) acc4 = acc4 + slice(s);
+        float v[4] = {acc4[0], acc4[1], acc4[2], acc4[3]};
+        const float bv = a.bias ? a.bias[cg] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // the kernels' own epilogue arithmetic (w32_act): same bits as their unsplit stores
+            const float z = v[k] + bv;
+            v[k] = a.act == WMD_ACT_ELU ? w32_act<WMD_ACT_ELU>(z, a.slope) : a.act == WMD_ACT_LEAKY ? w32_act<WMD_ACT_LEAKY>(z, a.slope)
+                 : a.act == WMD_ACT_SIGMOID ? w32_act<WMD_ACT_SIGMOID>(z, a.slope) : z;
+        }
+        if (MASKED && a.out_mask) {
+            const uint8_t* mp = a.out_mask + (size_t)b * plane + (size_t)oy * W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mp[min(ox + k, W - 1)] ? v[k] : 0.f;
+        }
+        float* dst = a.y_final + (size_t)b * fr + off;
+        if (v16) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) dst[k] = v[k];
+        }
+    }
+}
 
 // Device-chosen split of the input-channel reduction of a work-list launch: the same function in the convolution and in its
 // second pass.  Fills the machine (`slots` workgroup slots) when few tiles are active, at least two chunks per slice.

@@ -989,6 +989,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 struct ConvPlan {
     const ConvCfg* cfg;
+    bool ticket;   // ksplit > 1 is finished inside the convolution (32x32x2 kernels) instead of by the second-stage kernel
     int ksplit, chunks_per_split, nchunks, tiles_x, tiles_y;
     int H, W;  // problem as seen by the kernel (1x1 is flattened)
     size_t workspace_floats;
@@ -1022,9 +1023,14 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
     const int W = taps == 9 ? g->W : g->H * g->W;
     const int ncot = (g->Cout + 15) / 16;
     const int force = g->tune_cfg > 0 ? g->tune_cfg - 1 : env_int("WMD_CONV_CFG", -1);
-    const int force_ks = g->tune_ksplit > 0 ? g->tune_ksplit : env_int("WMD_CONV_KSPLIT", 0);
+    // tune_ksplit: k > 0 forces a k-way split, finished inside the convolution where the kernel can (32x32x2 families); k < 0 forces
+    // |k| slices summed by the second-stage kernel (rounds 1-5; offered to the kernels that have both forms only)
+    const int force_raw = g->tune_ksplit != 0 ? g->tune_ksplit : env_int("WMD_CONV_KSPLIT", 0);
+    const int force_ks = force_raw < 0 ? -force_raw : force_raw;
+    static const bool ticket_on = env_int("WMD_SPLITK_TICKET", 1) != 0;
     double best = 1e300;
     bool found = false;
+    plan->ticket = false;
     for (int i = 0; i < kNumCfgs; ++i) {
         const ConvCfg& c = kCfgs[i];
         const bool wino = c.TAPS >= 16;
@@ -1039,6 +1045,9 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             if (Cin % c.CK || (g->C2 > 0 && g->C1 % c.CK) || (g->in_mask && g->up1 == 2 && !g->in_mask_2x2)) continue;   // wino32_pure
         }
         if (force >= 0 && force != i) continue;
+        const bool can_ticket = c.TAPS >= 17 && !g->gate && (double)g->Cout * g->H * g->W * 4.0 < 2147483647.0;   // (32-bit buffer offsets inside a frame)
+        if (force_raw < 0 && (!can_ticket || force_ks < 2)) continue;   // "-k" names the second-stage form of a kernel that has both
+        const bool ticket = can_ticket && ticket_on && force_raw >= 0;
         const int tiles_x = (W + c.TW - 1) / c.TW, tiles_y = (H + c.TH - 1) / c.TH;
         const long tiles = (long)g->B * tiles_x * tiles_y;
         const int cob = (ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
@@ -1059,6 +1068,7 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             if (ksmax > 1 && (!have_ws || need > ws_floats)) continue;
             found = true;
             plan->cfg = &c;
+            plan->ticket = ticket;
             plan->ksplit = ksmax;
             plan->chunks_per_split = nchunks;
             plan->nchunks = nchunks;
@@ -1085,11 +1095,12 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
             cycles += 3000.0 * rounds;            // prologue/epilogue per block round
             if (c.TAPS == 16) cycles *= 1.3;      // transforms + 1.5 LDS reads per MFMA: measured, not modelled
             if (c.TAPS >= 17) cycles *= 0.8;      // 32x32x2 forms: fewer MFMAs on upsampled operands, lighter issue stream
-            if (ks_eff > 1) cycles += 6000.0;     // reduce pass launch
+            if (ks_eff > 1) cycles += ticket ? 2500.0 : 6000.0;     // the last block's finish / the reduce pass launch
             if (cycles < best) {
                 best = cycles;
                 found = true;
                 plan->cfg = &c;
+                plan->ticket = ticket;
                 plan->ksplit = ks_eff;
                 plan->chunks_per_split = cps;
                 plan->nchunks = nchunks;
@@ -1407,6 +1418,34 @@ extern "C" int wmd_conv_fwd(const wmd_conv_args* g, void* stream) {
     return run_conv(g, 0, g->H / g->up1, g->W / g->up1, stream);
 }
 
+// The ticket ring of the in-kernel split-K finish: 1 Mi counters, zero-filled once (outside any capture), handed out in
+// consecutive regions.
+static int* ticket_region(size_t items, hipStream_t stream) {
+    constexpr size_t kRing = 1u << 20;
+    static int* ring = nullptr;
+    static size_t next = 0;
+    static bool failed = false;
+    if (items == 0 || items > kRing || failed) return nullptr;
+    if (!ring) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;   // first use inside a capture: no allocation here (the decoders warm up eagerly first)
+        }
+        if (hipMalloc(&ring, kRing * sizeof(int)) != hipSuccess || hipMemset(ring, 0, kRing * sizeof(int)) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            ring = nullptr;
+            failed = true;
+            return nullptr;
+        }
+    }
+    if (next + items > kRing) next = 0;
+    int* r = ring + next;
+    next += items;
+    return r;
+}
+
 // Shared by the forward pass and by the data-gradient pass (which feeds dz through the same kernel with
 // transposed/flipped weights, shift1 = 1 and an (H+2) x (W+2) logical extent).
 int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stream) {
@@ -1451,6 +1490,19 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     a.ksplit = plan.ksplit;
     a.chunks_per_split = plan.chunks_per_split;
     a.y = plan.ksplit > 1 ? g->workspace : g->y;
+    // split-K finished inside the convolution: one self-resetting ticket counter per (tile, slab) item from the library's ring
+    // (the last arriver of an item re-arms its counter, so a region is all zero whenever no launch is using it; consecutive
+    // launches take consecutive regions, so launches in flight on different streams -- and the nodes of a captured graph, whose
+    // region is part of the captured arguments -- never share one).  No ring (allocation refused, or the first use would fall
+    // inside a stream capture): the second-stage kernels run as before.
+    bool ticket = plan.ticket && plan.ksplit > 1;
+    if (ticket) {
+        const int cob_t = (a.ncot + c.WM * c.MR - 1) / (c.WM * c.MR);
+        const size_t items = (size_t)g->B * plan.tiles_x * plan.tiles_y * cob_t;
+        a.tickets = ticket_region(items, (hipStream_t)stream);
+        if (!a.tickets) ticket = false;
+        else a.y_final = g->y;
+    }
     static const int no_x4 = env_int("WMD_X4", 1) == 0;
     a.no_x4 = no_x4;
     static const int st_coalesce = env_int("WMD_W32_COALESCE", 1);
@@ -1467,6 +1519,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
         a.list_slots = kNumCU * std::max(1, std::min(160 * 1024 / std::max(c.lds_bytes, 1), std::max(1, (c.TAPS == 18 ? 12 : 8) / (c.WM * c.WN))));
         a.y_final = g->y;
     }
+    if (ticket) a.y_final = g->y;
     a.gate = g->gate;
     a.gate_act = g->gate_act;
     a.gate_slope = g->gate_slope;
@@ -1505,6 +1558,7 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     }
     st = check_launch("conv_fwd_kernel");
     if (st) return st;
+    if (ticket) return st;   // the last K-slice block of every item has written the final values
     if (list) {
         if (plan.ksplit > 1) {   // (ksmax = 1: the device can never split, no second pass)
             const int ntiles = g->B * plan.tiles_x * plan.tiles_y;

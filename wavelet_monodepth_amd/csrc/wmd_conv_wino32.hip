@@ -110,6 +110,7 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
     const int hf = wave / WN;
 
     int t, by;
+    int tick;   // this block's (pixel tile, slab) item: index of its split-K ticket counter (splitk_ticket_finish)
     int ks_n = a.ksplit, cps = a.chunks_per_split;   // LIST: chosen below from the list's length
     if constexpr (LIST) {
         const int n_items = list_total(a.tile_count, a.B) * a.cob;
@@ -120,13 +121,16 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         const int ti = item / a.cob;
         by = item - ti * a.cob;
         t = list_entry(a.tile_list, a.tile_count, a.B, a.tiles_x * a.tiles_y, ti);
+        tick = item;
     } else if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD (see conv_fwd_kernel)
         const int item = xcd_contiguous(blockIdx.x, gridDim.x);
         t = item / a.cob;
         by = item - t * a.cob;
+        tick = item;
     } else {
         t = xcd_contiguous(blockIdx.x, gridDim.x);
         by = blockIdx.y;
+        tick = t * (int)gridDim.y + by;
     }
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
@@ -603,6 +607,8 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         float* ybase = (LIST && final_out) ? a.y_final + (size_t)b * a.Cout * plane2 : a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
         const bool vec_ok = (W & 3) == 0;
         const bool lines = !MASKED && a.st_coalesce != 0 && vec_ok;
+        const bool wt = a.tickets != nullptr && !final_out;   // split-K partial of a launch that finishes in-kernel: write-through stores
+        const __amdgpu_buffer_rsrc_t ry = agent_rsrc(ybase, (size_t)a.Cout * plane2 * 4);
         // bias + activation in place (ACT < 0: split-K partial sums, neither), then one of the two store forms
         auto finish = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
@@ -636,7 +642,17 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 #ifdef WMD_STAMPS
                     if ((a.dbg_mode & 1) && o[0] == o[0]) continue;
 #endif
-                    if (vec_ok && ox + 7 < W) {
+                    if (wt) {
+                        const unsigned ob = (unsigned)(((size_t)co * plane2 + (size_t)oy * W + ox) * 4);
+                        if (vec_ok && ox + 7 < W) {
+                            st16_agent(ry, ob, make_float4(o[0], o[1], o[2], o[3]));
+                            st16_agent(ry, ob + 16, make_float4(o[4], o[5], o[6], o[7]));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (ox + e < W) st4_agent(ry, ob + 4 * e, o[e]);
+                        }
+                    } else if (vec_ok && ox + 7 < W) {
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                         *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
                     } else {
@@ -674,8 +690,11 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
 #ifdef WMD_STAMPS
                 if ((a.dbg_mode & 1) && v.x == v.x) continue;
 #endif
-                if (cg < a.Cout && ts < T::NTILES && oy < H && ox < W)
-                    *reinterpret_cast<float4*>(ybase + (size_t)cg * plane2 + (size_t)oy * W + ox) = v;
+                if (cg < a.Cout && ts < T::NTILES && oy < H && ox < W) {
+                    const size_t o4 = (size_t)cg * plane2 + (size_t)oy * W + ox;
+                    if (wt) st16_agent(ry, (unsigned)(o4 * 4), v);
+                    else *reinterpret_cast<float4*>(ybase + o4) = v;
+                }
             }
         };
         int act_sel = final_out ? a.act : -1;
@@ -688,6 +707,8 @@ __global__ __launch_bounds__(WN * 128, 2) void conv_wino32_kernel(const ConvKArg
         else if (act_sel == WMD_ACT_SIGMOID) finish(std::integral_constant<int, WMD_ACT_SIGMOID>{});
         else finish(std::integral_constant<int, WMD_ACT_NONE>{});
         WMD_STAMP(10);   // stores issued
+        if (wt)   // (uniform) the last K-slice block of this (tile, slab) to arrive sums the slices and writes the final tile
+            splitk_ticket_finish<WN * 128, TH, TW, 32, MASKED>(a, reinterpret_cast<int*>(lds + T::LDS_FLOATS + T::TAB_FLOATS) + 8, tick, ks_n, b, y0, x0, by * 32);
 #ifdef WMD_STAMPS
         if (a.dbg && tid == 0) {
             unsigned xcc;

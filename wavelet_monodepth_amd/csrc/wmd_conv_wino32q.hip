@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
     const int qr = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's transformed row
 
     int t, by;
+    int tick;   // this block's (pixel tile, slab) item: index of its split-K ticket counter
     int ks_n = a.ksplit, cps = a.chunks_per_split;   // LIST: chosen below from the list's length
     if constexpr (LIST) {
         const int n_items = list_total(a.tile_count, a.B) * a.cob;
@@ -72,13 +73,16 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
         const int ti = item / a.cob;
         by = item - ti * a.cob;
         t = list_entry(a.tile_list, a.tile_count, a.B, a.tiles_x * a.tiles_y, ti);
+        tick = item;
     } else if (a.cob > 0) {   // (pixel tile, out-channel slab) items, slab fastest, one contiguous run per XCD
         const int item = xcd_contiguous(blockIdx.x, gridDim.x);
         t = item / a.cob;
         by = item - t * a.cob;
+        tick = item;
     } else {
         t = xcd_contiguous(blockIdx.x, gridDim.x);
         by = blockIdx.y;
+        tick = t * (int)gridDim.y + by;
     }
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
@@ -436,6 +440,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
         const bool final_out = (ks_n == 1);
         float* ybase = (LIST && final_out) ? a.y_final + (size_t)b * a.Cout * plane2 : a.y + ((size_t)ks * a.B + b) * a.Cout * plane2;
         const bool vec_ok = (W & 3) == 0;
+        const bool wt = a.tickets != nullptr && !final_out;
+        const __amdgpu_buffer_rsrc_t ry = agent_rsrc(ybase, (size_t)a.Cout * plane2 * 4);   // this slice's frame (write-through stores)
         // lane (co = l & 31, h = l >> 5) holds, for q2 = 0, 1 and r = 0..3: tile slot 8 (2 (R & 1) + q2) + 4 h + r, output row A,
         // 2 pixels.  16 slots x 2 pixels x 32 channels = 4 KB per wave: [co][8 pieces of two tiles] through the wave's own
         // quarter of the exchange area, then [8 channels][128 B] per store instruction (see conv_wino32_kernel::store_lines).
@@ -470,7 +476,15 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = mp[min(ox + e, W - 1)] ? o[e] : 0.f;
                     }
-                    if (vec_ok) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (wt) {   // split-K partial of a launch that finishes in-kernel: write-through (splitk_ticket_finish)
+                        const unsigned ob = (unsigned)(((size_t)cg * plane2 + (size_t)oy * W + ox) * 4);
+                        if (vec_ok) st16_agent(ry, ob, make_float4(o[0], o[1], o[2], o[3]));
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (ox + e < W) st4_agent(ry, ob + 4 * e, o[e]);
+                        }
+                    } else if (vec_ok) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -485,6 +499,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
         else if (act_sel == WMD_ACT_LEAKY) store_lines(std::integral_constant<int, WMD_ACT_LEAKY>{});
         else if (act_sel == WMD_ACT_SIGMOID) store_lines(std::integral_constant<int, WMD_ACT_SIGMOID>{});
         else store_lines(std::integral_constant<int, WMD_ACT_NONE>{});
+        if (wt)   // (uniform) the last K-slice block of this (tile, slab) to arrive sums the slices and writes the final tile
+            splitk_ticket_finish<256, TH, TW, 32, MASKED>(a, reinterpret_cast<int*>(lds + T::LDS_FLOATS + T::TAB_FLOATS) + 4, tick, ks_n, b, y0, x0, by * 32);
     };
     if (qr == 0) run(std::integral_constant<int, 0>{});
     else if (qr == 1) run(std::integral_constant<int, 1>{});

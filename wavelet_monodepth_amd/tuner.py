@@ -92,7 +92,9 @@ def tune(key, taps, launch):
     results = []
     best_t = float("inf")
     for cfg in cands:
-        for ks in KSPLITS:
+        # k > 0: k slices finished inside the convolution where the kernel can (round 6); -k: the same slices summed by the
+        # second-stage kernel -- the planner refuses -k for kernels that have only that form (k then already means it)
+        for ks in KSPLITS + tuple(-k for k in KSPLITS if k > 1):
             if launch(cfg, ks) != 0:      # invalid combination for this shape (planner refuses)
                 continue
             t = _time(launch, cfg, ks, 2, e0, e1)
