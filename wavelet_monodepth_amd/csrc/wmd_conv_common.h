@@ -168,6 +168,7 @@ struct ConvKArgs {
     // split-K finished inside the convolution (round 6, 32x32x2 kernels): one zero-at-rest counter per (pixel tile, out-channel
     // slab); null = the partial planes are summed by the second-stage kernels (conv_splitk_reduce[_list]_kernel)
     int* tickets;
+    int xcd_slab;   // 2-D grid launches: slab = linear workgroup id % slabs (one slab's weights per XCD) instead of slab = blockIdx.y
     // conv_wino32_kernel (round 5): output rows transposed through LDS into whole 128-byte lines (WMD_W32_COALESCE=0: 16-byte
     // pieces of 64 different lines per store instruction)
     int st_coalesce;

@@ -1535,6 +1535,15 @@ int wmd::run_conv(const wmd_conv_args* g, int shift1, int H1, int W1, void* stre
     const double wbytes = (double)a.ncot * 16 * a.nci4 * 4 * (wino ? 16 : taps) * 4;
     const bool tile_major = list || (cob > 1 && wbytes <= 3.0 * 1024 * 1024);   // (list items are always (tile, slab) pairs)
     a.cob = tile_major ? cob : 0;
+    // the coarse layers' 2-D grid: a slab per XCD when the slabs divide over the eight XCDs, every z-slice starts on XCD 0 and the
+    // weight image outweighs the input maps (they are then what each XCD re-reads; WMD_XCD_SLAB=0/1 forces it off / on)
+    {
+        static const int xs = env_int("WMD_XCD_SLAB", -1);
+        const size_t tiles_n = (size_t)g->B * plan.tiles_x * plan.tiles_y;
+        const double in_bytes = 4.0 * g->B * ((double)g->C1 * H1 * W1 + (double)g->C2 * g->H * g->W);
+        const bool fits = !tile_major && c.TAPS >= 17 && cob % 8 == 0 && (tiles_n * cob) % 8 == 0;
+        a.xcd_slab = fits && (xs >= 0 ? xs != 0 : wbytes > in_bytes) ? 1 : 0;
+    }
     dim3 grid((unsigned)((size_t)g->B * plan.tiles_x * plan.tiles_y * (tile_major ? cob : 1)), tile_major ? 1u : (unsigned)cob,
               (unsigned)plan.ksplit);
     if (env_int("WMD_CONV_VERBOSE", 0))

@@ -79,6 +79,14 @@ __global__ __launch_bounds__(256, 3) void conv_wino32q_kernel(const ConvKArgs a)
         t = item / a.cob;
         by = item - t * a.cob;
         tick = item;
+    } else if (a.xcd_slab) {
+        // 2-D grid, one out-channel slab per XCD (round 6): workgroup L of a z-slice runs on XCD L % 8 (tools/probes/xcc_probe.hip), so
+        // slab L % nslab with nslab a multiple of 8 keeps a slab's 1/nslab of the weight image in ONE L2 instead of streaming the whole
+        // image into all eight (counters: L0 / L1 of config 2 read inputs + 8 x 8.4 MB of weights per launch, profiles/r06_notes.md)
+        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+        by = L % (int)gridDim.y;
+        t = L / (int)gridDim.y;
+        tick = t * (int)gridDim.y + by;
     } else {
         t = xcd_contiguous(blockIdx.x, gridDim.x);
         by = blockIdx.y;
