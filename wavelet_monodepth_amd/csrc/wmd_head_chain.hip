@@ -24,11 +24,39 @@
 // fragment read hit disjoint banks.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 #include "wmd_internal.h"
+
+#ifndef WMD_CHAIN_PD256
+#define WMD_CHAIN_PD256 4   // chunks requested ahead, in registers (development: -DWMD_CHAIN_PD256=1 = rounds 2-5)
+#endif
+#ifndef WMD_CHAIN_PD128
+#define WMD_CHAIN_PD128 1
+#endif
 
 namespace wmd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class F, int... I>
+__device__ __forceinline__ void hc_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void hc_static_for(F&& f) {
+    hc_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt -- i.e. every global load in
+// flight, including the chunks requested AHEAD: with it a deeper prefetch changes nothing (measured: PD 1 / 2 / 4 = 33.7 / 32.9 /
+// 33.9 us) and a lone block still takes 16 x 0.94 us for 16 x 0.33 us of MFMA work.  The staged chunks travel global -> registers
+// (the compiler waits for exactly the registers it consumes) -> LDS, so lgkmcnt(0) is all the barrier needs.
+__device__ __forceinline__ void hc_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 struct HeadChainArgs {
     const float* x;      // [B, C, plane]
@@ -59,65 +87,69 @@ struct HeadChainTile {
     static constexpr int MT = MTS / RS;          // ... of one wave
     static constexpr int KS = C / 4;             // K-steps of GEMM 1
     static constexpr int NCH = KS / KC;          // staged chunks
-    static constexpr int XS = PXB + 16;          // x row stride in LDS: == 16 (mod 32) for PXB = 32, 64, 128
+    static constexpr int XS = PXB % 32 == 0 ? PXB + 16 : PXB + 32;   // x row stride in LDS: == 16 (mod 32) for PXB = 32, 48, 64, 128
     static constexpr int WF = MTS * KC * 64;     // floats of a weight chunk
     static constexpr int XF = KC * 4 * XS;       // floats of an x chunk
     static constexpr int NBUF = NCH > 1 ? 2 : 1;
-    static constexpr int WV = WF / 4 / NTH;                      // float4 per thread and weight chunk
+    static constexpr int WV = (WF / 4 + NTH - 1) / NTH;          // float4 per thread and weight chunk (last one may be partial: 12-wave blocks)
     static constexpr int XV = (KC * PXB + NTH - 1) / NTH;        // float4 per thread and x chunk (last one may be partial)
     static constexpr int RED = RS > 1 ? NW * 3 * NT * 256 : 0;   // floats of the cross-wave reduction (aliases the chunks; third tile: the low-pass rows)
     static constexpr int WFL = (C == 256 && RS == 4) ? RS * KC * 64 : 0;   // the low-pass chain's part of a weight chunk (C = 256 only): one row tile per channel slice
     static constexpr int STAGE = NBUF * (WF + WFL + XF);
     static constexpr int LDS_FLOATS = STAGE > RED ? STAGE : RED;
     static_assert(C % 16 == 0 && MTS % RS == 0 && KS % KC == 0, "whole tiles");
-    static_assert(WF % (4 * NTH) == 0, "weight chunk = whole float4 per thread");
     static_assert(XS % 32 == 16 && PXB % 4 == 0, "bank-conflict-free x rows");
 };
 
-// (LLX: the block also stages the low-pass chain's row tiles of the chunk -- WFL floats, one float4 for the first WFL/4 threads)
+// (LLX: the block also stages the low-pass chain's row tiles of the chunk -- WFL floats, one 16-byte piece for the first WFL/4
+//  threads.  The staged pieces are native vectors (f32x4), not HIP's float4 struct: with register SETS indexed by the prefetch
+//  distance the struct copies became memcpys into a stack object that the optimiser no longer promoted -- scratch.)
 template <class T, int KC, bool LLX>
-__device__ __forceinline__ void chain_fetch(float4 (&wreg)[T::WV], float4 (&xreg)[T::XV], float4& lreg, const float* __restrict__ w1,
+__device__ __forceinline__ void chain_fetch(f32x4 (&wreg)[T::WV], f32x4 (&xreg)[T::XV], f32x4& lreg, const float* __restrict__ w1,
                                             const float* __restrict__ wl, const float* __restrict__ xb, int c, int tid, int pix0, int plane) {
     if constexpr (LLX) {
-        static_assert(T::WFL > 0 && T::WFL / 4 <= T::NTH, "one float4 per thread covers the low-pass part of a chunk");
+        static_assert(T::WFL > 0 && T::WFL / 4 <= T::NTH, "one 16-byte piece per thread covers the low-pass part of a chunk");
         const int f = tid * 4, m = f / (KC * 64), rem = f % (KC * 64);
-        if (f < T::WFL) lreg = *reinterpret_cast<const float4*>(wl + ((size_t)m * T::KS + c * KC) * 64 + rem);
+        if (f < T::WFL) lreg = *reinterpret_cast<const f32x4*>(wl + ((size_t)m * T::KS + c * KC) * 64 + rem);
     }
 #pragma unroll
     for (int v = 0; v < T::WV; ++v) {
         const int f = (v * T::NTH + tid) * 4;                     // float index inside the chunk: [row tile][KC*64]
         const int m = f / (KC * 64), rem = f % (KC * 64);
-        wreg[v] = *reinterpret_cast<const float4*>(w1 + ((size_t)m * T::KS + c * KC) * 64 + rem);
+        f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+        if (T::WF % (4 * T::NTH) == 0 || f < T::WF) wv = *reinterpret_cast<const f32x4*>(w1 + ((size_t)m * T::KS + c * KC) * 64 + rem);
+        wreg[v] = wv;
     }
 #pragma unroll
     for (int v = 0; v < T::XV; ++v) {
-        const int q = v * T::NTH + tid;                           // float4 index: [channel of the chunk][PXB / 4]
+        const int q = v * T::NTH + tid;                           // piece index: [channel of the chunk][PXB / 4]
         const int chl = q / (T::PXB / 4), px = pix0 + (q % (T::PXB / 4)) * 4;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < KC * T::PXB && px < plane)                        // plane % 4 == 0 (host check): a float4 never straddles the end
-            val = *reinterpret_cast<const float4*>(xb + (size_t)(c * KC * 4 + chl) * plane + px);
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (q < KC * T::PXB && px < plane)                        // plane % 4 == 0 (host check): a piece never straddles the end
+            val = *reinterpret_cast<const f32x4*>(xb + (size_t)(c * KC * 4 + chl) * plane + px);
         xreg[v] = val;
     }
 }
 
 template <class T, int KC, bool LLX>
-__device__ __forceinline__ void chain_commit(const float4 (&wreg)[T::WV], const float4 (&xreg)[T::XV], const float4& lreg, float* ws, int tid) {
+__device__ __forceinline__ void chain_commit(const f32x4 (&wreg)[T::WV], const f32x4 (&xreg)[T::XV], const f32x4& lreg, float* ws, int tid) {
     float* xs = ws + T::WF + T::WFL;
     if constexpr (LLX) {
-        if (tid * 4 < T::WFL) *reinterpret_cast<float4*>(ws + T::WF + tid * 4) = lreg;
+        if (tid * 4 < T::WFL) *reinterpret_cast<f32x4*>(ws + T::WF + tid * 4) = lreg;
     }
 #pragma unroll
-    for (int v = 0; v < T::WV; ++v) *reinterpret_cast<float4*>(ws + (v * T::NTH + tid) * 4) = wreg[v];
+    for (int v = 0; v < T::WV; ++v)
+        if (T::WF % (4 * T::NTH) == 0 || (v * T::NTH + tid) * 4 < T::WF) *reinterpret_cast<f32x4*>(ws + (v * T::NTH + tid) * 4) = wreg[v];
 #pragma unroll
     for (int v = 0; v < T::XV; ++v) {
         const int q = v * T::NTH + tid;
-        if (q < KC * T::PXB) *reinterpret_cast<float4*>(xs + (q / (T::PXB / 4)) * T::XS + (q % (T::PXB / 4)) * 4) = xreg[v];
+        if (q < KC * T::PXB) *reinterpret_cast<f32x4*>(xs + (q / (T::PXB / 4)) * T::XS + (q % (T::PXB / 4)) * 4) = xreg[v];
     }
 }
 
 // One block's work.  LLX = the block also carries the low-pass chain (side 0 of the C = 256 launch): compiled as a second body
 // so that every size stays a compile-time constant of its body.
-template <int C, int RS, int PG, int NT, int KC, bool LLX>
+template <int C, int RS, int PG, int NT, int KC, bool LLX, int PD>
 __device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* lds) {
     using T = HeadChainTile<C, RS, PG, NT, KC>;
     constexpr int MT = T::MT, KS = T::KS, XS = T::XS, PXB = T::PXB;
@@ -148,7 +180,12 @@ __device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* l
     const float* w2 = a.wp2 + (size_t)side * 2 * KS * 64;        // fragments [tap-row tile 0..1][K-step][64 lanes]
 
     // ---- staging: chunk c = K-steps [c*KC, (c+1)*KC) of every row tile of W1_side, and channels [c*KC*4, +KC*4) of x ----
-    float4 wreg[T::WV], xreg[T::XV], lreg = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Round 6: the chunks are requested PD deep IN REGISTERS (chunk k PD iterations before its K-steps run, moved to the LDS double
+    // buffer one iteration before), behind barriers that do not drain the loads in flight (hc_barrier).
+    static_assert(PD >= 1 && (T::NCH % PD == 0 || T::NCH == 1), "the chunk loop is unrolled by the prefetch distance");
+    f32x4 wreg[PD][T::WV], xreg[PD][T::XV], lreg[PD];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) lreg[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int BUF = T::WF + T::WFL + T::XF;
 
     // ---- GEMM 1: acc[m][n] = rows 16(r*MT+m) .. +15 of W1_side x, pixels of group pg*NT + n (LLX: acc[MT] = row tile r of
@@ -159,30 +196,39 @@ __device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* l
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    chain_fetch<T, KC, LLX>(wreg, xreg, lreg, w1, a.ll_wp1, xb, 0, tid, pix0, plane);
-    chain_commit<T, KC, LLX>(wreg, xreg, lreg, lds, tid);
-    __syncthreads();
-    for (int c = 0; c < T::NCH; ++c) {
-        if (c + 1 < T::NCH) chain_fetch<T, KC, LLX>(wreg, xreg, lreg, w1, a.ll_wp1, xb, c + 1, tid, pix0, plane);
-        const float* ws = lds + (c & (T::NBUF - 1)) * BUF;
-        const float* xs = ws + T::WF + T::WFL;
+    chain_fetch<T, KC, LLX>(wreg[0], xreg[0], lreg[0], w1, a.ll_wp1, xb, 0, tid, pix0, plane);
+    chain_commit<T, KC, LLX>(wreg[0], xreg[0], lreg[0], lds, tid);
+    hc_static_for<PD>([&](auto kc) __attribute__((always_inline)) {      // chunks 1 .. PD -> register sets 1 .. PD-1, 0
+        constexpr int k = decltype(kc)::value + 1;
+        if (k < T::NCH) chain_fetch<T, KC, LLX>(wreg[k % PD], xreg[k % PD], lreg[k % PD], w1, a.ll_wp1, xb, k, tid, pix0, plane);
+    });
+    hc_barrier();
+    for (int c0 = 0; c0 < T::NCH; c0 += PD) {
+        hc_static_for<PD>([&](auto dc) __attribute__((always_inline)) {
+            constexpr int d = decltype(dc)::value, dn = (d + 1) % PD;   // register sets of chunk c (free: committed an iteration ago) and c + 1
+            const int c = c0 + d;                                       // (NCH % PD == 0: c < NCH)
+            const float* ws = lds + (c & (T::NBUF - 1)) * BUF;
+            const float* xs = ws + T::WF + T::WFL;
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            float xf[NT], wf[MTX];
+            for (int kk = 0; kk < KC; ++kk) {
+                float xf[NT], wf[MTX];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) xf[n] = xs[(kk * 4 + g) * XS + (pg * NT + n) * 16 + lc];
+                for (int n = 0; n < NT; ++n) xf[n] = xs[(kk * 4 + g) * XS + (pg * NT + n) * 16 + lc];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) wf[m] = ws[((r * MT + m) * KC + kk) * 64 + lane];
-            if constexpr (LLX) wf[MT] = ws[T::WF + (r * KC + kk) * 64 + lane];
+                for (int m = 0; m < MT; ++m) wf[m] = ws[((r * MT + m) * KC + kk) * 64 + lane];
+                if constexpr (LLX) wf[MT] = ws[T::WF + (r * KC + kk) * 64 + lane];
 #pragma unroll
-            for (int m = 0; m < MTX; ++m)
+                for (int m = 0; m < MTX; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[m], xf[n], acc[m][n], 0, 0, 0);
-        }
-        if (c + 1 < T::NCH) {
-            chain_commit<T, KC, LLX>(wreg, xreg, lreg, lds + ((c + 1) & (T::NBUF - 1)) * BUF, tid);
-            __syncthreads();
-        }
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[m], xf[n], acc[m][n], 0, 0, 0);
+            }
+            if (c + 1 < T::NCH) {
+                chain_commit<T, KC, LLX>(wreg[dn], xreg[dn], lreg[dn], lds + ((c + 1) & (T::NBUF - 1)) * BUF, tid);
+                if (c + 1 + PD < T::NCH)      // ... and set dn is free for chunk c + 1 + PD
+                    chain_fetch<T, KC, LLX>(wreg[dn], xreg[dn], lreg[dn], w1, a.ll_wp1, xb, c + 1 + PD, tid, pix0, plane);
+                hc_barrier();
+            }
+        });
     }
 
     // ---- bias + LeakyReLU in registers, then GEMM 2 straight from them ---------------------------------------------------
@@ -298,31 +344,33 @@ __device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* l
     }
 }
 
-template <int C, int RS, int PG, int NT, int KC, bool LLC = false>
-__global__ __launch_bounds__(RS* PG * 64) void head_chain_kernel(const HeadChainArgs a) {
+// (second launch bound = waves per SIMD: the 8- and 12-wave C = 256 blocks must not be throttled below 3 per SIMD by the staged
+//  register sets)
+template <int C, int RS, int PG, int NT, int KC, int PD, bool LLC = false>
+__global__ __launch_bounds__(RS* PG * 64, (RS * PG >= 8 ? 3 : 1)) void head_chain_kernel(const HeadChainArgs a) {
     using T = HeadChainTile<C, RS, PG, NT, KC>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     if constexpr (LLC) {
         if (blockIdx.y == 0) {
-            head_chain_body<C, RS, PG, NT, KC, true>(a, lds);
+            head_chain_body<C, RS, PG, NT, KC, true, PD>(a, lds);
             return;
         }
     }
-    head_chain_body<C, RS, PG, NT, KC, false>(a, lds);
+    head_chain_body<C, RS, PG, NT, KC, false, PD>(a, lds);
 }
 
-template <int C, int RS, int PG, int NT, int KC>
+template <int C, int RS, int PG, int NT, int KC, int PD>
 static void launch_chain(const HeadChainArgs& a, int B, hipStream_t s) {
     using T = HeadChainTile<C, RS, PG, NT, KC>;
     HeadChainArgs k = a;
     k.tiles = (a.plane + T::PXB - 1) / T::PXB;
     if constexpr (C == 256 && RS == 4) {
         if (a.ll_wp1) {
-            hipLaunchKernelGGL((head_chain_kernel<C, RS, PG, NT, KC, true>), dim3((unsigned)(B * k.tiles), 2), dim3(T::NTH), 0, s, k);
+            hipLaunchKernelGGL((head_chain_kernel<C, RS, PG, NT, KC, PD, true>), dim3((unsigned)(B * k.tiles), 2), dim3(T::NTH), 0, s, k);
             return;
         }
     }
-    hipLaunchKernelGGL((head_chain_kernel<C, RS, PG, NT, KC>), dim3((unsigned)(B * k.tiles), 2), dim3(T::NTH), 0, s, k);
+    hipLaunchKernelGGL((head_chain_kernel<C, RS, PG, NT, KC, PD>), dim3((unsigned)(B * k.tiles), 2), dim3(T::NTH), 0, s, k);
 }
 
 // -> true when the chained form took the launch (C = 64 / 128 / 256, image planes of a multiple of 4 pixels; WMD_HEAD_CHAIN=0
@@ -359,11 +407,22 @@ int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s)
     // (pixel-tile / wave-count / chunk variants -- 64 to 256 pixels, 2 to 16 waves, channel split 1 / 2 / 4 / 8 -- all measured
     //  within +-2 us of these)
     if (g->C == 64)
-        launch_chain<64, 1, 4, 2, 16>(a, g->B, s);    // 128 pixels x all 64 channels per wave quartet, one chunk
+        launch_chain<64, 1, 4, 2, 16, 1>(a, g->B, s);    // 128 pixels x all 64 channels per wave quartet, one chunk
     else if (g->C == 128)
-        launch_chain<128, 1, 4, 1, 8>(a, g->B, s);    // 64 pixels, 4 chunks of 32 channels
-    else
-        launch_chain<256, 4, 2, 1, 4>(a, g->B, s);    // 32 pixels, 4 waves share a pixel group's 256 channels, 16 chunks
+        launch_chain<128, 1, 4, 1, 8, WMD_CHAIN_PD128>(a, g->B, s);    // 64 pixels, 4 chunks of 32 channels
+    else {
+        // 32 pixels (8 waves: 4 share a pixel group's 256 channels), 16 chunks -- or 48 pixels (12 waves) when that brings the launch down
+        // to one block per CU: the level has so few pixels that whole blocks per CU is what its time is made of (config 2, batch 12:
+        // 360 blocks = two on 104 CUs, one on 152 -> 240 blocks, one each; profiles/r06_notes.md section 6)
+        static const int pg_force = [] {
+            const char* e = getenv("WMD_HEAD_CHAIN_PG256");
+            return e ? atoi(e) : 0;
+        }();
+        const long b32 = (long)g->B * ((plane + 31) / 32) * 2, b48 = (long)g->B * ((plane + 47) / 48) * 2;
+        const long cost32 = ((b32 + kNumCU - 1) / kNumCU) * 2, cost48 = ((b48 + kNumCU - 1) / kNumCU) * 3;
+        if (pg_force == 3 || (pg_force == 0 && cost48 < cost32)) launch_chain<256, 4, 3, 1, 4, WMD_CHAIN_PD256>(a, g->B, s);
+        else launch_chain<256, 4, 2, 1, 4, WMD_CHAIN_PD256>(a, g->B, s);
+    }
     return with_ll ? 2 : 1;
 }
 
