@@ -342,6 +342,11 @@ typedef struct {
     int mid_ct, mid_off_p, mid_off_n, mid_off_ll;
 } wmd_head_fused_args;
 int wmd_head_fused_fwd(const wmd_head_fused_args* args, void* stream);
+/* Round 6: the first stage of up to three levels in ONE launch (chained widths 64 / 128 / 256, no run_mask / mid_out; anything else
+ * falls back to n_levels calls of wmd_head_fused_fwd).  The heads of a level read only that level's trunk activation
+ * (depth_decoder.py:126-136,164-166), so a dense decoder may postpone levels 4..2 until `upconv(2,1)` is done: alone none of them
+ * fills 256 CUs, together they balance.  Same tap-partial planes, bit for bit.                                                  */
+int wmd_head_fused_multi_fwd(const wmd_head_fused_args* levels, int n_levels, void* stream);
 
 typedef struct {
     int B, H, W;

@@ -765,6 +765,74 @@ def test_streaming_head_level_vs_oracle(dev, B, H, W):
     assert out2 is None and disp2 is None and torch.equal(yh2, yh)
 
 
+def test_merged_first_stage_of_levels_4_to_2_equals_the_per_level_launches(dev):
+    """Round 6: wmd_head_fused_multi_fwd runs the chained GEMMs of levels 4 / 3 / 2 as block ranges of ONE launch (the dense decoder
+    postpones them until upconv(2,1) is done: alone none of these levels fills 256 CUs).  Same per-pixel arithmetic: every
+    tap-partial plane bit-identical to the per-level launches (the C = 256 level runs as 16-pixel blocks there, 32 / 48 here), with
+    and without the low-pass head, ragged plane sizes, and a level the merged launch cannot take (odd plane) falling back."""
+    from wavelet_monodepth_amd import ops
+    g = lambda v: v.to(dev)
+    for B, (h4, w4), with_ll in ((2, (6, 20), True), (3, (5, 12), True), (1, (12, 40), False)):
+        levels = []
+        for k, C in enumerate((256, 128, 64)):
+            H, W = h4 << k, w4 << k
+            x = g(t(synth.normal((B, C, H, W), "mx%d" % k, 31)))
+            hp = [g(t(a)) for a in synth.conv_params("m1p%d" % k, C, C, 1, 31)] + [g(t(a)) for a in synth.conv_params("m3p%d" % k, 3, C, 3, 31)]
+            hn = [g(t(a)) for a in synth.conv_params("m1n%d" % k, C, C, 1, 31)] + [g(t(a)) for a in synth.conv_params("m3n%d" % k, 3, C, 3, 31)]
+            hl = None
+            if C == 256 and with_ll:
+                hl = [g(t(a)) for a in synth.conv_params("m1l", C // 4, C, 1, 31)] + [g(t(a)) for a in synth.conv_params("m3l", 1, C // 4, 3, 31)]
+            levels.append((x, hp, hn, hl))
+        merged = ops.head_fused_gemm_multi_nograd(levels)
+        for (x, hp, hn, hl), m in zip(levels, merged):
+            one = ops.head_fused_gemm_nograd(x, hp, hn, hl)
+            used = 63 if hl is not None else 54          # (planes 63..80 of the 81-plane buffer are never written)
+            assert m["t"].shape == one["t"].shape and torch.equal(m["t"][:, :used], one["t"][:, :used]), "C=%d" % x.shape[1]
+        # completions from the merged items == the two-launch level
+        yl = None
+        for k, ((x, hp, hn, hl), m) in enumerate(zip(levels, merged)):
+            s = 4 - k
+            if hl is None and yl is None:
+                yl = g(t(synth.normal((B, 1, x.shape[2], x.shape[3]), "myl", 31)))
+            ref = ops.head_fused_level_nograd(x, hp, hn, scale=2.0 ** (s - 1), yl=None if hl is not None else yl, disp_scale=1.0 / 2 ** (s - 1),
+                                              clamp01=True, head_ll=hl, scale_ll=16.0)
+            yh, out, disp, yl_ll = ops.head_shiftsum_item_nograd(m, 2.0 ** (s - 1), 1.0 / 2 ** (s - 1), yl=None if hl is not None else yl, scale_ll=16.0)
+            assert torch.equal(yh, ref[0]) and torch.equal(out, ref[1]) and torch.equal(disp, ref[2])
+            if hl is not None:
+                assert torch.equal(yl_ll, ref[3])
+            yl = out
+    # a plane that is not a multiple of 4 pixels: the per-level fallback inside the entry point, same contract
+    x = g(t(synth.normal((1, 64, 3, 5), "mo", 31)))
+    hp = [g(t(a)) for a in synth.conv_params("o1p", 64, 64, 1, 31)] + [g(t(a)) for a in synth.conv_params("o3p", 3, 64, 3, 31)]
+    hn = [g(t(a)) for a in synth.conv_params("o1n", 64, 64, 1, 31)] + [g(t(a)) for a in synth.conv_params("o3n", 3, 64, 3, 31)]
+    both = ops.head_fused_gemm_multi_nograd([(x, hp, hn, None), (x, hp, hn, None)])
+    assert torch.equal(both[0]["t"], ops.head_fused_gemm_nograd(x, hp, hn)["t"]) and torch.equal(both[0]["t"], both[1]["t"])
+
+
+def test_dense_decoder_with_postponed_heads_equals_the_level_by_level_forward(dev):
+    """The dense KITTI decoder's inference forward postpones the first stage of levels 4..2 (one merged launch) at batches beyond the
+    chained-completion size: every output bit-identical to the level-by-level forward (fuse path forced per level)."""
+    from wavelet_monodepth_amd import ops
+    dec = _kitti_decoder(dev, seed=8)
+    feats = [f.to(dev) for f in kitti_feats(6, 96, 160, seed=8)]      # level 2: 6 x 24 x 40 = 5760 pixels (x 6 frames > the chained-completion size?)
+    with torch.no_grad():
+        old = ops._SHIFTSUM_CHAIN_MAX_PIXELS
+        ops._SHIFTSUM_CHAIN_MAX_PIXELS = 0            # neither decoder takes the chained completion: merged vs per-level first stages
+        try:
+            out = {k: v.clone() for k, v in dec(feats).items()}
+            saved = ops._HEAD_CHAIN_MULTI
+            ops._HEAD_CHAIN_MULTI = False
+            try:
+                ref = dec(feats)
+            finally:
+                ops._HEAD_CHAIN_MULTI = saved
+        finally:
+            ops._SHIFTSUM_CHAIN_MAX_PIXELS = old
+    assert set(out) == set(ref)
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), key_str(k)
+
+
 @pytest.mark.parametrize("C,H,W", [(256, 12, 40), (64, 9, 28), (128, 5, 7), (32, 6, 10)])
 def test_fused_head_level_with_the_low_pass_head_as_third_chain(dev, C, H, W):
     """Coarsest level (depth_decoder.py:104-106,126-136): the LL head C -> C/4 -> 1 rides in the fused launches as a third,

@@ -183,6 +183,7 @@ SIGNATURES = {
     "wmd_head3x3_fwd": (C.c_int, [C.POINTER(HeadArgs), C.c_void_p]),
     "wmd_head3x3_workspace_floats": (C.c_size_t, [C.POINTER(HeadArgs)]),
     "wmd_head_fused_fwd": (C.c_int, [C.POINTER(HeadFusedArgs), C.c_void_p]),
+    "wmd_head_fused_multi_fwd": (C.c_int, [C.POINTER(HeadFusedArgs), C.c_int, C.c_void_p]),
     "wmd_head_shiftsum_fwd": (C.c_int, [C.POINTER(HeadShiftsumArgs), C.c_void_p]),
     "wmd_head_shiftsum_chain_fwd": (C.c_int, [C.POINTER(HeadShiftsumArgs), C.c_int, C.c_void_p]),
     "wmd_head_level_supported": (C.c_int, [C.c_int]),

@@ -1119,6 +1119,23 @@ static bool plan_conv(const wmd_conv_args* g, ConvPlan* plan, bool have_ws, size
 
 using namespace wmd;
 
+extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream);
+
+extern "C" int wmd_head_fused_multi_fwd(const wmd_head_fused_args* levels, int n_levels, void* stream) {
+    if (!levels || n_levels < 1 || n_levels > 3) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_multi_fwd: 1..3 levels (got %d)", n_levels);
+    for (int k = 0; k < n_levels; ++k) {
+        const wmd_head_fused_args* g = &levels[k];
+        if (!g->x || !g->wp1 || !g->wp2 || !g->t) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_multi_fwd: level %d: null tensor pointer", k);
+        if (g->B <= 0 || g->H <= 0 || g->W <= 0) return fail(WMD_ERR_BAD_SHAPE, "wmd_head_fused_multi_fwd: level %d: B=%d H=%d W=%d", k, g->B, g->H, g->W);
+    }
+    if (head_chain_multi_launch(levels, n_levels, (hipStream_t)stream)) return check_launch("head_chain_multi_kernel");
+    for (int k = 0; k < n_levels; ++k) {      // a level the merged launch cannot take: the per-level launches, same planes
+        const int st = wmd_head_fused_fwd(&levels[k], stream);
+        if (st) return st;
+    }
+    return WMD_OK;
+}
+
 extern "C" int wmd_head_fused_fwd(const wmd_head_fused_args* g, void* stream) {
     if (!g) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: null args");
     if (!g->x || !g->wp1 || !g->wp2 || !g->t) return fail(WMD_ERR_BAD_ARG, "wmd_head_fused_fwd: null tensor pointer");

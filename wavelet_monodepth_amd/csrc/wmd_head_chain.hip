@@ -65,6 +65,7 @@ struct HeadChainArgs {
     const float* wp2;    // two packed [27, C, 1, 1] images
     float* t;            // [B, t_planes, plane]
     int plane, tiles, t_planes;
+    int C;               // (read by the merged launch only: which body a block range runs)
     float slope;
     const uint8_t* run_mask;   // optional [B, plane]: a block whose pixel run holds no set byte returns (wmd_head_fused_args.run_mask)
     // the coarsest level's low-pass chain (C = 256 only; wmd_head_fused_args.ll_wp1) rides in the blocks of side 0: W1_ll
@@ -150,7 +151,7 @@ __device__ __forceinline__ void chain_commit(const f32x4 (&wreg)[T::WV], const f
 // One block's work.  LLX = the block also carries the low-pass chain (side 0 of the C = 256 launch): compiled as a second body
 // so that every size stays a compile-time constant of its body.
 template <int C, int RS, int PG, int NT, int KC, bool LLX, int PD>
-__device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* lds) {
+__device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* lds, const int bx, const int side) {
     using T = HeadChainTile<C, RS, PG, NT, KC>;
     constexpr int MT = T::MT, KS = T::KS, XS = T::XS, PXB = T::PXB;
     constexpr int MTX = MT + (LLX ? 1 : 0);   // row tiles of the first product per wave
@@ -160,8 +161,7 @@ __device__ __forceinline__ void head_chain_body(const HeadChainArgs& a, float* l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = wave % RS, pg = wave / RS;   // channel slice, pixel group
     const int g = lane >> 4, lc = lane & 15;
-    const int side = blockIdx.y;
-    const int tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const int tile = bx % a.tiles, b = bx / a.tiles;   // (bx, side): blockIdx.x / .y of a level's own launch, or dealt by the merged one
     const int pix0 = tile * PXB, plane = a.plane;
     if (a.run_mask) {   // block-sparse levels: nothing downstream reads the tap-partials of a run without an active pixel
         static_assert(PXB <= T::NTH, "one mask byte per thread covers the block's pixel run");
@@ -352,11 +352,46 @@ __global__ __launch_bounds__(RS* PG * 64, (RS * PG >= 8 ? 3 : 1)) void head_chai
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     if constexpr (LLC) {
         if (blockIdx.y == 0) {
-            head_chain_body<C, RS, PG, NT, KC, true, PD>(a, lds);
+            head_chain_body<C, RS, PG, NT, KC, true, PD>(a, lds, blockIdx.x, 0);
             return;
         }
     }
-    head_chain_body<C, RS, PG, NT, KC, false, PD>(a, lds);
+    head_chain_body<C, RS, PG, NT, KC, false, PD>(a, lds, blockIdx.x, blockIdx.y);
+}
+
+// ---- round 6: the chained GEMMs of SEVERAL levels in ONE launch -------------------------------------------------------------
+// The coarse levels are too small to balance 256 CUs alone (5 760 / 23 040 / 92 160 pixels at config 2: block counts of 360 / 720 /
+// 1440 leave CUs idle through whole block times, profiles/r06_notes.md section 6), and a replayed graph runs its nodes one after
+// the other.  The heads of a level read only that level's trunk activation, so the dense decoder may postpone them: after
+// `upconv(2,1)` ONE launch runs the first stage of levels 4, 3 and 2 as consecutive block ranges (largest blocks first) and the
+// machine balances them against each other.  256-thread blocks throughout: the C = 256 level as 16-pixel blocks (RS = 4 waves
+// share a pixel group's channels).  Same per-pixel arithmetic as the per-level launches: bit-identical planes.
+struct HeadChainMulti {
+    HeadChainArgs lv[3];
+    int first[4];   // block ranges: level k owns [first[k], first[k + 1]) = (its B * tiles blocks of side 0, then of side 1)
+    int n;
+};
+constexpr int head_chain_multi_lds() {
+    int m = HeadChainTile<256, 4, 1, 1, 4>::LDS_FLOATS;
+    if (HeadChainTile<128, 1, 4, 1, 8>::LDS_FLOATS > m) m = HeadChainTile<128, 1, 4, 1, 8>::LDS_FLOATS;
+    if (HeadChainTile<64, 1, 4, 2, 16>::LDS_FLOATS > m) m = HeadChainTile<64, 1, 4, 2, 16>::LDS_FLOATS;
+    return m;
+}
+__global__ __launch_bounds__(256, 3) void head_chain_multi_kernel(const HeadChainMulti m) {
+    __shared__ __attribute__((aligned(16))) float lds[head_chain_multi_lds()];
+    int k = 0;
+    while (k + 1 < m.n && (int)blockIdx.x >= m.first[k + 1]) ++k;
+    const HeadChainArgs& a = m.lv[k];
+    const int v = (int)blockIdx.x - m.first[k], per_side = (m.first[k + 1] - m.first[k]) >> 1;
+    const int side = v >= per_side ? 1 : 0, bx = v - side * per_side;
+    if (a.C == 256) {
+        if (side == 0 && a.ll_wp1) head_chain_body<256, 4, 1, 1, 4, true, WMD_CHAIN_PD256>(a, lds, bx, 0);
+        else head_chain_body<256, 4, 1, 1, 4, false, WMD_CHAIN_PD256>(a, lds, bx, side);
+    } else if (a.C == 128) {
+        head_chain_body<128, 1, 4, 1, 8, false, WMD_CHAIN_PD128>(a, lds, bx, side);
+    } else {
+        head_chain_body<64, 1, 4, 2, 16, false, 1>(a, lds, bx, side);
+    }
 }
 
 template <int C, int RS, int PG, int NT, int KC, int PD>
@@ -375,13 +410,7 @@ static void launch_chain(const HeadChainArgs& a, int B, hipStream_t s) {
 
 // -> true when the chained form took the launch (C = 64 / 128 / 256, image planes of a multiple of 4 pixels; WMD_HEAD_CHAIN=0
 // keeps the FUSE form of conv_fwd_kernel)
-int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s) {
-    static const bool on = [] {
-        const char* e = getenv("WMD_HEAD_CHAIN");
-        return !(e && atoi(e) == 0);
-    }();
-    const long plane = (long)g->H * g->W;
-    if (!on || (plane & 3) || plane > (1L << 28) || (g->C != 64 && g->C != 128 && g->C != 256)) return 0;
+static HeadChainArgs head_chain_args(const wmd_head_fused_args* g, int t_planes, long plane, bool& with_ll) {
     HeadChainArgs a;
     a.x = g->x;
     a.wp1 = g->wp1;
@@ -393,7 +422,7 @@ int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s)
     a.t_planes = t_planes;
     a.slope = g->slope;
     a.run_mask = g->run_mask;
-    const bool with_ll = g->ll_wp1 && g->ll_wp2 && g->C == 256 && t_planes == 81 && !g->run_mask;
+    with_ll = g->ll_wp1 && g->ll_wp2 && g->C == 256 && t_planes == 81 && !g->run_mask;
     a.ll_wp1 = with_ll ? g->ll_wp1 : nullptr;
     a.ll_bias1 = with_ll ? g->ll_bias1 : nullptr;
     a.ll_wp2 = with_ll ? g->ll_wp2 : nullptr;
@@ -402,6 +431,19 @@ int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s)
     a.mid_off[0] = g->mid_off_p;
     a.mid_off[1] = g->mid_off_n;
     a.mid_off[2] = g->mid_off_ll;
+    a.C = g->C;
+    return a;
+}
+
+int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s) {
+    static const bool on = [] {
+        const char* e = getenv("WMD_HEAD_CHAIN");
+        return !(e && atoi(e) == 0);
+    }();
+    const long plane = (long)g->H * g->W;
+    if (!on || (plane & 3) || plane > (1L << 28) || (g->C != 64 && g->C != 128 && g->C != 256)) return 0;
+    bool with_ll = false;
+    HeadChainArgs a = head_chain_args(g, t_planes, plane, with_ll);
     const double pix = (double)g->B * plane;
     ProfScope prof("head_chain_kernel", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C), 4.0 * pix * (g->C + 54), s);
     // (pixel-tile / wave-count / chunk variants -- 64 to 256 pixels, 2 to 16 waves, channel split 1 / 2 / 4 / 8 -- all measured
@@ -424,6 +466,41 @@ int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s)
         else launch_chain<256, 4, 2, 1, 4, WMD_CHAIN_PD256>(a, g->B, s);
     }
     return with_ll ? 2 : 1;
+}
+
+// -> levels taken (n) or 0: the merged launch needs every level to be a chained width with planes of a multiple of 4 pixels, no
+// run mask and no training outputs (WMD_HEAD_CHAIN_MULTI=0 off)
+int head_chain_multi_launch(const wmd_head_fused_args* g, int n, hipStream_t s) {
+    static const bool on = [] {
+        const char* e = getenv("WMD_HEAD_CHAIN_MULTI");
+        const char* c = getenv("WMD_HEAD_CHAIN");
+        return !(e && atoi(e) == 0) && !(c && atoi(c) == 0);
+    }();
+    if (!on || n < 1 || n > 3) return 0;
+    HeadChainMulti m;
+    m.n = n;
+    m.first[0] = 0;
+    double flops = 0, bytes = 0;
+    for (int k = 0; k < n; ++k) {
+        const long plane = (long)g[k].H * g[k].W;
+        const int t_planes = g[k].t_planes ? g[k].t_planes : 54;
+        if ((plane & 3) || plane > (1L << 28) || (g[k].C != 64 && g[k].C != 128 && g[k].C != 256) || g[k].run_mask || g[k].mid_out || g[k].chain != 0)
+            return 0;
+        if (g[k].ll_wp1 && (g[k].C != 256 || t_planes != 81 || !g[k].ll_wp2)) return 0;
+        bool with_ll = false;
+        m.lv[k] = head_chain_args(&g[k], t_planes, plane, with_ll);
+        const int pxb = g[k].C == 256 ? 16 : (g[k].C == 128 ? 64 : 128);
+        m.lv[k].tiles = (int)((plane + pxb - 1) / pxb);
+        const long blocks = 2L * g[k].B * m.lv[k].tiles;
+        if (m.first[k] + blocks > (1L << 30)) return 0;
+        m.first[k + 1] = m.first[k] + (int)blocks;
+        const double pix = (double)g[k].B * plane;
+        flops += 2.0 * pix * (2.0 * g[k].C * g[k].C + 54.0 * g[k].C);
+        bytes += 4.0 * pix * (g[k].C + 54);
+    }
+    ProfScope prof("head_chain_multi_kernel", flops, bytes, s);
+    hipLaunchKernelGGL(head_chain_multi_kernel, dim3((unsigned)m.first[n]), dim3(256), 0, s, m);
+    return n;
 }
 
 }  // namespace wmd

@@ -81,6 +81,8 @@ __device__ __forceinline__ bool pad_coord(int& g, int n, int pad_mode) {
 // wmd_head_chain.hip: the chained-GEMM form of wmd_head_fused_fwd (chain = 0); false = not taken (unsupported shape / switched off)
 // -> 0 not taken, 1 taken, 2 taken together with the low-pass chain (wmd_head_fused_args.ll_wp1)
 int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s);
+// round 6: the chained first stages of up to three levels in ONE launch (0 = not taken; wmd_head_fused_multi_fwd)
+int head_chain_multi_launch(const wmd_head_fused_args* levels, int n, hipStream_t s);
 
 // wmd_head_stream.hip: the streaming form of wmd_head_level_fwd (C = 32, plain inference outputs); 0 = not taken
 int head_stream_launch(const wmd_head_level_args* g, hipStream_t s);

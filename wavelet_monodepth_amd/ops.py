@@ -966,6 +966,68 @@ def shiftsum_chain_supported(widths, finest_pixels=0):
             all(int(c) in (64, 128, 256) and not l.wmd_head_level_supported(int(c)) for c in widths) and int(widths[0]) == 256)
 
 
+def head_fused_gemm_multi_nograd(levels):
+    """The first stage of up to three levels in ONE launch (round 6, wmd_head_fused_multi_fwd): levels = [(x, head_p, head_n,
+    head_ll or None), ...] coarse to fine -> the same items head_fused_gemm_nograd returns, one per level (bit-identical planes).
+    The coarse levels cannot balance 256 CUs alone; together they do (profiles/r06_notes.md section 6)."""
+    l = _lib.lib()
+    n = len(levels)
+    arr = (_lib.HeadFusedArgs * n)()
+    items = []
+    for k, (x, head_p, head_n, head_ll) in enumerate(levels):
+        x = _c(x)
+        B, Cc, H, W = x.shape
+        (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
+        wp1, bias1 = stacked_pack([w1p, w1n], [b1p, b1n])
+        wp2 = _tap_partial_pack(w3p, w3n)
+        planes = 81 if head_ll is not None else 54
+        t = torch.empty((B, planes, H, W), device=x.device, dtype=torch.float32)
+        arr[k] = _lib.HeadFusedArgs(B=B, H=H, W=W, C=Cc, slope=0.1, x=ptr(x), wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), t=ptr(t),
+                                    chain=0, t_planes=planes)
+        keep = [x, wp1, bias1, wp2]
+        b3l = None
+        if head_ll is not None:
+            w1l, b1l, w3l, b3l = head_ll
+            wpl1, wpl2 = _ll_chain_pack(w1l, w3l)
+            b1l_c = _c(b1l.detach())
+            arr[k].ll_wp1, arr[k].ll_bias1, arr[k].ll_wp2 = ptr(wpl1), ptr(b1l_c), ptr(wpl2)
+            keep += [wpl1, wpl2, b1l_c]
+        items.append(dict(t=t, B=B, H=H, W=W, b3p=b3p, b3n=b3n, b3l=b3l, has_ll=head_ll is not None, keep=keep))
+    check(l.wmd_head_fused_multi_fwd(arr, n, current_stream()), "wmd_head_fused_multi_fwd")
+    return items
+
+
+def head_shiftsum_item_nograd(item, scale, disp_scale, yl=None, scale_ll=1.0, clamp01=True):
+    """Completes ONE level from an item of head_fused_gemm[_multi]_nograd (wmd_head_shiftsum_fwd): -> (yh [B,1,3,H,W], out, disp,
+    yl_ll or None).  yl: the level's low-pass input (None for the level whose item carries the low-pass head)."""
+    l = _lib.lib()
+    B, H, W = item["B"], item["H"], item["W"]
+    dev = item["t"].device
+    yh = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+    out = torch.empty((B, 1, 2 * H, 2 * W), device=dev, dtype=torch.float32)
+    disp = torch.empty_like(out)
+    yl_ll = torch.empty((B, 1, H, W), device=dev, dtype=torch.float32) if item["has_ll"] else None
+    if yl_ll is None and yl is None:
+        raise _lib.WmdError("head_shiftsum_item_nograd: the level needs its low-pass input (yl) or the low-pass head")
+    yl_c = _c(yl) if (yl is not None and yl_ll is None) else None
+    g = _lib.HeadShiftsumArgs(B=B, H=H, W=W, pad_mode=PAD["reflect"], scale=float(scale), t=ptr(item["t"]), bias_p=ptr(item["b3p"]),
+                              bias_n=ptr(item["b3n"]), yh=ptr(yh), yl=ptr(yl_c), out=ptr(out), disp=ptr(disp), disp_scale=float(disp_scale),
+                              clamp01=int(clamp01), bias_ll=ptr(item["b3l"]) if yl_ll is not None else None, scale_ll=float(scale_ll),
+                              yl_out=ptr(yl_ll))
+    check(l.wmd_head_shiftsum_fwd(C.byref(g), current_stream()), "wmd_head_shiftsum_fwd")
+    return yh.unsqueeze(1), out, disp, yl_ll
+
+
+_HEAD_CHAIN_MULTI = os.environ.get("WMD_HEAD_CHAIN_MULTI", "1") != "0"   # 0: every level's first stage as a launch of its own
+
+
+def head_chain_multi_supported(widths):
+    """Dense inference: may the first stages of these levels (coarse to fine) be postponed and run as ONE launch?"""
+    l = _lib.lib()
+    return (_HEAD_CHAIN_MULTI and not _TWO_LAUNCH_HEAD and 2 <= len(widths) <= 3 and _LL_FOLD and _LL_MERGE and _HEAD_CHAIN_ON and
+            all(int(c) in (64, 128, 256) and not l.wmd_head_level_supported(int(c)) for c in widths))
+
+
 def head_fused_gemm_nograd(x, head_p, head_n, head_ll=None):
     """First launch of the two-launch head form alone (wmd_head_fused_fwd: 1x1 -> LeakyReLU -> tap-partial planes, the coarsest
     level's low-pass chain riding along): -> what head_shiftsum_chain_nograd needs to complete the level later."""
