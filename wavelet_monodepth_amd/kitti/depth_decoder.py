@@ -357,6 +357,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
             all((input_features[k].shape[2] * input_features[k].shape[3]) % 4 == 0 for k in (3, 2, 1)) and \
             bool(ops._lib.lib().wmd_head_level_supported(int(self.num_ch_dec[1])))
         deferred = []
+        chain_multi = chain and edge is None and ops.head_chain_multi_supported([int(self.num_ch_dec[k]) for k in (4, 3, 2)]) and \
+            all((input_features[k].shape[2] * input_features[k].shape[3]) % 4 == 0 for k in (3, 2, 1))
         for i in range(4, 0, -1):
             if i == 4 and edge is not None:
                 x = self.convs[("upconv", 4, 0)](x, x1_pre=edge.pre())      # ReLU (+ affine) of the encoder's last block on load
@@ -381,7 +383,12 @@ class DepthWaveProgressiveDecoder(nn.Module):
                 continue
             if chain and i >= 2:
                 hd = lambda j: (lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias))(self.convs[("waveconv", i, j)])
-                pending.append(ops.head_fused_gemm_nograd(x, hd(1), hd(-1), hd(0) if i == 4 else None))
+                if chain_multi:      # round 6: the three first stages as ONE launch behind upconv(2,1), too (two graph nodes fewer)
+                    deferred.append((x, hd(1), hd(-1), hd(0) if i == 4 else None))
+                    if i == 2:
+                        pending = ops.head_fused_gemm_multi_nograd(deferred)
+                else:
+                    pending.append(ops.head_fused_gemm_nograd(x, hd(1), hd(-1), hd(0) if i == 4 else None))
                 if i == 2:
                     done = ops.head_shiftsum_chain_nograd(pending, [2.0 ** (k - 1) for k in (4, 3, 2)], [1.0 / 2 ** (k - 1) for k in (4, 3, 2)],
                                                           scale_ll=2.0 ** 4)
