@@ -786,7 +786,7 @@ def roofline(dec, feats, steps):
     # the HBM-bound kernel of the path: the Haar synthesis is fused into the head kernels, whose epilogues write
     # the planes it defines -- 8 B read + 4 B written per output pixel (+ 4 B for the disparity plane), 163 200 output pixels
     # per frame; reported against the time of the launches that contain it
-    idwt_recs = [r for r in recs if r["kernel"].startswith(("head_level_kernel", "head_shiftsum_kernel", "idwt_haar"))]
+    idwt_recs = [r for r in recs if r["kernel"].startswith(("head_level_kernel", "head_stream_kernel", "head_shiftsum", "idwt_haar"))]
     idwt_bytes = 16.0 * 163200 * feats[0].shape[0] * steps
     idwt_ms = sum(r["ms"] for r in idwt_recs)
     heads = [r for r in recs if r not in convs and not r["kernel"].startswith("conv_splitk")]

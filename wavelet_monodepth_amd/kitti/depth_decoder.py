@@ -343,22 +343,20 @@ class DepthWaveProgressiveDecoder(nn.Module):
         elu = ("elu", 0.0) if (torch.is_grad_enabled() and gated_backward_allowed(self)) else None
         self._gated = elu is not None
         edge = getattr(self, "_edge", None)
-        # dense inference: levels 4..2 launch only their chained GEMMs here, ONE launch after level 2's completes all three (round 5:
-        # level k's synthesis output is level k+1's low-pass input, pixel for pixel -- ops.head_shiftsum_chain_nograd)
-        chain = (not overlap) and (not torch.is_grad_enabled()) and self.fuse_heads and \
-            ops.shiftsum_chain_supported([int(self.num_ch_dec[k]) for k in (4, 3, 2)],
-                                         input_features[1].shape[0] * input_features[1].shape[2] * input_features[1].shape[3]) and \
+        # dense inference: the heads of a level read only that level's trunk activation, so levels 4..2 are POSTPONED until
+        # upconv(2,1) is done: ONE launch runs their chained first stages (round 6, ops.head_fused_gemm_multi_nograd: alone none of
+        # these levels fills 256 CUs; config 2, batch 12: 0.082 -> 0.069 ms, one frame 0.202 -> 0.177 ms), ONE launch completes all
+        # three (round 5, ops.head_shiftsum_chain_nograd: level k's synthesis output is level k+1's low-pass input, pixel for pixel).
+        # Without the merged launch (WMD_HEAD_CHAIN_MULTI=0, odd plane sizes) every level launches its first stage in place and the
+        # chained completion is used up to WMD_SHIFTSUM_CHAIN_MAX_PIXELS only (it then reads planes that have left the caches).
+        widths = [int(self.num_ch_dec[k]) for k in (4, 3, 2)]
+        plain = (not overlap) and (not torch.is_grad_enabled()) and self.fuse_heads and \
             bool(ops._lib.lib().wmd_head_level_supported(int(self.num_ch_dec[1])))
-        pending = []
-        # round 6, larger batches: the first stages of levels 4..2 are postponed until upconv(2,1) is done and run as ONE launch
-        # (ops.head_fused_gemm_multi_nograd: alone none of these levels fills 256 CUs), then one completion per level
-        multi = (not chain) and (not overlap) and (not torch.is_grad_enabled()) and self.fuse_heads and edge is None and \
-            ops.head_chain_multi_supported([int(self.num_ch_dec[k]) for k in (4, 3, 2)]) and \
-            all((input_features[k].shape[2] * input_features[k].shape[3]) % 4 == 0 for k in (3, 2, 1)) and \
-            bool(ops._lib.lib().wmd_head_level_supported(int(self.num_ch_dec[1])))
-        deferred = []
-        chain_multi = chain and edge is None and ops.head_chain_multi_supported([int(self.num_ch_dec[k]) for k in (4, 3, 2)]) and \
+        chain_multi = plain and edge is None and ops.head_chain_multi_supported(widths) and \
             all((input_features[k].shape[2] * input_features[k].shape[3]) % 4 == 0 for k in (3, 2, 1))
+        chain = plain and ops.shiftsum_chain_supported(
+            widths, 0 if chain_multi else input_features[1].shape[0] * input_features[1].shape[2] * input_features[1].shape[3])
+        pending, deferred = [], []
         for i in range(4, 0, -1):
             if i == 4 and edge is not None:
                 x = self.convs[("upconv", 4, 0)](x, x1_pre=edge.pre())      # ReLU (+ affine) of the encoder's last block on load
@@ -366,24 +364,9 @@ class DepthWaveProgressiveDecoder(nn.Module):
                 x = self.convs[("upconv", i, 0)](x, x1_gate=elu if i < 4 else None, grad_is_dz=elu is not None)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip=skip, up=2, x1_gate=elu, grad_is_dz=elu is not None)  # fused upsample + concat
-            if multi and i >= 2:
-                hd = lambda j: (lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias))(self.convs[("waveconv", i, j)])
-                deferred.append((x, hd(1), hd(-1), hd(0) if i == 4 else None))
-                if i == 2:
-                    items = ops.head_fused_gemm_multi_nograd(deferred)
-                    for k, it in zip((4, 3, 2), items):
-                        yh, out, disp, yl_ll = ops.head_shiftsum_item_nograd(it, 2.0 ** (k - 1), 1.0 / 2 ** (k - 1), yl=None if k == 4 else yl,
-                                                                             scale_ll=2.0 ** 4)
-                        self.outputs[("wavelets", k - 1, "LL")] = yl_ll if k == 4 else yl
-                        self.outputs[("wavelets", k - 1, "LH")] = yh[:, :, 0]
-                        self.outputs[("wavelets", k - 1, "HL")] = yh[:, :, 1]
-                        self.outputs[("wavelets", k - 1, "HH")] = yh[:, :, 2]
-                        self.outputs[("disp", k - 1)] = disp
-                        yl = out
-                continue
             if chain and i >= 2:
                 hd = lambda j: (lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias))(self.convs[("waveconv", i, j)])
-                if chain_multi:      # round 6: the three first stages as ONE launch behind upconv(2,1), too (two graph nodes fewer)
+                if chain_multi:
                     deferred.append((x, hd(1), hd(-1), hd(0) if i == 4 else None))
                     if i == 2:
                         pending = ops.head_fused_gemm_multi_nograd(deferred)
