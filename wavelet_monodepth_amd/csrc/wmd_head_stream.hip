@@ -8,20 +8,27 @@
 // but cut differently, because of what round 5 measured on that kernel (58 us for 30 us of MFMA work at its own 1.6x halo):
 // five barriers per 4 x 40 tile with nothing overlapping them, `mid` through LDS, and a 6 x 42 patch per 160 pixels.
 //
-//   * A block owns a STRIP SEGMENT: 32 columns x TH rows (TH chosen by the host, 24 at 96 x 320 x 12) and walks its
-//     (TH + 2) x 34 halo patch as ONE flattened sequence of positions, 64 per step: the halo costs 34/32 x (TH+2)/TH = 1.15x.
-//   * Four GEMM waves, each alone with 16 positions of the step: the wave stages ITS OWN x slice by LDS-DMA (32 channels x 16
-//     positions, laid out as the MFMA B fragments it reads back: no barrier, no bank conflict, three buffers deep), runs the
+//   * A block owns a STRIP SEGMENT: 32 columns x TH rows (TH chosen by the host, 48 at 96 x 320 x 12 = one block per CU) and walks
+//     its (TH + 2) x 34 halo patch as ONE flattened sequence of positions, 128 per step: the halo costs 34/32 x (TH+2)/TH = 1.1x.
+//   * Eight GEMM waves (two per SIMD), each alone with 16 positions of the step: the wave stages ITS OWN x slice by LDS-DMA (32
+//     channels x 16 positions, laid out as the MFMA B fragments it reads back: no barrier, no bank conflict, three buffers deep;
+//     reflect padding folded incrementally: the lane's patch coordinates advance by a compare-and-carry per step), runs the
 //     first product with the WEIGHTS as the A operand -- D[mid channel][position] -- so that its accumulator registers ARE the
 //     A operand of the second product (the head_chain_kernel trick: K-steps run over (m, i), the W3' fragment is gathered to
-//     match), applies bias (as the accumulators' initial value) + LeakyReLU in registers, and leaves D2[position][tap row] as
-//     16-byte LDS writes into a RING of tap-partial planes.  `mid` never touches LDS; all weights live in registers (64 + 16).
-//   * Two EPILOGUE waves run one step behind on the ring: 32 anchors x 2 sides per wave, 27 LDS reads per lane from three row
-//     bases (compile-time offsets), bias, sigmoid, the two sides meet through a lane shuffle, Haar butterfly, clamp, stores.
+//     match), applies bias (as the accumulators' initial value) + LeakyReLU in registers (4 v_mul + 4 v_max per tile in asm:
+//     fmaxf costs a canonicalising third), and leaves D2[position][tap row] as 16-byte LDS writes into a RING of tap-partial
+//     planes.  `mid` never touches LDS; all weights live in registers (64 + 16).
+//   * Four EPILOGUE waves (one per SIMD) run one step behind on the ring: 32 anchors x 2 sides per wave, 27 LDS reads per lane
+//     from three row bases (compile-time offsets), bias, sigmoid, the two sides meet through a lane shuffle, Haar butterfly, clamp,
+//     stores.
 //   * ONE barrier per step; GEMM of step s overlaps the epilogue of step s-1 and the DMA of step s+2.
-// LDS: ring 54 planes x 228 floats (2 steps + the reach of an anchor, 70 positions; plane stride == 4 mod 32: the 8 lanes of a
-// ds_write_b128 service group hit 32 distinct banks) + 3 x 4 x 2 KB of x slices = 72 KB -> two blocks per CU.
-// yh_mask / mid_out / sig_* (sparse and training forms) stay on head_level_kernel.
+// Every vector instruction of a GEMM wave comes out of the matrix rate (fp32 MFMA and the vector ALU are one resource): a step is
+// 64 MFMAs + 60 VALU + 58 SALU + 16 LDS + 8 DMA instructions (329 before the diet).  Measured (profiles/r06_notes.md section 2):
+// 64.5 (head_level_kernel) -> 57.1 (two 6-wave blocks per CU) -> 55.3 (diet) -> 49.8 us (one 12-wave block per CU: two GEMM
+// waves per SIMD hide each other's LDS / barrier waits, the epilogue waves load the four SIMDs evenly).
+// LDS: ring 54 planes x 356 floats (2 steps + the reach of an anchor, 70 positions; plane stride == 4 mod 32: the 8 lanes of a
+// ds_write_b128 service group hit 32 distinct banks) + 3 x 8 x 2 KB of x slices = 126 KB -> one block per CU.
+// yh_mask / mid_out / sig_* (sparse and training forms) and non-reflect padding stay on head_level_kernel.
 #include <algorithm>
 #include <cstdlib>
 #include "wmd_internal.h"
@@ -35,12 +42,15 @@ __device__ __forceinline__ void hs_dma4(__amdgpu_buffer_rsrc_t r, lds_ptr_t dst,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 4, voff, soff, 0, 0);
 }
 
+#ifndef WMD_HS_NG
+#define WMD_HS_NG 8      // GEMM waves per block: 8 (+ 4 epilogue waves) = one 12-wave block per CU, two GEMM waves and one epilogue wave per SIMD; 4 = rounds 6a (two 6-wave blocks per CU)
+#endif
 constexpr int HS_C = 32, HS_TW = 32, HS_PW = HS_TW + 2;
-constexpr int HS_NG = 4, HS_NE = 2;                             // GEMM waves, epilogue waves
+constexpr int HS_NG = WMD_HS_NG, HS_NE = HS_NG / 2;             // GEMM waves, epilogue waves
 constexpr int HS_S = HS_NG * 16;                                // positions per step
 constexpr int HS_L = 2 * HS_PW + 2;                             // an anchor's taps reach L positions ahead
 constexpr int HS_RING = ((2 * HS_S + HS_L + 15) / 16) * 16;     // live span: the step being written + the step being read + L
-constexpr int HS_TS = 228;                                      // plane stride: >= RING + 4 (mirror of slots 0..3), == 4 (mod 32)
+constexpr int HS_TS = ((HS_RING + 20 - 4 + 31) / 32) * 32 + 4;   // plane stride: >= RING + 4 (mirror of slots 0..3) + 16 spare, == 4 (mod 32)
 constexpr int HS_XW = HS_C * 16;                                // dwords of one wave's x slice of one step
 static_assert(HS_TS >= HS_RING + 4 && HS_TS % 32 == 4, "ring plane stride");
 static_assert(HS_NE * 32 == HS_S, "two sides of 32 anchors per epilogue wave cover a step");
@@ -102,6 +112,27 @@ __device__ __forceinline__ void hs_write_tiles(unsigned a0, unsigned a1, const f
         : : "v"(a0), "v"(a1), "v"(p0), "v"(p1), "v"(n0), "v"(n1), "n"(OFF) : "memory");
 }
 
+// LeakyReLU of one accumulator tile, max(v, slope v) for 0 <= slope <= 1, as 4 v_mul + 4 v_max: `fmaxf` costs a third instruction
+// per value (the compiler canonicalises the MFMA result with `v_max x, x` first), and every vector instruction of a GEMM wave comes
+// out of the matrix rate.  FIRST = the block directly behind the first product: the MFMA results it reads need their wait states
+// (the hazard recognizer does not look into asm); every block ends with the wait states an MFMA needs before it may read `o`.
+template <bool FIRST>
+__device__ __forceinline__ void hs_leaky4(const f32x4& v, float slope, float (&o)[4]) {
+    if constexpr (FIRST) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    asm volatile(
+        "v_mul_f32 %0, %8, %4\n\t"
+        "v_mul_f32 %1, %8, %5\n\t"
+        "v_mul_f32 %2, %8, %6\n\t"
+        "v_mul_f32 %3, %8, %7\n\t"
+        "v_max_f32 %0, %0, %4\n\t"
+        "v_max_f32 %1, %1, %5\n\t"
+        "v_max_f32 %2, %2, %6\n\t"
+        "v_max_f32 %3, %3, %7\n\t"
+        "s_nop 1"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(slope));
+}
+
 // (second launch bound = waves per SIMD: two 6-wave blocks per CU -> 3, i.e. <= 168 VGPRs)
 __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(const wmd_head_level_args a, const HeadStreamGeom gm) {
     constexpr int C = HS_C, PW = HS_PW, TW = HS_TW, S = HS_S, L = HS_L, RING = HS_RING, TS = HS_TS, XW = HS_XW;
@@ -154,25 +185,29 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
             const int x0 = strip * TW, y0 = seg * gm.TH;
             const int th = min(gm.TH, H - y0);
             const int npu = (th + 2) * PW, nsteps = (npu + S - 1) / S;
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.x + (size_t)b * C * plane), 0, (int)(C * plane * 4), 0x00020000);
             const unsigned chq = (unsigned)(plane * 16);   // byte stride of four channels
 
-            // stage this wave's slice of step s: 8 LDS-DMA instructions of [4 channels][16 positions]
-            auto issue = [&](int s, float* buf) {
-                const int p = s * S + wave * 16 + lc;
-                const int py = p / PW, px = p - py * PW;
-                int gy = y0 - 1 + py, gx = x0 - 1 + px;
-                bool ok = p < npu;
-                ok = pad_coord(gy, H, a.pad_mode) && ok;
-                ok = pad_coord(gx, W, a.pad_mode) && ok;
-                ok = ok && gy >= 0 && gx >= 0 && gy < H && gx < W;   // strip / segment overhang
-                gy = min(max(gy, 0), H - 1);
-                gx = min(max(gx, 0), W - 1);
-                const unsigned off = ok ? (unsigned)(((size_t)g * plane + (size_t)gy * W + gx) * 4) : 0x80000000u;   // out of range -> 0
+            // stage this wave's slice of the NEXT step in sequence: 8 LDS-DMA instructions of [4 channels][16 positions].  The calls
+            // come strictly in step order, so the lane's patch coordinates advance incrementally ((py, px) += S positions: one
+            // compare-and-carry instead of a division per step), and the padding is the heads' reflect padding folded by min / abs
+            // (other modes stay on head_level_kernel): ~18 vector instructions per step where the generic form had ~45 and a dozen
+            // scalar branches -- every one of them comes out of the matrix rate (fp32 MFMA and the vector ALU are one resource).
+            int ipy = (wave * 16 + lc) / PW, ipx = (wave * 16 + lc) % PW;
+            const unsigned gch = (unsigned)g * (unsigned)(plane * 4);
+            auto issue = [&](float* buf) {
+                const int gy = y0 - 1 + ipy, gx = x0 - 1 + ipx;
+                const int ay = gy < 0 ? -gy : gy, ax = gx < 0 ? -gx : gx;
+                const int ry = min(ay, 2 * H - 2 - ay), rx = min(ax, 2 * W - 2 - ax);     // reflect: -1 -> 1, n -> n - 2
+                const bool ok = ipy < th + 2 && rx >= 0;                                   // beyond the patch / strip overhang -> 0
+                const unsigned off = ok ? gch + (unsigned)(ry * W + rx) * 4u : 0x80000000u;
                 float* dst = buf + wave * XW;
 #pragma unroll
-                for (int q = 0; q < KS; ++q) hs_dma4(rx, (lds_ptr_t)(dst + q * 64), off, (unsigned)q * chq);
+                for (int q = 0; q < KS; ++q) hs_dma4(rx_, (lds_ptr_t)(dst + q * 64), off, (unsigned)q * chq);
+                ipx += S % PW;
+                ipy += S / PW;
+                if (ipx >= PW) ipx -= PW, ipy += 1;
             };
 
             // ring write addresses of this lane (bytes): tap row lc (j = 0) and 16 + lc (j = 1) at slot 4g of the group; the j = 1
@@ -191,7 +226,7 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
                 if (s + 1 < nsteps) hs_read_slice<KS>(hs_lds_addr(cur + wave * XW + lane), xf);   // the next slice's 8 may stay in flight
                 else hs_read_slice<0>(hs_lds_addr(cur + wave * XW + lane), xf);
 #endif
-                if (s + 2 < nsteps && !HS_DBG_ON(2)) issue(s + 2, nxt2);
+                if (s + 2 < nsteps && !HS_DBG_ON(2)) issue(nxt2);
                 f32x4 acc[2][MR];
 #pragma unroll
                 for (int sd = 0; sd < 2; ++sd)
@@ -211,19 +246,25 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
                 for (int sd = 0; sd < 2; ++sd)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc2[sd][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!HS_DBG_ON(4))
+                if (!HS_DBG_ON(4)) {
+                    float mid[2][MR][4];
 #pragma unroll
-                for (int m = 0; m < MR; ++m)
+                    for (int sd = 0; sd < 2; ++sd)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int sd = 0; sd < 2; ++sd) {
-                            const float v = acc[sd][m][i];
-                            const float mid = fmaxf(v, v * slope);   // LeakyReLU for 0 <= slope <= 1 (host check)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc2[sd][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mid, w2f[sd][j][m * 4 + i], acc2[sd][j], 0, 0, 0);
+                        for (int m = 0; m < MR; ++m) {
+                            if (sd == 0 && m == 0) hs_leaky4<true>(acc[sd][m], slope, mid[sd][m]);
+                            else hs_leaky4<false>(acc[sd][m], slope, mid[sd][m]);
                         }
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    acc2[sd][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mid[sd][m][i], w2f[sd][j][m * 4 + i], acc2[sd][j], 0, 0, 0);
+                }
                 // D2[position 4g + i][tap row 16j + lc] -> ring plane (side, row), 4 consecutive slots
                 const int slot0 = (s * S + wave * 16) % RING;
 #ifdef HS_CWRITE
@@ -251,8 +292,8 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
                 hs_barrier();
             };
 
-            issue(0, xs0);
-            if (nsteps > 1) issue(1, xs1);
+            issue(xs0);
+            if (nsteps > 1) issue(xs1);
             for (int s = 0; s < nsteps; s += 3) {
                 step(s, xs0, xs2);
                 if (s + 1 < nsteps) step(s + 1, xs1, xs0);
@@ -363,7 +404,7 @@ static int head_stream_pick_th(int B, int H, int strips) {
         const long units = (long)B * strips * segs;
         const long per_cu = (units + kNumCU - 1) / kNumCU;
         const double steps = ((th + 2) * HS_PW + HS_S - 1) / HS_S + 4;
-        const double f = (double)(per_cu / 2) * 1.8 + (double)(per_cu % 2);   // pairs of co-resident blocks, then a lone one
+        const double f = HS_NG > 4 ? (double)per_cu : (double)(per_cu / 2) * 1.8 + (double)(per_cu % 2);   // pairs of co-resident blocks, then a lone one
         const double c = steps * f;
         if (c < best - 1e-9) best = c, best_th = th;
     }
@@ -376,13 +417,13 @@ int head_stream_launch(const wmd_head_level_args* g, hipStream_t s) {
         const char* e = getenv("WMD_HEAD_STREAM");
         return !(e && atoi(e) == 0);
     }();
-    if (!on || g->C != HS_C || g->yh_mask || g->mid_out || g->sig_p || g->sig_n) return 0;
+    if (!on || g->C != HS_C || g->yh_mask || g->mid_out || g->sig_p || g->sig_n || g->pad_mode != WMD_PAD_REFLECT) return 0;
     if (!(g->slope >= 0.f && g->slope <= 1.f)) return 0;
     // small maps stay on the one-shot tile kernel: a streaming block needs ~5 steps to fill and drain its pipeline (2 x 12 x 40:
     // 17.1 vs 13.5 us, one 96 x 320 frame: 17.2 vs 15.2 us)
     static const long min_pixels = [] {
         const char* e = getenv("WMD_HEAD_STREAM_MIN_PIXELS");
-        return e ? atol(e) : 100000L;
+        return e ? atol(e) : 0L;
     }();
     if ((long)g->B * g->H * g->W < min_pixels) return 0;
     HeadStreamGeom gm;
@@ -408,7 +449,7 @@ int head_stream_launch(const wmd_head_level_args* g, hipStream_t s) {
         }
         prof.mfma(2.0 * pos * g->B * gm.strips * 2.0 * (g->C * g->C + 32.0 * g->C));
     }
-    const dim3 grid((unsigned)std::min(gm.nunits, 2 * kNumCU));
+    const dim3 grid((unsigned)std::min(gm.nunits, (HS_NG > 4 ? 1 : 2) * kNumCU));
     hipLaunchKernelGGL(head_stream_kernel, grid, dim3((HS_NG + HS_NE) * 64), 0, s, *g, gm);
     return 1;
 }
