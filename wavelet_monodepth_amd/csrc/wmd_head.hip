@@ -20,6 +20,12 @@
 
 namespace wmd {
 
+// sigmoid of the completion kernels (round 6): v_exp_f32 + v_rcp_f32 (1 ulp each, ~2e-7 on the value) instead of expf + an IEEE
+// division (~60 instructions for 7 sigmoids per pixel in kernels that are made of latency and instruction issue); the per-level and
+// the chained completion share it, so their outputs stay bit-identical to each other
+__device__ __forceinline__ float fast_sigmoid(float h) { return __builtin_amdgcn_rcpf(1.f + __expf(-h)); }
+
+
 constexpr int HT_H = 16, HT_W = 32, H_CK = 8, H_TT = 128;  // H_TT threads cover the tile once (4 px each)
 constexpr int H_PH = HT_H + 2;        // 18 patch rows
 constexpr int H_PWV = HT_W + 2;       // 34 valid patch columns
@@ -345,7 +351,7 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
                     sp += okf[t] * vp[co * 9 + t];
                     sn += okf[t] * vn[co * 9 + t];
                 }
-                const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
+                const float a1 = fast_sigmoid(sp), a2 = fast_sigmoid(sn);
                 yh[co] = in_mask ? a.scale * a1 - a.scale * a2 : 0.f;
                 if (a.sig_p && live) {   // training forward: what the heads' backward multiplies by
                     a.sig_p[(b * 3 + co) * plane + (size_t)y * W + x] = a1;
@@ -362,9 +368,10 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
             float sl = a.bias_ll ? a.bias_ll[0] : 0.f;
 #pragma unroll
             for (int t = 0; t < 9; ++t) sl += okf[t] * tb[(size_t)(54 + t) * plane + off[t]];
-            l = a.scale_ll / (1.f + expf(-sl));
+            const float sgl = fast_sigmoid(sl);
+            l = a.scale_ll * sgl;
             if (live) a.yl_out[i] = l;
-            if (live && a.sig_ll) a.sig_ll[i] = 1.f / (1.f + expf(-sl));
+            if (live && a.sig_ll) a.sig_ll[i] = sgl;     // (what the backward multiplies by: the value the forward used)
         } else if (a.yl) {
             l = a.yl[i];
         }
@@ -418,6 +425,7 @@ __global__ void head_shiftsum_kernel(const wmd_head_shiftsum_args a) {
 struct ShiftsumChainArgs {
     wmd_head_shiftsum_args lv[3];
     int n;
+    int by0, bx0;   // tile of the coarsest level (by0 * bx0 == 16)
 };
 
 // one coefficient pixel of one level: gathers, bias, sigmoid, combine; -> yh[3] (stored), the low-pass value l (from yl_out's head,
@@ -452,7 +460,7 @@ __device__ __forceinline__ void shiftsum_pixel(const wmd_head_shiftsum_args& a, 
             sp += okf[t] * vp[co * 9 + t];
             sn += okf[t] * vn[co * 9 + t];
         }
-        const float a1 = 1.f / (1.f + expf(-sp)), a2 = 1.f / (1.f + expf(-sn));
+        const float a1 = fast_sigmoid(sp), a2 = fast_sigmoid(sn);
         yh[co] = a.scale * a1 - a.scale * a2;
         a.yh[(b * 3 + co) * plane + (size_t)y * W + x] = yh[co];
     }
@@ -461,7 +469,7 @@ __device__ __forceinline__ void shiftsum_pixel(const wmd_head_shiftsum_args& a, 
         float sl = a.bias_ll ? a.bias_ll[0] : 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) sl += okf[t] * tb[(size_t)(54 + t) * plane + off[t]];
-        l = a.scale_ll / (1.f + expf(-sl));
+        l = a.scale_ll * fast_sigmoid(sl);
         a.yl_out[i] = l;
     } else if (!have_l_in && a.yl) {
         l = a.yl[i];
@@ -488,9 +496,12 @@ __device__ __forceinline__ void shiftsum_pixel(const wmd_head_shiftsum_args& a, 
 }
 
 __global__ __launch_bounds__(256) void head_shiftsum_chain_kernel(const ShiftsumChainArgs c) {
-    __shared__ float low[2][16 * 16];     // low-pass tiles handed from level k to level k + 1: 8 x 8, then 16 x 16
+    __shared__ float low[2][256];     // low-pass tiles handed from level k to level k + 1
+    // tile of the coarsest level: by0 x bx0 pixels (16 of them), doubling per level up to 256 at the third.  Round 6: 2 x 8 instead
+    // of 4 x 4 -- the finest level's 8 x 32 tile reads and writes whole 128-byte rows where the 16 x 16 one touched 64-byte halves
+    const int by0 = c.by0, bx0 = c.bx0;
     const int H0 = c.lv[0].H, W0 = c.lv[0].W;
-    const int tiles_x = (W0 + 3) / 4, tiles_y = (H0 + 3) / 4;
+    const int tiles_x = (W0 + bx0 - 1) / bx0, tiles_y = (H0 + by0 - 1) / by0;
     int t = blockIdx.x;
     const int tx = t % tiles_x;
     t /= tiles_x;
@@ -498,16 +509,16 @@ __global__ __launch_bounds__(256) void head_shiftsum_chain_kernel(const Shiftsum
     const size_t b = t / tiles_y;
     const int tid = threadIdx.x;
     for (int k = 0; k < c.n; ++k) {
-        const int side = 4 << k;                       // the tile's edge at level k
-        if (tid < side * side) {
-            const int py = tid / side, px = tid % side;
-            const int y = ty * side + py, x = tx * side + px;
+        const int sy = by0 << k, sx = bx0 << k;        // the tile at level k
+        if (tid < sy * sx) {
+            const int py = tid / sx, px = tid % sx;
+            const int y = ty * sy + py, x = tx * sx + px;
             if (y < c.lv[k].H && x < c.lv[k].W) {
                 float v[4];
-                shiftsum_pixel(c.lv[k], b, y, x, k > 0, k > 0 ? low[(k - 1) & 1][py * side + px] : 0.f, v);
+                shiftsum_pixel(c.lv[k], b, y, x, k > 0, k > 0 ? low[(k - 1) & 1][py * sx + px] : 0.f, v);
                 if (k + 1 < c.n) {
                     float* nl = low[k & 1];
-                    const int ns = side * 2;
+                    const int ns = sx * 2;
                     nl[(2 * py) * ns + 2 * px] = v[0];
                     nl[(2 * py) * ns + 2 * px + 1] = v[1];
                     nl[(2 * py + 1) * ns + 2 * px] = v[2];
@@ -606,7 +617,13 @@ extern "C" int wmd_head_shiftsum_chain_fwd(const wmd_head_shiftsum_args* levels,
         c.lv[k] = g;
     }
     for (int k = n_levels; k < 3; ++k) c.lv[k] = levels[0];
-    const int tiles = ((levels[0].W + 3) / 4) * ((levels[0].H + 3) / 4);
+    static const int square = [] {
+        const char* e = getenv("WMD_SHIFTSUM_CHAIN_SQUARE");
+        return e ? atoi(e) : 0;
+    }();
+    c.by0 = square ? 4 : 2;
+    c.bx0 = square ? 4 : 8;
+    const int tiles = ((levels[0].W + c.bx0 - 1) / c.bx0) * ((levels[0].H + c.by0 - 1) / c.by0);
     hipStream_t s = (hipStream_t)stream;
     double n = 0;
     for (int k = 0; k < n_levels; ++k) n += (double)levels[k].B * levels[k].H * levels[k].W;
