@@ -421,6 +421,12 @@ typedef struct {
 } wmd_head_level_args;
 int wmd_head_level_supported(int C);
 int wmd_head_level_fwd(const wmd_head_level_args* args, void* stream);
+/* Round 6: the level's heads + synthesis AND the completions of up to three coarser levels in ONE launch (the streaming kernel's
+ * pyramid, wmd_head_stream.hip): coarse[k] as for wmd_head_shiftsum_chain_fwd (coarse to fine; the finest is half this level's size
+ * and its synthesis output IS this level's low-pass input, depth_decoder.py:164: args->yl must be NULL).  Same values, bit for bit,
+ * as wmd_head_shiftsum_chain_fwd followed by wmd_head_level_fwd.  Dense inference outputs only; C = 32, H and W multiples of 8.    */
+int wmd_head_level_pyramid_supported(int C, int B, int H, int W);   /* 0: no; 1: runs; 2: runs and is expected to pay (enough CUs for its <= 64-row segments) */
+int wmd_head_level_pyramid_fwd(const wmd_head_level_args* args, const wmd_head_shiftsum_args* coarse, int n_coarse, void* stream);
 
 /* Backward of the 3x3 stage of a level's wavelet heads (training): the 2-3 heads Conv3x3(C, 3 | 1) + sigmoid of a level
  * (depth_decoder.py:104-136; backward from torch.autograd, KITTI/trainer.py:211) given the pre-sigmoid gradients dy3

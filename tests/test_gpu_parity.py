@@ -833,6 +833,40 @@ def test_dense_decoder_with_postponed_heads_equals_the_level_by_level_forward(de
         assert torch.equal(out[k], ref[k]), key_str(k)
 
 
+@pytest.mark.parametrize("B,H1,W1", [(2, 48, 96), (3, 96, 64), (1, 16, 16), (2, 104, 72)])
+def test_level1_launch_with_the_coarser_completions_as_a_pyramid(dev, B, H1, W1):
+    """Round 6: wmd_head_level_pyramid_fwd -- head_stream_kernel's epilogue waves complete levels 4..2 over every unit's footprint
+    (4 x TH/8, 8 x TH/4, 16 x TH/2 pixels under its 32 x TH) before the level's own pipeline starts, handing the low-pass tiles down
+    through LDS.  Every output of every level bit-identical to the chained completion launch followed by the level-1 launch;
+    whole / ragged strips and segments, one unit per frame, a level 4 of 2 x 2 pixels."""
+    from wavelet_monodepth_amd import ops
+    g = lambda v: v.to(dev)
+    levels = []
+    for k, C in enumerate((256, 128, 64)):
+        H, W = H1 >> (3 - k), W1 >> (3 - k)
+        x = g(t(synth.normal((B, C, H, W), "px%d" % k, 41)))
+        hp = [g(t(a)) for a in synth.conv_params("p1p%d" % k, C, C, 1, 41)] + [g(t(a)) for a in synth.conv_params("p3p%d" % k, 3, C, 3, 41)]
+        hn = [g(t(a)) for a in synth.conv_params("p1n%d" % k, C, C, 1, 41)] + [g(t(a)) for a in synth.conv_params("p3n%d" % k, 3, C, 3, 41)]
+        hl = [g(t(a)) for a in synth.conv_params("p1l", C // 4, C, 1, 41)] + [g(t(a)) for a in synth.conv_params("p3l", 1, C // 4, 3, 41)] if C == 256 else None
+        levels.append((x, hp, hn, hl))
+    x1 = g(t(synth.normal((B, 32, H1, W1), "px1", 41)))
+    hp1 = [g(t(a)) for a in synth.conv_params("q1p", 32, 32, 1, 41)] + [g(t(a)) for a in synth.conv_params("q3p", 3, 32, 3, 41)]
+    hn1 = [g(t(a)) for a in synth.conv_params("q1n", 32, 32, 1, 41)] + [g(t(a)) for a in synth.conv_params("q3n", 3, 32, 3, 41)]
+    sc, ds = [2.0 ** (k - 1) for k in (4, 3, 2)], [1.0 / 2 ** (k - 1) for k in (4, 3, 2)]
+    items = ops.head_fused_gemm_multi_nograd(levels)
+    ref = ops.head_shiftsum_chain_nograd(items, sc, ds, scale_ll=16.0)
+    ref1 = ops.head_fused_level_nograd(x1, hp1, hn1, scale=1.0, yl=ref[2][1], disp_scale=1.0, clamp01=True)
+    items = ops.head_fused_gemm_multi_nograd(levels)
+    got, got1 = ops.head_level_pyramid_nograd(x1, hp1, hn1, 1.0, 1.0, items, sc, ds, scale_ll=16.0)
+    for k in range(3):
+        for a, b in zip(got[k], ref[k]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), "coarse level %d" % k
+    for a, b in zip(got1, ref1[:3]):
+        assert torch.equal(a, b), "level 1"
+
+
 @pytest.mark.parametrize("C,H,W", [(256, 12, 40), (64, 9, 28), (128, 5, 7), (32, 6, 10)])
 def test_fused_head_level_with_the_low_pass_head_as_third_chain(dev, C, H, W):
     """Coarsest level (depth_decoder.py:104-106,126-136): the LL head C -> C/4 -> 1 rides in the fused launches as a third,

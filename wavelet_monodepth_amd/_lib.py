@@ -188,6 +188,8 @@ SIGNATURES = {
     "wmd_head_shiftsum_chain_fwd": (C.c_int, [C.POINTER(HeadShiftsumArgs), C.c_int, C.c_void_p]),
     "wmd_head_level_supported": (C.c_int, [C.c_int]),
     "wmd_head_level_fwd": (C.c_int, [C.POINTER(HeadLevelArgs), C.c_void_p]),
+    "wmd_head_level_pyramid_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "wmd_head_level_pyramid_fwd": (C.c_int, [C.POINTER(HeadLevelArgs), C.POINTER(HeadShiftsumArgs), C.c_int, C.c_void_p]),
     "wmd_head3x3_bwd_workspace_floats": (C.c_size_t, [C.POINTER(Head3x3BwdArgs)]),
     "wmd_head3x3_bwd": (C.c_int, [C.POINTER(Head3x3BwdArgs), C.c_void_p]),
     "wmd_head1x1_bwd_workspace_floats": (C.c_size_t, [C.POINTER(Head1x1BwdArgs)]),

@@ -361,7 +361,7 @@ extern "C" int wmd_head_level_fwd(const wmd_head_level_args* g, void* stream) {
     if (g->mid_out && (g->mid_ct <= 0 || g->mid_off_p < 0 || g->mid_off_n < 0 || g->mid_off_p + g->C > g->mid_ct || g->mid_off_n + g->C > g->mid_ct))
         return fail(WMD_ERR_BAD_ARG, "wmd_head_level_fwd: mid_out channel offsets outside mid_ct = %d", g->mid_ct);
     hipStream_t s = (hipStream_t)stream;
-    if (head_stream_launch(g, s)) return check_launch("head_stream_kernel");   // round 6: plain inference outputs stream (wmd_head_stream.hip)
+    if (head_stream_launch(g, nullptr, 0, s)) return check_launch("head_stream_kernel");   // round 6: plain inference outputs stream (wmd_head_stream.hip)
     const int tiles_x = (g->W + HL_TW - 1) / HL_TW, tiles_y = (g->H + HL_TH - 1) / HL_TH;
     const double pix = (double)g->B * g->H * g->W;
     ProfScope prof("head_level_kernel", 2.0 * pix * (2.0 * g->C * g->C + 54.0 * g->C),
@@ -370,4 +370,40 @@ extern "C" int wmd_head_level_fwd(const wmd_head_level_args* g, void* stream) {
     const dim3 grid((unsigned)std::min(ntiles, 2 * kNumCU));   // persistent: 70 KB of LDS = 2 blocks per CU
     hipLaunchKernelGGL((head_level_kernel<32, 4>), grid, dim3(256), 0, s, *g, tiles_x, tiles_y, ntiles);
     return check_launch("head_level_kernel");
+}
+
+// Round 6: the level's heads + synthesis AND the completions of up to three coarser levels in one launch (head_stream_kernel's
+// pyramid, wmd_head_stream.hip).  coarse[k] as for wmd_head_shiftsum_chain_fwd (coarse to fine, each twice the one before, the
+// first takes exactly one of yl / yl_out, the others the chain's low-pass); the finest coarse level is half this level's size and
+// its synthesis output is this level's low-pass input: args->yl must be NULL, args->out is required.
+extern "C" int wmd_head_level_pyramid_supported(int C, int B, int H, int W) {   // 1: runs, 2: runs and pays (see head_stream_pyramid_pays)
+    if (!(wmd_head_level_supported(C) && (H % 8) == 0 && (W % 8) == 0 && H >= 8 && W >= 8 && B > 0)) return 0;
+    return head_stream_pyramid_pays(B, H, W) ? 2 : 1;
+}
+
+extern "C" int wmd_head_level_pyramid_fwd(const wmd_head_level_args* g, const wmd_head_shiftsum_args* coarse, int n_coarse, void* stream) {
+    if (!g || !coarse || n_coarse < 1 || n_coarse > 3) return fail(WMD_ERR_BAD_ARG, "wmd_head_level_pyramid_fwd: args and 1..3 coarse levels");
+    if (!g->x || !g->wp1 || !g->wp2 || !g->yh || !g->out) return fail(WMD_ERR_BAD_ARG, "wmd_head_level_pyramid_fwd: null tensor pointer (x, wp1, wp2, yh, out)");
+    if (g->yl) return fail(WMD_ERR_BAD_ARG, "wmd_head_level_pyramid_fwd: the low-pass input comes from the pyramid: yl must be NULL");
+    if (g->yh_mask || g->mid_out || g->sig_p || g->sig_n || g->pad_mode != WMD_PAD_REFLECT || !(g->slope >= 0.f && g->slope <= 1.f))
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_level_pyramid_fwd: plain inference outputs, reflect padding, 0 <= slope <= 1 only");
+    if (!wmd_head_level_pyramid_supported(g->C, g->B, g->H, g->W))
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_level_pyramid_fwd: C=%d %dx%d (C = 32, sizes that are multiples of 8)", g->C, g->H, g->W);
+    if ((double)g->C * g->H * g->W * 4 > 2147483647.0) return fail(WMD_ERR_UNSUPPORTED, "wmd_head_level_pyramid_fwd: a per-image tensor slice exceeds 2 GiB");
+    for (int k = 0; k < n_coarse; ++k) {
+        const wmd_head_shiftsum_args& c = coarse[k];
+        const int sh = n_coarse - k;
+        if (!c.t || !c.yh || !c.out) return fail(WMD_ERR_BAD_ARG, "wmd_head_level_pyramid_fwd: coarse level %d: t, yh and out are required", k);
+        if (c.B != g->B || c.H != (g->H >> sh) || c.W != (g->W >> sh) || (c.H << sh) != g->H || (c.W << sh) != g->W)
+            return fail(WMD_ERR_BAD_SHAPE, "wmd_head_level_pyramid_fwd: coarse level %d is %dx%dx%d, expected %dx%dx%d", k, c.B, c.H, c.W, g->B, g->H >> sh, g->W >> sh);
+        if (c.pad_mode < 0 || c.pad_mode > 2 || (c.pad_mode == WMD_PAD_REFLECT && (c.H < 2 || c.W < 2)))
+            return fail(WMD_ERR_BAD_ARG, "wmd_head_level_pyramid_fwd: coarse level %d: pad_mode=%d on %dx%d", k, c.pad_mode, c.H, c.W);
+        if (c.yh_mask || c.range_keys || c.sig_p || c.sig_n || c.sig_ll)
+            return fail(WMD_ERR_UNSUPPORTED, "wmd_head_level_pyramid_fwd: dense inference only (no yh_mask / range_keys / sigmoid outputs)");
+        if (k == 0 ? ((c.yl != nullptr) == (c.yl_out != nullptr)) : (c.yl != nullptr || c.yl_out != nullptr))
+            return fail(WMD_ERR_BAD_ARG, "wmd_head_level_pyramid_fwd: the first coarse level takes exactly one of yl / yl_out, the others the chain's low-pass");
+    }
+    if (!head_stream_launch(g, coarse, n_coarse, (hipStream_t)stream))
+        return fail(WMD_ERR_UNSUPPORTED, "wmd_head_level_pyramid_fwd: the streaming kernel is switched off (WMD_HEAD_STREAM=0)");
+    return check_launch("head_stream_kernel");
 }

@@ -31,7 +31,9 @@
 // yh_mask / mid_out / sig_* (sparse and training forms) and non-reflect padding stay on head_level_kernel.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "wmd_internal.h"
+#include "wmd_head_shiftsum.h"
 
 namespace wmd {
 
@@ -54,6 +56,19 @@ constexpr int HS_TS = ((HS_RING + 20 - 4 + 31) / 32) * 32 + 4;   // plane stride
 constexpr int HS_XW = HS_C * 16;                                // dwords of one wave's x slice of one step
 static_assert(HS_TS >= HS_RING + 4 && HS_TS % 32 == 4, "ring plane stride");
 static_assert(HS_NE * 32 == HS_S, "two sides of 32 anchors per epilogue wave cover a step");
+
+// The completions of the coarser levels (up to three, coarse to fine, each twice the size of the one before; the finest is half
+// this level's size) as a PYRAMID inside this kernel: level k's synthesis output is level k+1's low-pass input pixel for pixel, and
+// the last one's is THIS level's (wmd_head_level_args.yl).  A unit's 32 x TH pixels nest over 16 x TH/2, 8 x TH/4, 4 x TH/8 pixels of
+// the coarser levels (TH a multiple of 8), so its four epilogue waves complete those regions first -- shiftsum_pixel, the arithmetic
+// of head_shiftsum_chain_kernel: same bits -- handing the low-pass tiles down through LDS, the last one (32 x TH) being what the
+// level's own epilogue reads instead of global memory.  Removes the completion launch of the dense decoder (21.7 us of latency-bound
+// gathers at config 2) at the price of the GEMM waves waiting for the pyramid behind their first step.
+struct HeadStreamPyr {
+    wmd_head_shiftsum_args lv[3];
+    int n;   // 0: no pyramid (a.yl from memory)
+};
+constexpr int HS_PYR_TH_MAX = 64;   // 16 x TH/2 pixels of the finest coarse level <= the GEMM waves' 512 lanes: one pixel per lane
 
 struct HeadStreamGeom {
     int strips, segs, TH, nunits;
@@ -133,14 +148,75 @@ __device__ __forceinline__ void hs_leaky4(const f32x4& v, float slope, float (&o
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(slope));
 }
 
+// The pyramid of one unit, run by ALL waves of the block before the unit's pipeline starts.  Every level's gathers are issued at once
+// on disjoint lanes -- the finest coarse level (16 x TH/2 pixels) on the GEMM waves' 512 lanes, the one or two above it (8 x TH/4,
+// 4 x TH/8) side by side on the epilogue waves' 256 -- so the memory round trip of ~60 gathers per pixel is paid ONCE; only the
+// low-pass hand-over (one LDS value in, four out per pixel, a butterfly) is sequential, one block barrier per level.  (First version:
+// one phase per level on the epilogue waves' lanes, loads and all: 18.5 us per unit -- as much as the launch it replaced.)
+__device__ __forceinline__ void hs_pyramid(const HeadStreamPyr& pyr, int b, int y0, int x0, int TH, int tid, float (*pyr_low)[16 * (HS_PYR_TH_MAX / 2)],
+                                           float* yl_tile) {
+    constexpr int NGL = HS_NG * 64;
+    static_assert((HS_TW / 2) * (HS_PYR_TH_MAX / 2) <= HS_NG * 64 && (HS_TW / 4) * (HS_PYR_TH_MAX / 4) + (HS_TW / 8) * (HS_PYR_TH_MAX / 8) <= HS_NE * 64, "one pixel per lane");
+    const int n = pyr.n;
+    const bool gemm_lane = tid < NGL;
+    // job of this lane: (level, pixel index inside the unit's region of that level)
+    int lvl = -1, idx = 0;
+    if (gemm_lane) {
+        lvl = n - 1;
+        idx = tid;
+    } else {
+        int et = tid - NGL, base = 0;
+        for (int k = n - 2; k >= 0; --k) {      // level n-2 first (the larger region), then n-3
+            const int sh = n - k, cnt = (HS_TW >> sh) * (TH >> sh);
+            if (lvl < 0 && et >= base && et < base + cnt) lvl = k, idx = et - base;
+            base += cnt;
+        }
+    }
+    float yh[3], l_own = 0.f;
+    int py = 0, px = 0;
+    bool live = false, own = false;
+    if (lvl >= 0) {
+        const int sh = n - lvl, rw = HS_TW >> sh, rh = TH >> sh;
+        if (idx < rw * rh) {
+            py = idx / rw, px = idx - py * rw;
+            const int yy = (y0 >> sh) + py, xx = (x0 >> sh) + px;
+            live = yy < pyr.lv[lvl].H && xx < pyr.lv[lvl].W;
+            if (live) own = shiftsum_gather(pyr.lv[lvl], (size_t)b, yy, xx, yh, l_own);
+        }
+    }
+    // hand-over, coarse to fine: level k reads the tile level k - 1 left, finishes, leaves its own 2 x 2 per pixel
+    for (int k = 0; k < n; ++k) {
+        if (lvl == k && live) {
+            const int sh = n - k, rw = HS_TW >> sh;
+            const float* lp = pyr_low[(k + 1) & 1];
+            float* nl = k + 1 < n ? pyr_low[k & 1] : yl_tile;
+            const int ns = rw * 2;
+            const float l = own ? l_own : (k > 0 ? lp[py * rw + px] : 0.f);
+            float v[4];
+            shiftsum_finish(pyr.lv[k], (size_t)b, (y0 >> sh) + py, (x0 >> sh) + px, yh, l, v);
+            nl[(2 * py) * ns + 2 * px] = v[0];
+            nl[(2 * py) * ns + 2 * px + 1] = v[1];
+            nl[(2 * py + 1) * ns + 2 * px] = v[2];
+            nl[(2 * py + 1) * ns + 2 * px + 1] = v[3];
+        }
+        hs_barrier();
+    }
+}
+
 // (second launch bound = waves per SIMD: two 6-wave blocks per CU -> 3, i.e. <= 168 VGPRs)
-__global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(const wmd_head_level_args a, const HeadStreamGeom gm) {
+// PYR: the instantiation that carries the pyramid (its mere presence in the code costs the plain launch 7 us of 49: two kernels)
+template <bool PYR>
+__global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(const wmd_head_level_args a, const HeadStreamGeom gm, const HeadStreamPyr pyr_) {
+    struct NoPyr { int n; };
+    const std::conditional_t<PYR, HeadStreamPyr, NoPyr> pyr = [&] { if constexpr (PYR) return pyr_; else return NoPyr{0}; }();
     constexpr int C = HS_C, PW = HS_PW, TW = HS_TW, S = HS_S, L = HS_L, RING = HS_RING, TS = HS_TS, XW = HS_XW;
     constexpr int MR = C / 16, KS = C / 4;
     __shared__ __attribute__((aligned(16))) float ts[54 * TS];
     __shared__ __attribute__((aligned(16))) float xs0[HS_NG * XW];
     __shared__ __attribute__((aligned(16))) float xs1[HS_NG * XW];
     __shared__ __attribute__((aligned(16))) float xs2[HS_NG * XW];
+    __shared__ float pyr_low[2][PYR ? 16 * (HS_PYR_TH_MAX / 2) : 1];   // low-pass tiles handed down the pyramid: 8 x TH/4, then 16 x TH/2
+    __shared__ float yl_tile[PYR ? 32 * HS_PYR_TH_MAX : 1];            // ... and the last one: this level's low-pass input, 32 x TH
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,30 +232,33 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
         // channel 16m + 4g + i -- fragment 4m + g of the ordinary image, lane 16 i + lc.
         float w1f[2][MR][KS], w2f[2][2][KS];
         f32x4 b1v[2][MR];
+        auto load_weights = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int sd = 0; sd < 2; ++sd) {
-            const float* w1 = a.wp1 + (size_t)sd * MR * KS * 64 + lane;
-            const float* w2 = a.wp2 + (size_t)sd * 2 * KS * 64;
-#pragma unroll
-            for (int m = 0; m < MR; ++m)
-#pragma unroll
-                for (int k = 0; k < KS; ++k) w1f[sd][m][k] = w1[(m * KS + k) * 64];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int sd = 0; sd < 2; ++sd) {
+                const float* w1 = a.wp1 + (size_t)sd * MR * KS * 64 + lane;
+                const float* w2 = a.wp2 + (size_t)sd * 2 * KS * 64;
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) w2f[sd][j][m * 4 + i] = w2[((size_t)j * KS + 4 * m + g) * 64 + i * 16 + lc];
+                    for (int k = 0; k < KS; ++k) w1f[sd][m][k] = w1[(m * KS + k) * 64];
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.bias1) b4 = *reinterpret_cast<const float4*>(a.bias1 + sd * C + m * 16 + g * 4);
-                b1v[sd][m] = f32x4{b4.x, b4.y, b4.z, b4.w};
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w2f[sd][j][m * 4 + i] = w2[((size_t)j * KS + 4 * m + g) * 64 + i * 16 + lc];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.bias1) b4 = *reinterpret_cast<const float4*>(a.bias1 + sd * C + m * 16 + g * 4);
+                    b1v[sd][m] = f32x4{b4.x, b4.y, b4.z, b4.w};
+                }
             }
-        }
+        };
+        if constexpr (!PYR) load_weights();      // (with a pyramid: behind it, unit by unit -- its gathers need the registers)
         const float slope = a.slope;
 
-        for (int unit = blockIdx.x; unit < gm.nunits; unit += gridDim.x) {
+        for (int unit = blockIdx.x; unit < gm.nunits; unit += gridDim.x) {   // (PYR: one unit per block -- HS_UNIT_END -- see the launch)
             const int b = unit / upb, rem = unit - b * upb;
             const int seg = rem / gm.strips, strip = rem - seg * gm.strips;
             const int x0 = strip * TW, y0 = seg * gm.TH;
@@ -294,12 +373,17 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
 
             issue(xs0);
             if (nsteps > 1) issue(xs1);
+            if constexpr (PYR) {   // behind the first two slices' DMA (they land meanwhile); ends in pyr.n block barriers
+                hs_pyramid(pyr, b, y0, x0, gm.TH, tid, pyr_low, yl_tile);
+                load_weights();
+            }
             for (int s = 0; s < nsteps; s += 3) {
                 step(s, xs0, xs2);
                 if (s + 1 < nsteps) step(s + 1, xs1, xs0);
                 if (s + 2 < nsteps) step(s + 2, xs2, xs1);
             }
             hs_barrier();   // the epilogue of the last step has read the ring: the next unit may overwrite it
+            if constexpr (PYR) break;
         }
     } else {
         // ============================================== epilogue waves =======================================================
@@ -313,13 +397,14 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
         }
         const float* tsl = ts + side * 27 * TS;
 
-        for (int unit = blockIdx.x; unit < gm.nunits; unit += gridDim.x) {
+        for (int unit = blockIdx.x; unit < gm.nunits; unit += gridDim.x) {   // (PYR: one unit per block -- HS_UNIT_END -- see the launch)
             const int b = unit / upb, rem = unit - b * upb;
             const int seg = rem / gm.strips, strip = rem - seg * gm.strips;
             const int x0 = strip * TW, y0 = seg * gm.TH;
             const int th = min(gm.TH, H - y0);
             const int npu = (th + 2) * PW, nsteps = (npu + S - 1) / S;
 
+            if constexpr (PYR) hs_pyramid(pyr, b, y0, x0, gm.TH, tid, pyr_low, yl_tile);
             hs_barrier();   // step 0 has no finished anchors
             for (int s = 1; s <= nsteps; ++s) {
                 // anchors of this interval: [(s-1) S - L, s S - L) -- every tap of theirs was written in steps <= s-1
@@ -331,7 +416,11 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
                 if (__builtin_amdgcn_ballot_w64(valid) != 0 && !HS_DBG_ON(1)) {
                     const int y = y0 + oy, x = x0 + ox;
                     const bool writer = valid && side == 0;
-                    const float yl_v = (writer && a.yl) ? a.yl[(size_t)b * plane + (size_t)y * W + x] : 0.f;
+                    // (the global low-pass value is requested here, unconditionally as far as the pyramid is concerned, and consumed
+                    //  after the gathers: behind a select on pyr.n the compiler issued it late and every step waited for it)
+                    const float yl_g = (writer && a.yl) ? a.yl[(size_t)b * plane + (size_t)y * W + x] : 0.f;
+                    float yl_v = yl_g;
+                    if constexpr (PYR) yl_v = yl_tile[min(oy, HS_PYR_TH_MAX - 1) * TW + min(ox, TW - 1)];
                     const int sb = ((abase % RING) + RING) % RING;          // (uniform)
                     int r0 = sb + al;
                     r0 -= r0 >= RING ? RING : 0;
@@ -360,7 +449,7 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
                         const size_t px = (size_t)y * W + x;
 #pragma unroll
                         for (int co = 0; co < 3; ++co) a.yh[((size_t)b * 3 + co) * plane + px] = yh[co];
-                        if (a.yl && a.out) {
+                        if ((a.yl || PYR) && a.out) {
                             const float l = yl_v;
                             float v[4] = {(l + yh[0] + yh[1] + yh[2]) * 0.5f, (l + yh[0] - yh[1] - yh[2]) * 0.5f,
                                           (l - yh[0] + yh[1] - yh[2]) * 0.5f, (l - yh[0] - yh[1] + yh[2]) * 0.5f};
@@ -382,6 +471,7 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
                 if (s < nsteps) hs_barrier();
             }
             hs_barrier();   // unit end (pairs with the GEMM waves')
+            if constexpr (PYR) break;
         }
     }
 }
@@ -390,16 +480,17 @@ __global__ __launch_bounds__((HS_NG + HS_NE) * 64, 3) void head_stream_kernel(co
 // and two co-resident blocks gain little over running one after the other (measured at 96 x 320 x 12: 480 units of 24 rows
 // 62.0 us, 240 units of 48 rows 57.5 us: the matrix pipe and the vector ALU are one resource, a second block's waves mostly
 // queue behind the first's) -- so prefer one block per CU as long as that fills the chip; ties -> the taller segment (less halo)
-static int head_stream_pick_th(int B, int H, int strips) {
+static int head_stream_pick_th(int B, int H, int strips, bool pyramid, double* cost_out = nullptr) {
     static const int forced = [] {
         const char* e = getenv("WMD_HEAD_STREAM_TH");
         return e ? atoi(e) : 0;
     }();
-    if (forced > 0) return std::min(forced, H);
+    if (forced > 0) return pyramid ? std::min(((std::min(forced, H) + 7) / 8) * 8, HS_PYR_TH_MAX) : std::min(forced, H);
     double best = 1e300;
     int best_th = std::min(H, 24);
     for (int segs = 1; segs <= (H + 3) / 4; ++segs) {
-        const int th = (H + segs - 1) / segs;                        // equal segments (the last one may be shorter)
+        int th = (H + segs - 1) / segs;                              // equal segments (the last one may be shorter)
+        if (pyramid) th = std::min(((th + 7) / 8) * 8, HS_PYR_TH_MAX);   // the coarser levels' regions nest in multiples of 8 rows
         if ((H + th - 1) / th != segs) continue;
         const long units = (long)B * strips * segs;
         const long per_cu = (units + kNumCU - 1) / kNumCU;
@@ -408,11 +499,23 @@ static int head_stream_pick_th(int B, int H, int strips) {
         const double c = steps * f;
         if (c < best - 1e-9) best = c, best_th = th;
     }
+    if (cost_out) *cost_out = best;
     return best_th;
 }
 
+// Does the pyramid pay for a level of this size?  Its segments are at most 64 rows (one pixel of the finest coarse level per GEMM-wave
+// lane), so a tall level may need more units than CUs where the plain launch needs one per CU (1024x320, batch 8: 384 units of 56
+// rows against 256 of 80: 1.297 vs 1.279 ms for the whole forward) -- then the completion stays a launch of its own.
+int head_stream_pyramid_pays(int B, int H, int W) {
+    const int strips = (W + HS_TW - 1) / HS_TW;
+    double plain = 0, pyr = 0;
+    head_stream_pick_th(B, H, strips, false, &plain);
+    head_stream_pick_th(B, H, strips, true, &pyr);
+    return pyr <= plain * 1.05;
+}
+
 // -> 1 when the streaming kernel took the launch (C = 32, no sparse / training outputs, 0 <= slope <= 1; WMD_HEAD_STREAM=0 off)
-int head_stream_launch(const wmd_head_level_args* g, hipStream_t s) {
+int head_stream_launch(const wmd_head_level_args* g, const wmd_head_shiftsum_args* coarse, int n_coarse, hipStream_t s) {
     static const bool on = [] {
         const char* e = getenv("WMD_HEAD_STREAM");
         return !(e && atoi(e) == 0);
@@ -428,7 +531,15 @@ int head_stream_launch(const wmd_head_level_args* g, hipStream_t s) {
     if ((long)g->B * g->H * g->W < min_pixels) return 0;
     HeadStreamGeom gm;
     gm.strips = (g->W + HS_TW - 1) / HS_TW;
-    gm.TH = head_stream_pick_th(g->B, g->H, gm.strips);
+    HeadStreamPyr pyr;
+    pyr.n = 0;
+    if (n_coarse > 0) {      // (shapes validated by wmd_head_level_pyramid_fwd)
+        if (n_coarse > 3 || (g->H & 7) || g->H > 8 * 4096) return 0;
+        for (int k = 0; k < n_coarse; ++k) pyr.lv[k] = coarse[k];
+        pyr.n = n_coarse;
+    }
+    for (int k = pyr.n; k < 3; ++k) pyr.lv[k] = pyr.lv[0];
+    gm.TH = head_stream_pick_th(g->B, g->H, gm.strips, pyr.n > 0);
     gm.segs = (g->H + gm.TH - 1) / gm.TH;
     const long nunits = (long)g->B * gm.strips * gm.segs;
     if (nunits > (1L << 30)) return 0;
@@ -449,8 +560,11 @@ int head_stream_launch(const wmd_head_level_args* g, hipStream_t s) {
         }
         prof.mfma(2.0 * pos * g->B * gm.strips * 2.0 * (g->C * g->C + 32.0 * g->C));
     }
-    const dim3 grid((unsigned)std::min(gm.nunits, (HS_NG > 4 ? 1 : 2) * kNumCU));
-    hipLaunchKernelGGL(head_stream_kernel, grid, dim3((HS_NG + HS_NE) * 64), 0, s, *g, gm);
+    // the pyramid instantiation takes ONE unit per block: its three argument blocks must not stay live across the step loops of a
+    // persistent block (132 SGPR spills to VGPR lanes, v_readlane in the hot loops: 7 us of 49)
+    const dim3 grid((unsigned)(pyr.n > 0 ? gm.nunits : std::min(gm.nunits, (HS_NG > 4 ? 1 : 2) * kNumCU)));
+    if (pyr.n > 0) hipLaunchKernelGGL(head_stream_kernel<true>, grid, dim3((HS_NG + HS_NE) * 64), 0, s, *g, gm, pyr);
+    else hipLaunchKernelGGL(head_stream_kernel<false>, grid, dim3((HS_NG + HS_NE) * 64), 0, s, *g, gm, pyr);
     return 1;
 }
 

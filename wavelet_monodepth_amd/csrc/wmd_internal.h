@@ -85,6 +85,7 @@ int head_chain_launch(const wmd_head_fused_args* g, int t_planes, hipStream_t s)
 int head_chain_multi_launch(const wmd_head_fused_args* levels, int n, hipStream_t s);
 
 // wmd_head_stream.hip: the streaming form of wmd_head_level_fwd (C = 32, plain inference outputs); 0 = not taken
-int head_stream_launch(const wmd_head_level_args* g, hipStream_t s);
+int head_stream_launch(const wmd_head_level_args* g, const wmd_head_shiftsum_args* coarse, int n_coarse, hipStream_t s);
+int head_stream_pyramid_pays(int B, int H, int W);
 
 }  // namespace wmd

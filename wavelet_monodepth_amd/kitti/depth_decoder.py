@@ -357,6 +357,10 @@ class DepthWaveProgressiveDecoder(nn.Module):
         chain = plain and ops.shiftsum_chain_supported(
             widths, 0 if chain_multi else input_features[1].shape[0] * input_features[1].shape[2] * input_features[1].shape[3])
         pending, deferred = [], []
+        # ... and (round 6) the completions of levels 4..2 run INSIDE level 1's launch: the streaming kernel's epilogue waves complete
+        # the coarser levels over each unit's footprint first (ops.head_level_pyramid_nograd): one graph node and 21.7 us fewer
+        f0 = input_features[0]
+        pyramid = chain and ops.head_level_pyramid_supported(int(self.num_ch_dec[1]), f0.shape[0], f0.shape[2], f0.shape[3])
         for i in range(4, 0, -1):
             if i == 4 and edge is not None:
                 x = self.convs[("upconv", 4, 0)](x, x1_pre=edge.pre())      # ReLU (+ affine) of the encoder's last block on load
@@ -372,6 +376,8 @@ class DepthWaveProgressiveDecoder(nn.Module):
                         pending = ops.head_fused_gemm_multi_nograd(deferred)
                 else:
                     pending.append(ops.head_fused_gemm_nograd(x, hd(1), hd(-1), hd(0) if i == 4 else None))
+                if i == 2 and pyramid:
+                    continue        # ... completed inside level 1's launch (below)
                 if i == 2:
                     done = ops.head_shiftsum_chain_nograd(pending, [2.0 ** (k - 1) for k in (4, 3, 2)], [1.0 / 2 ** (k - 1) for k in (4, 3, 2)],
                                                           scale_ll=2.0 ** 4)
@@ -382,6 +388,26 @@ class DepthWaveProgressiveDecoder(nn.Module):
                         self.outputs[("wavelets", k - 1, "HH")] = yh[:, :, 2]
                         self.outputs[("disp", k - 1)] = disp
                         yl = out
+                continue
+            if pyramid and i == 1:
+                hp, hn = self.convs[("waveconv", 1, 1)], self.convs[("waveconv", 1, -1)]
+                hw = lambda m: (m[0].conv.weight, m[0].conv.bias, m[2].conv.weight, m[2].conv.bias)
+                done, (yh, out, disp) = ops.head_level_pyramid_nograd(
+                    x, hw(hp), hw(hn), 1.0, 1.0, pending, [2.0 ** (k - 1) for k in (4, 3, 2)], [1.0 / 2 ** (k - 1) for k in (4, 3, 2)],
+                    scale_ll=2.0 ** 4)
+                for k, (yhk, outk, dispk, yl_ll) in zip((4, 3, 2), done):
+                    self.outputs[("wavelets", k - 1, "LL")] = yl_ll if k == 4 else yl
+                    self.outputs[("wavelets", k - 1, "LH")] = yhk[:, :, 0]
+                    self.outputs[("wavelets", k - 1, "HL")] = yhk[:, :, 1]
+                    self.outputs[("wavelets", k - 1, "HH")] = yhk[:, :, 2]
+                    self.outputs[("disp", k - 1)] = dispk
+                    yl = outk
+                self.outputs[("wavelets", 0, "LL")] = yl
+                self.outputs[("wavelets", 0, "LH")] = yh[:, :, 0]
+                self.outputs[("wavelets", 0, "HL")] = yh[:, :, 1]
+                self.outputs[("wavelets", 0, "HH")] = yh[:, :, 2]
+                self.outputs[("disp", 0)] = disp
+                yl = out
                 continue
             if overlap:
                 keep.append(x)

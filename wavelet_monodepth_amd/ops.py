@@ -1081,6 +1081,56 @@ def head_shiftsum_chain_nograd(items, scales, disp_scales, scale_ll=1.0, yl=None
     return res
 
 
+_HEAD_PYRAMID = os.environ.get("WMD_HEAD_PYRAMID", "1") != "0"   # 0: the coarser levels' completions as a launch of their own
+
+
+def head_level_pyramid_supported(C_, B, H, W):
+    """Dense inference: can the C = 32 level run its heads + synthesis AND the coarser levels' completions in one launch?"""
+    return _HEAD_PYRAMID and not _TWO_LAUNCH_HEAD and os.environ.get("WMD_HEAD_STREAM", "1") != "0" and \
+        _lib.lib().wmd_head_level_pyramid_supported(int(C_), int(B), int(H), int(W)) >= (1 if os.environ.get("WMD_HEAD_PYRAMID") == "2" else 2)
+
+
+def head_level_pyramid_nograd(x, head_p, head_n, scale, disp_scale, items, scales, disp_scales, scale_ll=1.0, yl=None, clamp01=True):
+    """Round 6 (wmd_head_level_pyramid_fwd): the finest level's heads + synthesis AND the completions of the coarser levels (items of
+    head_fused_gemm[_multi]_nograd, coarse to fine) in ONE launch -- the streaming kernel's epilogue waves complete the coarser
+    levels over each unit's footprint first and hand the low-pass tiles down through LDS.  -> ([(yh, out, disp, yl_ll or None) per
+    coarse level], (yh, out, disp) of this level); same bits as head_shiftsum_chain_nograd + head_fused_level_nograd."""
+    l = _lib.lib()
+    x = _c(x)
+    B, Cc, H, W = x.shape
+    n = len(items)
+    arr = (_lib.HeadShiftsumArgs * n)()
+    res = []
+    yl_c = _c(yl) if yl is not None else None
+    for k, it in enumerate(items):
+        Bk, Hk, Wk = it["B"], it["H"], it["W"]
+        dev = it["t"].device
+        yh = torch.empty((Bk, 3, Hk, Wk), device=dev, dtype=torch.float32)
+        out = torch.empty((Bk, 1, 2 * Hk, 2 * Wk), device=dev, dtype=torch.float32)
+        disp = torch.empty_like(out)
+        yl_ll = torch.empty((Bk, 1, Hk, Wk), device=dev, dtype=torch.float32) if (k == 0 and it["has_ll"]) else None
+        if k == 0 and not it["has_ll"] and yl is None:
+            raise _lib.WmdError("head_level_pyramid_nograd: the first coarse level needs its low-pass input (yl) or the low-pass head")
+        arr[k] = _lib.HeadShiftsumArgs(B=Bk, H=Hk, W=Wk, pad_mode=PAD["reflect"], scale=float(scales[k]), t=ptr(it["t"]), bias_p=ptr(it["b3p"]),
+                                       bias_n=ptr(it["b3n"]), yh=ptr(yh), yl=ptr(yl_c) if (k == 0 and yl_ll is None) else None, out=ptr(out),
+                                       disp=ptr(disp), disp_scale=float(disp_scales[k]), clamp01=int(clamp01),
+                                       bias_ll=ptr(it["b3l"]) if yl_ll is not None else None, scale_ll=float(scale_ll),
+                                       yl_out=ptr(yl_ll))
+        res.append((yh.unsqueeze(1), out, disp, yl_ll))
+    (w1p, b1p, w3p, b3p), (w1n, b1n, w3n, b3n) = head_p, head_n
+    wp1, bias1 = stacked_pack([w1p, w1n], [b1p, b1n])
+    wp2 = _tap_partial_pack(w3p, w3n)
+    yh1 = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
+    out1 = torch.empty((B, 1, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    disp1 = torch.empty_like(out1) if disp_scale is not None else None
+    a = _lib.HeadLevelArgs(B=B, H=H, W=W, C=Cc, pad_mode=PAD["reflect"], slope=0.1, scale=float(scale), x=ptr(x),
+                           wp1=ptr(wp1), bias1=ptr(bias1), wp2=ptr(wp2), bias_p=ptr(b3p), bias_n=ptr(b3n), yh=ptr(yh1),
+                           yl=None, out=ptr(out1), disp=ptr(disp1), disp_scale=float(disp_scale or 1.0), clamp01=int(clamp01), yh_mask=None)
+    check(l.wmd_head_level_pyramid_fwd(C.byref(a), arr, n, current_stream()), "wmd_head_level_pyramid_fwd")
+    del yl_c
+    return res, (yh1.unsqueeze(1), out1, disp1)
+
+
 _TRAIN_FUSED = os.environ.get("WMD_TRAIN_FUSED_HEADS", "1") != "0"   # 0: training forward of the heads on _StackedHeadsFn + idwt_haar
 _HEAD_CHAIN_ON = os.environ.get("WMD_HEAD_CHAIN", "1") != "0"
 
