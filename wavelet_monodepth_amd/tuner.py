@@ -16,6 +16,7 @@ _cache = {}
 _cache_file = os.environ.get("WMD_TUNE_CACHE")
 _loaded = False
 KSPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
+ranked = {}   # key -> [(config name, ksplit, ms)] of the last isolated sweep, best first (tools/step_tune.py starts from these)
 
 
 def _load():
@@ -106,6 +107,7 @@ def tune(key, taps, launch):
         _cache[key] = ("", 0)
         return (0, 0)
     results.sort()
+    ranked[key] = [(names[cfg - 1], ks, t) for t, cfg, ks in results[:12]]
     final = sorted((_time(launch, cfg, ks, 6, e0, e1), cfg, ks) for _, cfg, ks in results[:5])
     t, cfg, ks = final[0]
     _cache[key] = (names[cfg - 1], ks)
