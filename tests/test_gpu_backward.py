@@ -439,6 +439,51 @@ def test_fused_training_level_vs_oracle_and_stacked_path(dev, C, H, W, B, with_l
         assert_close(a_.grad, b_.grad, GRAD_TOL, "fused vs stacked path: gradient of leaf %d" % k)
 
 
+@pytest.mark.parametrize("H,W,B", [(16, 64, 16), (24, 40, 18), (8, 128, 17)])
+def test_one_pass_head_backward_at_32_channels_vs_oracle_and_the_launch_set(dev, H, W, B, monkeypatch):
+    """Round 6: head_bwd_fused32_kernel (wmd_head_bwd at C = 32: the 3x3 data + weight gradients, the 1x1 data + weight gradients of
+    both heads in ONE pass, dz in a wave-private LDS tile) against autograd through the oracle and against the separate launch sets
+    (wmd_head3x3_bwd + wmd_head1x1_bwd), on maps where most 16-pixel groups touch an edge (16 x 64), where groups straddle rows
+    (24 x 40) and with an ELU gate on x; the kernel must be the one that ran."""
+    from wavelet_monodepth_amd import _lib, ops
+    C = 32
+    x = t(synth.normal((B, C, H, W), "f32x", 5))
+    mk = lambda tag, mid, out: [t(a) for a in synth.conv_params(tag + "1", mid, C, 1, 5)] + [t(a) for a in synth.conv_params(tag + "3", out, mid, 3, 5)]
+    hp, hn = mk("f32p", C, 3), mk("f32n", C, 3)
+    yl0 = t(synth.uniform((B, 1, H, W), "f32yl", 5, 2.0, 9.0))
+    g_yh, g_out = t(synth.normal((B, 3, H, W), "f32gyh", 5)), t(synth.normal((B, 1, 2 * H, 2 * W), "f32gout", 5))
+    lk = lambda v: torch.nn.functional.leaky_relu(v, 0.1)
+    leaves = [x] + hp + hn + [yl0]
+    grads, masks = {}, None
+    for merged in (True, False):
+        monkeypatch.setattr(ops, "_HEAD_BWD_MERGED", merged)
+        d = [v.to(dev).requires_grad_(True) for v in leaves]
+        xin = torch.nn.functional.elu(d[0]).detach().requires_grad_(True)
+        yh, lo, out, disp, mid = ops.fused_level_train(xin, d[1:5], d[5:9], 4.0, yl=d[9], disp_scale=0.3, clamp01=True, x_gate=("elu", 0.0))
+        masks = ((mid[:, :C] > 0).cpu(), (mid[:, C:] > 0).cpu())       # the LeakyReLU piece every element took (order [+, -])
+        _lib.profile_begin()
+        ((yh * g_yh.to(dev)).sum() + (out * g_out.to(dev)).sum()).backward()
+        names = {r["kernel"] for r in _lib.profile_end()}
+        assert ("head_bwd_fused32_kernel" in names) == merged, names
+        grads[merged] = [xin.grad] + [v.grad for v in d[1:]]
+    for k, (a_, b_) in enumerate(zip(grads[True], grads[False])):
+        assert_close(a_, b_, GRAD_TOL, "one-pass vs launch set: gradient of leaf %d" % k)
+    # the oracle differentiates the LeakyReLU piece the device took (the only kink on the path); x is an ELU output whose producer
+    # wants dz: the oracle's gradient of the pre-activation leaf is what the kernel's gate returns
+    ref = [v.clone().requires_grad_(True) for v in leaves]
+    xe = torch.nn.functional.elu(ref[0])
+
+    def sig(h, m):
+        z = R.conv1x1(xe, h[0], h[1])
+        return torch.sigmoid(R.conv3x3(torch.where(m, z, 0.1 * z), h[2], h[3], "reflect"))
+
+    r_yh = 4.0 * (sig(ref[1:5], masks[0]) - sig(ref[5:9], masks[1]))
+    r_out = R.haar_idwt(ref[9], r_yh.unsqueeze(1))
+    ((r_yh * g_yh).sum() + (r_out * g_out).sum()).backward()
+    for k, (a_, b_) in enumerate(zip(grads[True], [v.grad for v in ref])):
+        assert_close(a_, b_, GRAD_TOL, "one-pass head backward vs oracle: gradient of leaf %d" % k)
+
+
 @pytest.mark.parametrize("C,H,W,B,with_ll", [(32, 9, 21, 2, False), (64, 2, 5, 1, True), (16, 3, 2, 3, False), (80, 7, 66, 1, False), (128, 5, 9, 1, True),
                                              (256, 6, 20, 2, True)])
 def test_head3x3_backward_kernels_vs_oracle_and_generic_path(dev, C, H, W, B, with_ll, monkeypatch):

@@ -487,6 +487,368 @@ __global__ __launch_bounds__(256) void head_bwd_reduce2_kernel(const HeadBwdStag
     head1x1_bwd_reduce_body(m.h1, blockIdx.x - m.n3, blockIdx.y, m.n1w);
 }
 
+// ---- both stages of a C = 32 level as ONE pass (round 6) ----------------------------------------------------------------------
+// The launch set above moves mid twice, dz three times and x twice (693 MB at the finest level of BASELINE config 2 for 188 MB of
+// operands) because its four GEMMs live in four bodies.  At C = 32 (two 3-channel heads of 32 channels: Ct = 64) a wave can hold
+// ALL of a 64-pixel tile's work: it gathers g, loads mid ONCE and uses the registers twice (B operand of the 3x3 weight gradient
+// with the K index ordered the way the data gradient's accumulators come out: pixel 16 g + 4 kq + i), keeps dz in a wave-private
+// LDS tile [64 channels][64 pixels] (row stride 68 floats: every 16-byte access pattern below is conflict-free; dz never reaches
+// memory), reads it back as the A operand of the 1x1 data gradient (four consecutive pixels of a channel) and of the 1x1 weight
+// gradient (sixteen), and loads x ONCE (the gate of dx, then the B operand of the 1x1 weight gradient).  Edge handling is per
+// 16-pixel group (the weight body above sends the whole 64-pixel tile down the element-wise path when any lane sees an edge:
+// two tiles of every five at W = 320).  No block barrier in the loop.  Block partials in the layouts of the bodies above:
+// head_bwd_reduce2_kernel finishes them.
+struct HeadBwdFusedK {
+    const float* dy3;
+    const float* mid;
+    const float* x;
+    const float* w1;       // [64][32]
+    const float* w3[2];    // [3][32][3][3] per head
+    float* dx;
+    float* part3;          // [nblk][2][HB_PART]
+    float* part1;          // [nblk][H1_PART]
+    int B, H, W, n_out, pad_mode;
+    int row0[2], ch0[2];
+    float m_dslope, m_delu;   // act'(mid) = mid > 0 ? 1 : m_dslope + m_delu * mid
+    float x_dslope, x_delu;
+    int dbg;
+};
+constexpr int HF_RS = 68;
+constexpr int HF_WAVE_FLOATS = 64 * HF_RS;
+typedef float hf_f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global load
+
+// head_g_edge for the fused kernel: the same values, two rows (eight loads, eight lane masks) at a time behind scheduling barriers --
+// inlined eight times into a kernel that already holds 130 registers, the all-at-once form spilled 350 of them
+template <int N>
+__device__ __forceinline__ void hf_g_edge(float (&out)[N], const float* __restrict__ dyb, int r_first, int r_step, int r_limit,
+                                          const HeadPix& p, int W, int HW) {
+#pragma unroll
+    for (int n0 = 0; n0 < N; n0 += 2) {
+        float x[2][4];
+        bool ok[2][4];
+#pragma unroll
+        for (int n = n0; n < N && n < n0 + 2; ++n) {
+            const int r = min(r_first + n * r_step, 26), o = r / 9, ty = (r - 9 * o) / 3, tx = (r - 9 * o) % 3;
+            const int toff = o * HW - (ty - 1) * W - (tx - 1);
+            const bool want = r_first + n * r_step < r_limit;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    ok[n - n0][2 * c + d] = want && ((p.rm[c] >> ty) & (p.cm[d] >> tx) & 1u) != 0;
+                    x[n - n0][2 * c + d] = dyb[ok[n - n0][2 * c + d] ? p.base[c][d] + toff : 0];
+                }
+        }
+#pragma unroll
+        for (int n = n0; n < N && n < n0 + 2; ++n) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v += ok[n - n0][q] ? x[n - n0][q] : 0.f;
+            out[n] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// operands of one (head, 16-pixel group) step of the 3x3 stage, requested one step ahead
+struct HfPref {
+    float gA[7];      // data layout: rows 4 s + kq at pixel 16 g + j
+    float gW[2][4];   // weight layout: rows 16 rt + j at pixels 16 g + 4 kq + i
+    float4 mv[2];     // mid: channels 16 ct + j of the head at pixels 16 g + 4 kq + i
+};
+
+__global__ __launch_bounds__(256, 2) void head_bwd_fused32_kernel(const HeadBwdFusedK a) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * HF_WAVE_FLOATS + 32 * HF_RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int H = a.H, W = a.W, HW = H * W, T = HW / 64;
+    float* dzs = smem + wave * HF_WAVE_FLOATS;
+    float* w1t = smem + 4 * HF_WAVE_FLOATS;      // W1 as the B operand of the 1x1 data gradient: [ci][kq][s], c = 4 s + kq
+    const HeadFold fold = head_fold(H, W, a.pad_mode);
+    constexpr int KS = 7;     // K-steps of the 27 -> 28 rows of a head
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int c = e >> 5, ci = e & 31;
+        w1t[ci * HF_RS + (c & 3) * 16 + (c >> 2)] = a.w1[e];
+    }
+
+    // rows this lane gathers: data layout (A[pixel][row 4 s + kq]) and weight layout (A[row 16 rt + j][pixel])
+    int goff[KS], goffW[2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int r = min(4 * s + kq, 26), o = r / 9, ty = (r - 9 * o) / 3, tx = (r - 9 * o) % 3;
+        goff[s] = o * HW - (ty - 1) * W - (tx - 1);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = min(rt * 16 + j, 26), o = r / 9, ty = (r - 9 * o) / 3, tx = (r - 9 * o) % 3;
+        goffW[rt] = o * HW - (ty - 1) * W - (tx - 1);
+    }
+    // W3 as the B operand of the data gradient: row 4 s + kq, channel 16 ct + j of head h
+    float bw[2][2][KS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int r = min(4 * s + kq, 26), o = r / 9, tap = r - 9 * o;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) bw[h][ct][s] = 4 * s + kq < 27 ? a.w3[h][((size_t)o * 32 + ct * 16 + j) * 9 + tap] : 0.f;
+        }
+
+    f32x4 acc3[2][2][2], acc1[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc3[h][rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc1[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db3s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, db1s[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // requests the operands of step (head hh, group g) of tile (b, P0); edge handling per 16-pixel group (wave-uniform: the four kq
+    // replicas of a pixel agree).  The element-wise path consumes its loads on the spot (a stall on ~12 % of the groups).
+    auto fetch = [&](HfPref& p, int b, int P0, int hh, int g) __attribute__((always_inline)) {
+        const float* dyb = a.dy3 + ((size_t)b * a.n_out + (hh ? a.row0[1] : a.row0[0])) * HW;
+        const float* mp = a.mid + ((size_t)b * 64 + (hh ? a.ch0[1] : a.ch0[0]) + j) * HW + P0 + 16 * g + 4 * kq;
+        p.mv[0] = *reinterpret_cast<const float4*>(mp);
+        p.mv[1] = *reinterpret_cast<const float4*>(mp + (size_t)16 * HW);
+        const int P = P0 + 16 * g + j, qy = P / W, qx = P - qy * W;
+        const bool inner = qy >= 2 && qy < H - 2 && qx >= 2 && qx < W - 2;
+        if ((a.dbg & 1) || __builtin_amdgcn_ballot_w64(!inner) == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) p.gA[s] = 4 * s + kq < 27 ? dyb[goff[s] + P] : 0.f;
+            const int Pw = P0 + 16 * g + 4 * kq;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const hf_f32x4u v = *reinterpret_cast<const hf_f32x4u*>(dyb + goffW[rt] + Pw);
+                const bool ok = rt * 16 + j < 27;
+                p.gW[rt][0] = ok ? v.x : 0.f, p.gW[rt][1] = ok ? v.y : 0.f, p.gW[rt][2] = ok ? v.z : 0.f, p.gW[rt][3] = ok ? v.w : 0.f;
+            }
+        } else {
+            {
+                HeadPix pp;
+                head_pix(pp, qy, qx, H, W, fold);
+                hf_g_edge<KS>(p.gA, dyb, kq, 4, 27, pp, W, HW);          // rows 4 s + kq
+            }
+            // weight layout = the transpose of what the wave now holds: g[row 16 rt + j][pixel 4 kq + i] is register (16 rt + j) >> 2
+            // of lane (4 kq + i) + 16 (j & 3) -- 28 lane permutes instead of four more element-wise gathers
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int src = 4 * kq + i + 16 * (j & 3);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (4 * rt + q < KS) {
+                            const float t = __shfl(p.gA[4 * rt + q], src);
+                            v = (j >> 2) == q ? t : v;
+                        }
+                    }
+                    p.gW[rt][i] = rt * 16 + j < 27 ? v : 0.f;
+                }
+            }
+        }
+    };
+
+    __syncthreads();     // w1t is complete
+    const int ntile = a.B * T, stride = gridDim.x * 4;
+    int id = blockIdx.x * 4 + wave;
+    HfPref cur, nxt;
+    if (id < ntile) {
+        const int b = id / T;
+        fetch(cur, b, (id - b * T) * 64, 0, 0);
+    }
+    for (; id < ntile; id += stride) {
+        const int b = id / T, P0 = (id - b * T) * 64;
+        const int idn = id + stride, bn = idn / T, P0n = (idn - bn * T) * 64;
+        float4 xv[2][4];
+        // ---- 3x3 stage: one head, one 16-pixel group per step; the next step's operands are in flight behind this one's MFMAs ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* dyb = a.dy3 + ((size_t)b * a.n_out + a.row0[h]) * HW;
+            float dbv[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) dbv[o] = dyb[(size_t)o * HW + P0 + lane];
+            if (h == 1) {        // x: the gate of dx, then the B operand of the 1x1 weight gradient
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float* xp = a.x + ((size_t)b * 32 + ct * 16 + j) * HW + P0 + 16 * kq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xv[ct][i] = *reinterpret_cast<const float4*>(xp + 4 * i);
+                }
+            }
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+                {   // the successor of step (h, g): the next group, the other head, the next tile
+                    int nb = b, nP0 = P0, nh = h, ng = g + 1;
+                    if (g == 3) {
+                        ng = 0;
+                        if (h == 0) nh = 1;
+                        else nb = bn, nP0 = P0n, nh = 0;
+                    }
+                    if (h == 0 || g < 3 || idn < ntile) fetch(nxt, nb, nP0, nh, ng);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float4 m = cur.mv[ct];
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gA[s], bw[h][ct][s], acc, 0, 0, 0);
+                    f32x4 o;
+                    o[0] = acc[0] * (m.x > 0.f ? 1.f : fmaf(a.m_delu, m.x, a.m_dslope));
+                    o[1] = acc[1] * (m.y > 0.f ? 1.f : fmaf(a.m_delu, m.y, a.m_dslope));
+                    o[2] = acc[2] * (m.z > 0.f ? 1.f : fmaf(a.m_delu, m.z, a.m_dslope));
+                    o[3] = acc[3] * (m.w > 0.f ? 1.f : fmaf(a.m_delu, m.w, a.m_dslope));
+                    *reinterpret_cast<f32x4*>(dzs + (a.ch0[h] + ct * 16 + j) * HF_RS + 16 * g + 4 * kq) = o;
+                    // 3x3 weight gradient: K index kq of step (g, i) = pixel 16 g + 4 kq + i -- what m holds
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][0], m.x, acc3[h][rt][ct], 0, 0, 0);
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][1], m.y, acc3[h][rt][ct], 0, 0, 0);
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][2], m.z, acc3[h][rt][ct], 0, 0, 0);
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][3], m.w, acc3[h][rt][ct], 0, 0, 0);
+                    }
+                }
+                cur = nxt;
+            }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) db3s[h][o] += dbv[o];
+        }
+        // ---- 1x1 data gradient: D[pixel 4 j' + g][ci] += dz[pixel][c = 4 s + kq] * W1[c][ci] ----
+        if (!(a.dbg & 2)) {
+            f32x4 accB[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) accB[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+                const f32x4 wq0 = *reinterpret_cast<const f32x4*>(w1t + j * HF_RS + kq * 16 + 4 * sq);
+                const f32x4 wq1 = *reinterpret_cast<const f32x4*>(w1t + (16 + j) * HF_RS + kq * 16 + 4 * sq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int s = 4 * sq + e;
+                    const f32x4 A = *reinterpret_cast<const f32x4*>(dzs + (4 * s + kq) * HF_RS + 4 * j);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        accB[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g], wq0[e], accB[g][0], 0, 0, 0);
+                        accB[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g], wq1[e], accB[g][1], 0, 0, 0);
+                    }
+                }
+            }
+            // register i of group g = pixel 4 (4 kq + i) + g: a float4 over g is four consecutive pixels of channel 16 ct + j
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                float* dp = a.dx + ((size_t)b * 32 + ct * 16 + j) * HW + P0 + 16 * kq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 m = xv[ct][i];
+                    float4 o;
+                    o.x = accB[0][ct][i] * (m.x > 0.f ? 1.f : fmaf(a.x_delu, m.x, a.x_dslope));
+                    o.y = accB[1][ct][i] * (m.y > 0.f ? 1.f : fmaf(a.x_delu, m.y, a.x_dslope));
+                    o.z = accB[2][ct][i] * (m.z > 0.f ? 1.f : fmaf(a.x_delu, m.z, a.x_dslope));
+                    o.w = accB[3][ct][i] * (m.w > 0.f ? 1.f : fmaf(a.x_delu, m.w, a.x_dslope));
+                    *reinterpret_cast<float4*>(dp + 4 * i) = o;
+                }
+            }
+        }
+        // ---- 1x1 weight gradient: D[c][ci] += dz[c = 16 rt + j][pixel 16 kq + s] * x[pixel][ci] ----
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            if (a.dbg & 4) break;
+            f32x4 A[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) A[q] = *reinterpret_cast<const f32x4*>(dzs + (rt * 16 + j) * HF_RS + 16 * kq + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) db1s[rt] += (A[q][0] + A[q][1]) + (A[q][2] + A[q][3]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc1[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][0], xv[ct][q].x, acc1[rt][ct], 0, 0, 0);
+                    acc1[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][1], xv[ct][q].y, acc1[rt][ct], 0, 0, 0);
+                    acc1[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][2], xv[ct][q].z, acc1[rt][ct], 0, 0, 0);
+                    acc1[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][3], xv[ct][q].w, acc1[rt][ct], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- block partials (the layouts of head3x3_bwd_weight_body / head1x1_bwd_weight_body) ----
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) db3s[h][o] += __shfl_xor(db3s[h][o], sh);
+        }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        db1s[rt] += __shfl_xor(db1s[rt], 16);
+        db1s[rt] += __shfl_xor(db1s[rt], 32);
+    }
+    __syncthreads();     // every wave is done with its dz tile: the space becomes the reduction buffer
+    f32x4 (*red)[16][64] = reinterpret_cast<f32x4 (*)[16][64]>(smem);            // [3][16 tiles][64 lanes]
+    float (*dbr3)[8] = reinterpret_cast<float (*)[8]>(smem + 3 * 16 * 64 * 4);    // [4][8]
+    float (*dbr1)[64] = reinterpret_cast<float (*)[64]>(smem + 3 * 16 * 64 * 4 + 32);   // [4][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) red[wave - 1][h * 4 + rt * 2 + ct][lane] = acc3[h][rt][ct];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) red[wave - 1][8 + rt * 2 + ct][lane] = acc1[rt][ct];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) dbr3[wave][h * 3 + o] = db3s[h][o];
+    }
+    if (kq == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) dbr1[wave][rt * 16 + j] = db1s[rt];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float* out = a.part3 + ((size_t)blockIdx.x * 2 + h) * HB_PART;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    f32x4 v = acc3[h][rt][ct];
+                    for (int w = 0; w < 3; ++w) v += red[w][h * 4 + rt * 2 + ct][lane];
+                    *reinterpret_cast<f32x4*>(out + ((rt * 4 + ct) * 64 + lane) * 4) = v;
+                }
+            if (lane < 3) {
+                float t = dbr3[0][h * 3 + lane];
+                for (int w = 1; w < 4; ++w) t += dbr3[w][h * 3 + lane];
+                out[8 * 256 + lane] = t;
+            }
+        }
+        float* out = a.part1 + (size_t)blockIdx.x * H1_PART;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x4 v = acc1[rt][ct];
+                for (int w = 0; w < 3; ++w) v += red[w][8 + rt * 2 + ct][lane];
+                *reinterpret_cast<f32x4*>(out + ((rt * 4 + ct) * 64 + lane) * 4) = v;
+            }
+        float t = dbr1[0][lane];
+        for (int w = 1; w < 4; ++w) t += dbr1[w][lane];
+        out[16 * 256 + lane] = t;
+    }
+}
+
 int head1x1_blocks(const wmd_head1x1_bwd_args* g);
 int head1x1_validate(const wmd_head1x1_bwd_args* g);
 void head1x1_fill(const wmd_head1x1_bwd_args* g, Head1x1K* a);
@@ -494,6 +856,11 @@ void head1x1_fill(const wmd_head1x1_bwd_args* g, Head1x1K* a);
 static int head_bwd_blocks(const wmd_head3x3_bwd_args* g) {
     const long tiles = (long)g->B * (((long)g->H * g->W + 63) / 64);
     return (int)std::max<long>(1, std::min<long>((tiles + HB_WW - 1) / HB_WW, 256));
+}
+// blocks the workspace is sized for: the fused C = 32 launch runs the 1x1 stage's block count (two blocks per CU)
+static int head_bwd_ws_blocks(const wmd_head3x3_bwd_args* g) {
+    const long tiles = (long)g->B * (((long)g->H * g->W + 63) / 64);
+    return std::max(head_bwd_blocks(g), (int)std::max<long>(1, std::min<long>((tiles + H1_WW - 1) / H1_WW, H1_MAX_BLK)));
 }
 
 }  // namespace wmd
@@ -529,7 +896,7 @@ static int head_bwd_validate(const wmd_head3x3_bwd_args* g, int* n_slices) {
 extern "C" size_t wmd_head3x3_bwd_workspace_floats(const wmd_head3x3_bwd_args* g) {
     int n = 0;
     if (head_bwd_validate(g, &n)) return 0;
-    return (size_t)head_bwd_blocks(g) * n * HB_PART;
+    return (size_t)head_bwd_ws_blocks(g) * n * HB_PART;
 }
 
 // fills the kernel arguments of the launch set for heads with `nrows` output channels; returns the floats of partials it uses
@@ -600,8 +967,21 @@ extern "C" int wmd_head3x3_bwd(const wmd_head3x3_bwd_args* g, void* stream) {
     return WMD_OK;
 }
 
+// may both stages run as head_bwd_fused32_kernel?  (two 3-channel heads of 32 channels each over a 32-channel x, whole 64-pixel
+// tiles, rows that are multiples of four pixels; WMD_HEAD_BWD_FUSED=0: never)
+static bool head_bwd_fused_ok(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bwd_args* a1) {
+    static const bool on = !(getenv("WMD_HEAD_BWD_FUSED") && atoi(getenv("WMD_HEAD_BWD_FUSED")) == 0);
+    if (!on || a3->n_heads != 2 || a3->Ct != 64 || a1->C != 32 || !a1->dx) return false;
+    for (int k = 0; k < 2; ++k)
+        if (a3->head[k].nrows != 3 || a3->head[k].nch != 32 || (a3->head[k].ch0 != 0 && a3->head[k].ch0 != 32)) return false;
+    if (a3->head[0].ch0 == a3->head[1].ch0) return false;
+    const long HW = (long)a3->H * a3->W;
+    return a3->H >= 4 && a3->W >= 4 && a3->W % 4 == 0 && HW % 64 == 0;
+}
+
 // Both stages of a level's heads in three launches: the 3x3 data gradient (-> dzmid), then the 3x3 weight gradient + the 1x1
 // data gradient + the 1x1 weight gradient as ONE launch, then both reduces as one.  a1->dz must be a3->dzmid.
+// Round 6, C = 32 levels: ONE launch for all four GEMMs (head_bwd_fused32_kernel; dzmid is then not written) + the reduce.
 extern "C" int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bwd_args* a1, void* stream) {
     int n_all = 0;
     if (int st = head_bwd_validate(a3, &n_all)) return st;
@@ -610,7 +990,8 @@ extern "C" int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bw
         if (a3->head[k].nrows != 3) return fail(WMD_ERR_UNSUPPORTED, "wmd_head_bwd: 3-channel heads only (the low-pass head: wmd_head3x3_bwd + wmd_head1x1_bwd)");
     if (a1->dz != a3->dzmid || a1->B != a3->B || a1->H != a3->H || a1->W != a3->W || a1->Ct != a3->Ct)
         return fail(WMD_ERR_BAD_ARG, "wmd_head_bwd: the 1x1 stage must consume the 3x3 stage's dzmid (same B, H, W, Ct)");
-    const int nblk3 = head_bwd_blocks(a3);
+    const bool fused = head_bwd_fused_ok(a3, a1) && a3->workspace && a3->workspace_floats >= (size_t)head1x1_blocks(a1) * n_all * HB_PART;
+    const int nblk3 = fused ? head1x1_blocks(a1) : head_bwd_blocks(a3);
     if (!a3->workspace || a3->workspace_floats < (size_t)nblk3 * n_all * HB_PART)
         return fail(WMD_ERR_WORKSPACE, "wmd_head_bwd: 3x3 workspace %zu < %zu floats", a3->workspace_floats, (size_t)nblk3 * n_all * HB_PART);
     HeadBwdStage2K m;
@@ -622,7 +1003,6 @@ extern "C" int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bw
     if (!a1->workspace || a1->workspace_floats < need1)
         return fail(WMD_ERR_WORKSPACE, "wmd_head_bwd: 1x1 workspace %zu < %zu floats", a1->workspace_floats, need1);
     hipStream_t s = (hipStream_t)stream;
-    if (int st = head_bwd_launch_data(a3, m.h3, 3, ch, s)) return st;
     const double pix = (double)a3->B * a3->H * a3->W;
     const long tiles = (long)a3->B * (((long)a3->H * a3->W + 63) / 64);
     m.n3 = m.h3.n_slices;
@@ -631,12 +1011,28 @@ extern "C" int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bw
     m.nb3 = nblk3;
     m.nb1d = (int)std::max<long>(1, std::min<long>((tiles + 3) / 4, 1024));
     m.nb1w = m.h1.nblk;
+    if (fused) {
+        HeadBwdFusedK f;
+        memset(&f, 0, sizeof(f));
+        f.dy3 = a3->dy3, f.mid = a3->mid, f.x = a1->x, f.w1 = a1->w1, f.dx = a1->dx;
+        f.part3 = m.h3.partial, f.part1 = m.h1.partial;
+        f.B = a3->B, f.H = a3->H, f.W = a3->W, f.n_out = a3->n_out, f.pad_mode = a3->pad_mode;
+        for (int k = 0; k < 2; ++k) f.w3[k] = a3->head[k].w3, f.row0[k] = a3->head[k].row0, f.ch0[k] = a3->head[k].ch0;
+        f.m_dslope = a3->act == WMD_ACT_LEAKY ? a3->slope : 1.f, f.m_delu = a3->act == WMD_ACT_ELU ? 1.f : 0.f;
+        f.x_dslope = m.h1.dslope, f.x_delu = m.h1.delu;
+        f.dbg = getenv("WMD_HF_DBG") ? atoi(getenv("WMD_HF_DBG")) : 0;
+        ProfScope prof("head_bwd_fused32_kernel", 2.0 * pix * (2.0 * 27 * 64 + 2.0 * 64 * 32), 4.0 * pix * (64 + 32 + 32 + a3->n_out), s);
+        hipLaunchKernelGGL(head_bwd_fused32_kernel, dim3(nblk3), dim3(256), 0, s, f);
+        if (int st = check_launch("head_bwd_fused32_kernel")) return st;
+    } else {
+    if (int st = head_bwd_launch_data(a3, m.h3, 3, ch, s)) return st;
     {
         ProfScope prof("head_bwd_stage2_kernel", 2.0 * pix * (27.0 * ch + 2.0 * a1->C * a1->Ct),
                        4.0 * pix * (ch + 3.0 + 2.0 * a1->Ct + 3.0 * a1->C), s);
         hipLaunchKernelGGL(head_bwd_stage2_kernel, dim3(std::max(m.nb3, std::max(m.nb1d, m.nb1w)), m.n3 + m.n1d + m.n1w), dim3(256), 0, s, m);
     }
     if (int st = check_launch("head_bwd_stage2_kernel")) return st;
+    }
     {
         ProfScope prof("head_bwd_reduce2_kernel", (double)nblk3 * m.n3 * HB_PART + (double)need1, 4.0 * (nblk3 * m.n3 * HB_PART + need1), s);
         hipLaunchKernelGGL(head_bwd_reduce2_kernel, dim3(m.n3 + m.n1w, (64 * 64 + 64 + 15) / 16), dim3(256), 0, s, m);
