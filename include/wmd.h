@@ -486,7 +486,9 @@ int wmd_head1x1_bwd(const wmd_head1x1_bwd_args* args, void* stream);
  * 3x3 weight gradient, the 1x1 data gradient and the 1x1 weight gradient -- independent of each other once dzmid exists, each a
  * latency chain on its own -- as ONE launch; then both reduces as one.  Same arguments and results as wmd_head3x3_bwd(a3)
  * followed by wmd_head1x1_bwd(a1) with a1->dz == a3->dzmid; 3-channel heads only (a level with the low-pass head: the two
- * separate calls).                                                                                                        */
+ * separate calls).  Round 6: a level of two 32-channel heads over a 32-channel x (Ct = 64, whole 64-pixel tiles, W % 4 == 0,
+ * dx wanted) runs all four GEMMs as ONE launch (head_bwd_fused32_kernel) + the reduce; dzmid then stays in LDS and the buffer
+ * is NOT written (it is scratch of this call either way).  WMD_HEAD_BWD_FUSED=0: always the three-launch form.               */
 int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bwd_args* a1, void* stream);
 
 /* ------------------------------------------------------------------ *

@@ -494,10 +494,15 @@ __global__ __launch_bounds__(256) void head_bwd_reduce2_kernel(const HeadBwdStag
 // with the K index ordered the way the data gradient's accumulators come out: pixel 16 g + 4 kq + i), keeps dz in a wave-private
 // LDS tile [64 channels][64 pixels] (row stride 68 floats: every 16-byte access pattern below is conflict-free; dz never reaches
 // memory), reads it back as the A operand of the 1x1 data gradient (four consecutive pixels of a channel) and of the 1x1 weight
-// gradient (sixteen), and loads x ONCE (the gate of dx, then the B operand of the 1x1 weight gradient).  Edge handling is per
-// 16-pixel group (the weight body above sends the whole 64-pixel tile down the element-wise path when any lane sees an edge:
-// two tiles of every five at W = 320).  No block barrier in the loop.  Block partials in the layouts of the bodies above:
-// head_bwd_reduce2_kernel finishes them.
+// gradient (sixteen), and loads x ONCE (the gate of dx, then the B operand of the 1x1 weight gradient).  The 3x3 stage walks
+// (head, 16-pixel group) steps on two operand sets: the next step's gathers and mid are in flight behind this step's 30 MFMAs (a
+// register rotation by copies would wait for the very loads it copies).  Edge handling is per 16-pixel group (the weight body above
+// sends the whole 64-pixel tile down the element-wise path when any lane sees an edge: two tiles of every five at W = 320): the
+// data layout is gathered element-wise, the weight layout is its transpose by 28 lane permutes.  No block barrier in the loop.
+// Block partials in the layouts of the bodies above: head_bwd_reduce2_kernel finishes them.
+// Measured (config 2's finest level, 12 x 96 x 320): 0.139 ms against 0.215 ms for head3x3_bwd_data_kernel + this level's share of
+// head_bwd_stage2_kernel.  Where the rest goes (switches since removed): no edge groups 0.116; no mid loads 0.094; no loads at all
+// 0.084; the 3x3 stage's instruction stream alone 0.048 for 22.7 us of MFMA issue -- 30 MFMAs of K = 4 per ~65 other instructions.
 struct HeadBwdFusedK {
     const float* dy3;
     const float* mid;
@@ -511,11 +516,9 @@ struct HeadBwdFusedK {
     int row0[2], ch0[2];
     float m_dslope, m_delu;   // act'(mid) = mid > 0 ? 1 : m_dslope + m_delu * mid
     float x_dslope, x_delu;
-    int dbg;
 };
 constexpr int HF_RS = 68;
 constexpr int HF_WAVE_FLOATS = 64 * HF_RS;
-typedef float hf_f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global load
 
 // head_g_edge for the fused kernel: the same values, two rows (eight loads, eight lane masks) at a time behind scheduling barriers --
 // inlined eight times into a kernel that already holds 130 registers, the all-at-once form spilled 350 of them
@@ -554,7 +557,9 @@ __device__ __forceinline__ void hf_g_edge(float (&out)[N], const float* __restri
 struct HfPref {
     float gA[7];      // data layout: rows 4 s + kq at pixel 16 g + j
     float gW[2][4];   // weight layout: rows 16 rt + j at pixels 16 g + 4 kq + i
-    float4 mv[2];     // mid: channels 16 ct + j of the head at pixels 16 g + 4 kq + i
+};
+struct HfMid {
+    float4 v[2];      // mid: channels 16 ct + j of the head at pixels 16 g + 4 kq + i
 };
 
 __global__ __launch_bounds__(256, 2) void head_bwd_fused32_kernel(const HeadBwdFusedK a) {
@@ -607,24 +612,29 @@ __global__ __launch_bounds__(256, 2) void head_bwd_fused32_kernel(const HeadBwdF
         for (int ct = 0; ct < 2; ++ct) acc1[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float db3s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, db1s[4] = {0.f, 0.f, 0.f, 0.f};
 
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy3), 0, a.B * a.n_out * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmid = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mid), 0, a.B * 64 * HW * 4, 0x00020000);
+    const unsigned mid_lane = (unsigned)(j * HW + 4 * kq) * 4u;
     // requests the operands of step (head hh, group g) of tile (b, P0); edge handling per 16-pixel group (wave-uniform: the four kq
     // replicas of a pixel agree).  The element-wise path consumes its loads on the spot (a stall on ~12 % of the groups).
     auto fetch = [&](HfPref& p, int b, int P0, int hh, int g) __attribute__((always_inline)) {
         const float* dyb = a.dy3 + ((size_t)b * a.n_out + (hh ? a.row0[1] : a.row0[0])) * HW;
-        const float* mp = a.mid + ((size_t)b * 64 + (hh ? a.ch0[1] : a.ch0[0]) + j) * HW + P0 + 16 * g + 4 * kq;
-        p.mv[0] = *reinterpret_cast<const float4*>(mp);
-        p.mv[1] = *reinterpret_cast<const float4*>(mp + (size_t)16 * HW);
         const int P = P0 + 16 * g + j, qy = P / W, qx = P - qy * W;
         const bool inner = qy >= 2 && qy < H - 2 && qx >= 2 && qx < W - 2;
-        if ((a.dbg & 1) || __builtin_amdgcn_ballot_w64(!inner) == 0) {
+        if (__builtin_amdgcn_ballot_w64(!inner) == 0) {
+            // buffer loads: the plane's base is a scalar offset, the lane adds ONE 32-bit offset per load.  Rows past the 27th (the
+            // pad of the K index / of the last row tile) read row 26 again: their products meet a zero weight (data gradient) or
+            // land in rows of the weight tile that the reduce never reads -- no selects.
+            const unsigned soff = (unsigned)((b * a.n_out + (hh ? a.row0[1] : a.row0[0])) * HW) * 4u;
+            const int P4 = P * 4;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) p.gA[s] = 4 * s + kq < 27 ? dyb[goff[s] + P] : 0.f;
-            const int Pw = P0 + 16 * g + 4 * kq;
+            for (int s = 0; s < KS; ++s)
+                p.gA[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, (unsigned)(goff[s] * 4 + P4), soff, 0));
+            const int Pw4 = (P0 + 16 * g + 4 * kq) * 4;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const hf_f32x4u v = *reinterpret_cast<const hf_f32x4u*>(dyb + goffW[rt] + Pw);
-                const bool ok = rt * 16 + j < 27;
-                p.gW[rt][0] = ok ? v.x : 0.f, p.gW[rt][1] = ok ? v.y : 0.f, p.gW[rt][2] = ok ? v.z : 0.f, p.gW[rt][3] = ok ? v.w : 0.f;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (unsigned)(goffW[rt] * 4 + Pw4), soff, 0));
+                p.gW[rt][0] = v[0], p.gW[rt][1] = v[1], p.gW[rt][2] = v[2], p.gW[rt][3] = v[3];
             }
         } else {
             {
@@ -653,13 +663,24 @@ __global__ __launch_bounds__(256, 2) void head_bwd_fused32_kernel(const HeadBwdF
         }
     };
 
+    auto fetch_mid = [&](HfMid& m, int b, int P0, int hh, int g) __attribute__((always_inline)) {
+        // scalar offset: the head's first plane + the group; lane offset: its channel's plane + its four pixels (a constant)
+        const unsigned soff = (unsigned)((b * 64 + (hh ? a.ch0[1] : a.ch0[0])) * HW + P0 + 16 * g) * 4u;
+        const f32x4 v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmid, mid_lane, soff, 0));
+        const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmid, mid_lane, soff + (unsigned)(16 * HW) * 4u, 0));
+        m.v[0] = make_float4(v0[0], v0[1], v0[2], v0[3]);
+        m.v[1] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    };
+
     __syncthreads();     // w1t is complete
     const int ntile = a.B * T, stride = gridDim.x * 4;
     int id = blockIdx.x * 4 + wave;
-    HfPref cur, nxt;
+    HfPref pa, pb;       // operand sets of the even / odd steps
+    HfMid ma, mb;
     if (id < ntile) {
-        const int b = id / T;
-        fetch(cur, b, (id - b * T) * 64, 0, 0);
+        const int b = id / T, P0 = (id - b * T) * 64;
+        fetch_mid(ma, b, P0, 0, 0);
+        fetch(pa, b, P0, 0, 0);
     }
     for (; id < ntile; id += stride) {
         const int b = id / T, P0 = (id - b * T) * 64;
@@ -672,16 +693,8 @@ __global__ __launch_bounds__(256, 2) void head_bwd_fused32_kernel(const HeadBwdF
             float dbv[3];
 #pragma unroll
             for (int o = 0; o < 3; ++o) dbv[o] = dyb[(size_t)o * HW + P0 + lane];
-            if (h == 1) {        // x: the gate of dx, then the B operand of the 1x1 weight gradient
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const float* xp = a.x + ((size_t)b * 32 + ct * 16 + j) * HW + P0 + 16 * kq;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xv[ct][i] = *reinterpret_cast<const float4*>(xp + 4 * i);
-                }
-            }
-#pragma unroll 1
-            for (int g = 0; g < 4; ++g) {
+            // two steps per iteration on two operand sets (A, B): a register rotation by copies would wait for the loads it copies
+            auto step = [&](const HfPref& c, const HfMid& cm, HfPref& n, HfMid& nm, int g) __attribute__((always_inline)) {
                 {   // the successor of step (h, g): the next group, the other head, the next tile
                     int nb = b, nP0 = P0, nh = h, ng = g + 1;
                     if (g == 3) {
@@ -689,14 +702,24 @@ __global__ __launch_bounds__(256, 2) void head_bwd_fused32_kernel(const HeadBwdF
                         if (h == 0) nh = 1;
                         else nb = bn, nP0 = P0n, nh = 0;
                     }
-                    if (h == 0 || g < 3 || idn < ntile) fetch(nxt, nb, nP0, nh, ng);
+                    if (h == 0 || g < 3) {      // (the next tile's first step is requested behind the 1x1 data gradient, below)
+                        fetch_mid(nm, nb, nP0, nh, ng);
+                        fetch(n, nb, nP0, nh, ng);
+                    } else {                    // the tile's last step requests x: the gate of dx, then the B operand of the 1x1 weight gradient
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const float* xp = a.x + ((size_t)b * 32 + ct * 16 + j) * HW + P0 + 16 * kq;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xv[ct][i] = *reinterpret_cast<const float4*>(xp + 4 * i);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const float4 m = cur.mv[ct];
+                    const float4 m = cm.v[ct];
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gA[s], bw[h][ct][s], acc, 0, 0, 0);
+                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.gA[s], bw[h][ct][s], acc, 0, 0, 0);
                     f32x4 o;
                     o[0] = acc[0] * (m.x > 0.f ? 1.f : fmaf(a.m_delu, m.x, a.m_dslope));
                     o[1] = acc[1] * (m.y > 0.f ? 1.f : fmaf(a.m_delu, m.y, a.m_dslope));
@@ -706,59 +729,61 @@ __global__ __launch_bounds__(256, 2) void head_bwd_fused32_kernel(const HeadBwdF
                     // 3x3 weight gradient: K index kq of step (g, i) = pixel 16 g + 4 kq + i -- what m holds
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
-                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][0], m.x, acc3[h][rt][ct], 0, 0, 0);
-                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][1], m.y, acc3[h][rt][ct], 0, 0, 0);
-                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][2], m.z, acc3[h][rt][ct], 0, 0, 0);
-                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gW[rt][3], m.w, acc3[h][rt][ct], 0, 0, 0);
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.gW[rt][0], m.x, acc3[h][rt][ct], 0, 0, 0);
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.gW[rt][1], m.y, acc3[h][rt][ct], 0, 0, 0);
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.gW[rt][2], m.z, acc3[h][rt][ct], 0, 0, 0);
+                        acc3[h][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.gW[rt][3], m.w, acc3[h][rt][ct], 0, 0, 0);
                     }
                 }
-                cur = nxt;
+            };
+#pragma unroll 1
+            for (int gp = 0; gp < 2; ++gp) {
+                step(pa, ma, pb, mb, 2 * gp);
+                step(pb, mb, pa, ma, 2 * gp + 1);
             }
 #pragma unroll
             for (int o = 0; o < 3; ++o) db3s[h][o] += dbv[o];
         }
-        // ---- 1x1 data gradient: D[pixel 4 j' + g][ci] += dz[pixel][c = 4 s + kq] * W1[c][ci] ----
-        if (!(a.dbg & 2)) {
-            f32x4 accB[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) accB[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int sq = 0; sq < 4; ++sq) {
-                const f32x4 wq0 = *reinterpret_cast<const f32x4*>(w1t + j * HF_RS + kq * 16 + 4 * sq);
-                const f32x4 wq1 = *reinterpret_cast<const f32x4*>(w1t + (16 + j) * HF_RS + kq * 16 + 4 * sq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int s = 4 * sq + e;
-                    const f32x4 A = *reinterpret_cast<const f32x4*>(dzs + (4 * s + kq) * HF_RS + 4 * j);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        accB[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g], wq0[e], accB[g][0], 0, 0, 0);
-                        accB[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g], wq1[e], accB[g][1], 0, 0, 0);
-                    }
-                }
-            }
-            // register i of group g = pixel 4 (4 kq + i) + g: a float4 over g is four consecutive pixels of channel 16 ct + j
+        // ---- 1x1 data gradient: D[pixel 4 j' + g][ci] += dz[pixel][c = 4 s + kq] * W1[c][ci]; one 16-channel tile of ci at a time
+        //      (both at once: 32 accumulators more than the register file has left) ----
+        {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
+                f32x4 accB[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) accB[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sq = 0; sq < 4; ++sq) {
+                    const f32x4 wq = *reinterpret_cast<const f32x4*>(w1t + (ct * 16 + j) * HF_RS + kq * 16 + 4 * sq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int s = 4 * sq + e;
+                        const f32x4 A = *reinterpret_cast<const f32x4*>(dzs + (4 * s + kq) * HF_RS + 4 * j);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) accB[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g], wq[e], accB[g], 0, 0, 0);
+                    }
+                }
+                // register i of group g = pixel 4 (4 kq + i) + g: a float4 over g is four consecutive pixels of channel 16 ct + j
                 float* dp = a.dx + ((size_t)b * 32 + ct * 16 + j) * HW + P0 + 16 * kq;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float4 m = xv[ct][i];
                     float4 o;
-                    o.x = accB[0][ct][i] * (m.x > 0.f ? 1.f : fmaf(a.x_delu, m.x, a.x_dslope));
-                    o.y = accB[1][ct][i] * (m.y > 0.f ? 1.f : fmaf(a.x_delu, m.y, a.x_dslope));
-                    o.z = accB[2][ct][i] * (m.z > 0.f ? 1.f : fmaf(a.x_delu, m.z, a.x_dslope));
-                    o.w = accB[3][ct][i] * (m.w > 0.f ? 1.f : fmaf(a.x_delu, m.w, a.x_dslope));
+                    o.x = accB[0][i] * (m.x > 0.f ? 1.f : fmaf(a.x_delu, m.x, a.x_dslope));
+                    o.y = accB[1][i] * (m.y > 0.f ? 1.f : fmaf(a.x_delu, m.y, a.x_dslope));
+                    o.z = accB[2][i] * (m.z > 0.f ? 1.f : fmaf(a.x_delu, m.z, a.x_dslope));
+                    o.w = accB[3][i] * (m.w > 0.f ? 1.f : fmaf(a.x_delu, m.w, a.x_dslope));
                     *reinterpret_cast<float4*>(dp + 4 * i) = o;
                 }
             }
         }
+        if (idn < ntile) {       // the next tile's first step: in flight behind the 128 MFMAs below
+            fetch_mid(ma, bn, P0n, 0, 0);
+            fetch(pa, bn, P0n, 0, 0);
+        }
         // ---- 1x1 weight gradient: D[c][ci] += dz[c = 16 rt + j][pixel 16 kq + s] * x[pixel][ci] ----
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            if (a.dbg & 4) break;
             f32x4 A[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) A[q] = *reinterpret_cast<const f32x4*>(dzs + (rt * 16 + j) * HF_RS + 16 * kq + 4 * q);
@@ -1020,7 +1045,6 @@ extern "C" int wmd_head_bwd(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_bw
         for (int k = 0; k < 2; ++k) f.w3[k] = a3->head[k].w3, f.row0[k] = a3->head[k].row0, f.ch0[k] = a3->head[k].ch0;
         f.m_dslope = a3->act == WMD_ACT_LEAKY ? a3->slope : 1.f, f.m_delu = a3->act == WMD_ACT_ELU ? 1.f : 0.f;
         f.x_dslope = m.h1.dslope, f.x_delu = m.h1.delu;
-        f.dbg = getenv("WMD_HF_DBG") ? atoi(getenv("WMD_HF_DBG")) : 0;
         ProfScope prof("head_bwd_fused32_kernel", 2.0 * pix * (2.0 * 27 * 64 + 2.0 * 64 * 32), 4.0 * pix * (64 + 32 + 32 + a3->n_out), s);
         hipLaunchKernelGGL(head_bwd_fused32_kernel, dim3(nblk3), dim3(256), 0, s, f);
         if (int st = check_launch("head_bwd_fused32_kernel")) return st;
