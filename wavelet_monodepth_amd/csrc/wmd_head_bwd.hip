@@ -253,9 +253,10 @@ __global__ __launch_bounds__(256) void head3x3_bwd_data_kernel(const HeadBwdK a)
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
-// D[row 16][channel 16] += A[row][pixel] * B[pixel][channel] over the pixels (K index kq of MFMA step s = pixel 16 kq + s of the
-// wave's 64): lane (r16 = l & 15, kq) gathers g of ITS row for 16 consecutive pixels, lane (j, kq) loads mid of channel j for
-// the same 16 pixels (four 16-byte loads when the plane allows).  Accumulators stay in registers over all tiles of the block.
+// D[row 16][channel 16] += A[row][pixel] * B[pixel][channel] over the pixels (K index kq of MFMA step 4 g + i = pixel
+// 16 g + 4 kq + i of the wave's 64): lane (r16 = l & 15, kq) gathers g of ITS row for four pixels of each 16-pixel group, lane
+// (j, kq) loads mid of channel j for the same pixels (four 16-byte loads when the plane allows).  Accumulators stay in registers
+// over all tiles of the block.
 constexpr int HB_WW = 4;   // wavefronts per block of the weight kernel (256 threads: it also runs as a component of the merged launch)
 template <int NROWS>
 __device__ __forceinline__ void head3x3_bwd_weight_body(const HeadBwdK& a, int bx, int by, int nbx, float* smem) {
@@ -290,21 +291,26 @@ __device__ __forceinline__ void head3x3_bwd_weight_body(const HeadBwdK& a, int b
     for (int id = bx * HB_WW + wave; id < a.B * T; id += nbx * HB_WW) {
         const int b = id / T, P0 = (id - b * T) * 64;
         const float* dyb = a.dy3 + ((size_t)b * a.n_out + sl.row0) * HW;
-        const int Pl = P0 + 16 * kq;     // this lane's 16 pixels
+        // K index kq of MFMA step 4 g + i = pixel 16 g + 4 kq + i of the wave's 64 (round 6; before: 16 kq + s): the edge test is
+        // then per 16-PIXEL GROUP -- with sixteen consecutive pixels per lane one edge pixel anywhere sent the whole tile down the
+        // element-wise path: two tiles of five at W = 320, four of five at W = 160, every tile at W = 80
         float gA[RT][16];
-        {
-            int qy = Pl / a.W, qx = Pl - qy * a.W;     // walks the 16 pixels in raster order
-            // the lane's 16 pixels are all two or more away from every edge <=> one row, columns 2 .. W-3, rows 2 .. H-3
-            const bool inner = Pl + 16 <= HW && qy >= 2 && qy < a.H - 2 && qx >= 2 && qx + 15 < a.W - 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int Pj = P0 + 16 * g + j;             // the group's pixels, one per j (the four kq replicas agree)
+            const int qyj = Pj / a.W, qxj = Pj - qyj * a.W;
+            const bool inner = Pj < HW && qyj >= 2 && qyj < a.H - 2 && qxj >= 2 && qxj < a.W - 2;
+            const int Pq = P0 + 16 * g + 4 * kq;        // this lane's four pixels of the group
             if (__builtin_amdgcn_ballot_w64(!inner) == 0) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) gA[rt][s] = rt * 16 + j < KR ? dyb[goff[rt] + Pl + s] : 0.f;
+                    for (int rt = 0; rt < RT; ++rt) gA[rt][4 * g + i] = rt * 16 + j < KR ? dyb[goff[rt] + Pq + i] : 0.f;
             } else {
+                int qy = Pq / a.W, qx = Pq - qy * a.W;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const bool valid = Pl + s < HW;
+                for (int i = 0; i < 4; ++i) {
+                    const bool valid = Pq + i < HW;
                     if (!tiny) {
                         HeadPix pp;
                         head_pix(pp, valid ? qy : 2, valid ? qx : 2, a.H, a.W, fold);
@@ -314,14 +320,14 @@ __device__ __forceinline__ void head3x3_bwd_weight_body(const HeadBwdK& a, int b
                         for (int rt = 0; rt < RT; ++rt) want[rt] = valid && rt * 16 + j < KR;
                         head_g_edge<RT>(gv, dyb, go, gty, gtx, want, pp, a.W, HW);
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) gA[rt][s] = gv[rt];
+                        for (int rt = 0; rt < RT; ++rt) gA[rt][4 * g + i] = gv[rt];
                     } else {
                         int ys[3], xs[3];
                         const int ny = fold_preimage(qy, a.H, a.pad_mode, ys), nx = fold_preimage(qx, a.W, a.pad_mode, xs);
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            gA[rt][s] = (valid && rt * 16 + j < KR)
-                                            ? head_g(dyb + (size_t)go[rt] * HW, a.H, a.W, ys, ny, xs, nx, gty[rt], gtx[rt]) : 0.f;
+                            gA[rt][4 * g + i] = (valid && rt * 16 + j < KR)
+                                                    ? head_g(dyb + (size_t)go[rt] * HW, a.H, a.W, ys, ny, xs, nx, gty[rt], gtx[rt]) : 0.f;
                     }
                     if (++qx == a.W) qx = 0, ++qy;
                 }
@@ -337,16 +343,18 @@ __device__ __forceinline__ void head3x3_bwd_weight_body(const HeadBwdK& a, int b
         for (int ct = 0; ct < 4; ++ct) {
             const int c = sl.c_begin + ct * 16 + j;
             const bool c_ok = ct < nct && c < sl.c_begin + sl.c_count;
-            const float* mp = a.mid + ((size_t)b * a.Ct + sl.ch0 + min(c, sl.c_begin + sl.c_count - 1)) * HW + Pl;
-            if (vec && Pl + 16 <= HW) {
+            const float* mp = a.mid + ((size_t)b * a.Ct + sl.ch0 + min(c, sl.c_begin + sl.c_count - 1)) * HW + P0 + 4 * kq;
+            if (vec && P0 + 64 <= HW) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float4 v = c_ok ? *reinterpret_cast<const float4*>(mp + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    mB[ct][4 * q4] = v.x, mB[ct][4 * q4 + 1] = v.y, mB[ct][4 * q4 + 2] = v.z, mB[ct][4 * q4 + 3] = v.w;
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = c_ok ? *reinterpret_cast<const float4*>(mp + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    mB[ct][4 * g] = v.x, mB[ct][4 * g + 1] = v.y, mB[ct][4 * g + 2] = v.z, mB[ct][4 * g + 3] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) mB[ct][s] = (c_ok && Pl + s < HW) ? mp[s] : 0.f;
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mB[ct][4 * g + i] = (c_ok && P0 + 16 * g + 4 * kq + i < HW) ? mp[16 * g + i] : 0.f;
             }
         }
 #pragma unroll
