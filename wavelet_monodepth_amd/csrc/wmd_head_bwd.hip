@@ -16,6 +16,7 @@
 // resident) and mid; both are bound by reading mid once (+ writing dz once).
 #include <algorithm>
 #include <cstring>
+#include <cstdint>
 #include "wmd_internal.h"
 #include "wmd_head_bwd1.h"
 
@@ -1009,6 +1010,9 @@ static bool head_bwd_fused_ok(const wmd_head3x3_bwd_args* a3, const wmd_head1x1_
         if (a3->head[k].nrows != 3 || a3->head[k].nch != 32 || (a3->head[k].ch0 != 0 && a3->head[k].ch0 != 32)) return false;
     if (a3->head[0].ch0 == a3->head[1].ch0) return false;
     const long HW = (long)a3->H * a3->W;
+    // 16-byte accesses of mid, x and dx; 32-bit byte offsets into dy3 and mid (buffer loads)
+    if ((((uintptr_t)a3->mid | (uintptr_t)a1->x | (uintptr_t)a1->dx) & 15) != 0) return false;
+    if ((double)a3->B * 64 * HW * 4 >= 2147483648.0) return false;
     return a3->H >= 4 && a3->W >= 4 && a3->W % 4 == 0 && HW % 64 == 0;
 }
 
