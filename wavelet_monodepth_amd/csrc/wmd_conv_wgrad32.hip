@@ -127,13 +127,11 @@ __global__ __launch_bounds__(WCO* WCI * 128, (WCO * WCI >= 4 ? 2 : 1)) void conv
     };
     auto tile_src = [&](int tile) {
         TileSrc ts;
-        // tiles walk DOWN the image first (round 6): consecutive tiles of a block then share TWO of their four patch rows -- cache
-        // hits -- instead of two halo columns (tx first: every input row was fetched twice, L14 486 MB for 153 MB of operands)
         int t = tile;
-        const int ty = t % a.tiles_y;
-        t /= a.tiles_y;
         const int tx = t % a.tiles_x;
-        const int b = t / a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int b = t / a.tiles_y;
         const int y0 = ty * TH, x0 = tx * TW;
         ts.rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz + (size_t)b * a.Cout * plane), 0, (int)(a.Cout * plane * 4), 0x00020000);
         ts.r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x1 + (size_t)b * a.C1 * plane1), 0, (int)(a.C1 * plane1 * 4), 0x00020000);
