@@ -49,7 +49,10 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--margin", type=float, default=0.0012, help="ms per step a candidate must gain to replace the incumbent")
+    ap.add_argument("--ksplits", default=None, help="comma-separated split counts to offer instead of tuner.KSPLITS")
     args = ap.parse_args()
+    if args.ksplits:
+        tuner.KSPLITS = tuple(int(v) for v in args.ksplits.split(","))
     dev = torch.device("cuda:0")
     committed = json.load(open(os.path.join(ROOT, "profiles", bench.TUNE_CACHE)))
     dec, feats = bench.build_model(dev)

@@ -15,7 +15,7 @@ enabled = os.environ.get("WMD_AUTOTUNE", "1") != "0"
 _cache = {}
 _cache_file = os.environ.get("WMD_TUNE_CACHE")
 _loaded = False
-KSPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
+KSPLITS = (1, 2, 3, 4, 5, 6, 8, 12, 16)
 ranked = {}   # key -> [(config name, ksplit, ms)] of the last isolated sweep, best first (tools/step_tune.py starts from these)
 
 
