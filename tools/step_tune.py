@@ -49,13 +49,22 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--margin", type=float, default=0.0012, help="ms per step a candidate must gain to replace the incumbent")
+    ap.add_argument("--workload", choices=["fwd", "fwd-1024"], default="fwd")
     ap.add_argument("--ksplits", default=None, help="comma-separated split counts to offer instead of tuner.KSPLITS")
     args = ap.parse_args()
     if args.ksplits:
         tuner.KSPLITS = tuple(int(v) for v in args.ksplits.split(","))
     dev = torch.device("cuda:0")
     committed = json.load(open(os.path.join(ROOT, "profiles", bench.TUNE_CACHE)))
-    dec, feats = bench.build_model(dev)
+    if args.workload == "fwd":
+        dec, feats = bench.build_model(dev)
+    else:       # bench.py's fwd_1024x320 extra: R50 channels, batch 8
+        import numpy as np
+        from wavelet_monodepth_amd import synth
+        from wavelet_monodepth_amd.kitti import DepthWaveProgressiveDecoder
+        chans = [64, 256, 512, 1024, 2048]
+        dec = synth.fill_state_dict(DepthWaveProgressiveDecoder(np.array(chans)), seed=1).to(dev)
+        feats = [torch.from_numpy(f).to(dev) for f in synth.encoder_features(8, 320, 1024, chans, seed=1)]
 
     # 1. fresh isolated sweep of every layer -> tuner.ranked
     dec.enable_graph(False)
