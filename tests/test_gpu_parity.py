@@ -833,7 +833,7 @@ def test_dense_decoder_with_postponed_heads_equals_the_level_by_level_forward(de
         assert torch.equal(out[k], ref[k]), key_str(k)
 
 
-@pytest.mark.parametrize("B,H1,W1", [(2, 48, 96), (3, 96, 64), (1, 16, 16), (2, 104, 72)])
+@pytest.mark.parametrize("B,H1,W1", [(2, 48, 96), (3, 96, 64), (1, 16, 16), (2, 104, 72), (12, 96, 320), (2, 160, 512)])
 def test_level1_launch_with_the_coarser_completions_as_a_pyramid(dev, B, H1, W1):
     """Round 6: wmd_head_level_pyramid_fwd -- head_stream_kernel's epilogue waves complete levels 4..2 over every unit's footprint
     (4 x TH/8, 8 x TH/4, 16 x TH/2 pixels under its 32 x TH) before the level's own pipeline starts, handing the low-pass tiles down
